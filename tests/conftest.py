@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "free-surgs_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    import numpy as np
+    from oracle.fsgs_oracle import Oracle
+
+    o = Oracle(np.float32)
+    o.set_threads(1)  # deterministic accumulation order
+    return o
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    import numpy as np
+    from oracle.fsgs_oracle import Oracle
+
+    o = Oracle(np.float64)
+    o.set_threads(1)
+    return o
