@@ -1,0 +1,73 @@
+"""Builds libfsgs_hip.so (all HIP kernels + the C ABI of include/fsgs.h) for gfx950, in-tree.
+
+    python free-surgs_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so lands in free-surgs_amd/fsgs_amd/lib/ and
+travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "fsgs_amd", "lib")
+LIB = os.path.join(OUT_DIR, "libfsgs_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+    "-ffp-contract=on", "-Wno-unused-result", "-DNDEBUG",
+]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "fsgs.h"))
+    hs.append(os.path.abspath(__file__))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", ".o"))
+    if _stale(obj, [src] + headers()):
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OUT_DIR):
+            if f.endswith((".o", ".so")):
+                os.remove(os.path.join(OUT_DIR, f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, sources()))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,150 @@
+// fsgs_device.h -- device-side helpers shared by the gfx950 kernels.
+// Written for CDNA4 only: 64-lane wavefronts, DPP row operations, v_readlane /
+// v_writelane scalar broadcast.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FSGS_TILE 16
+#define FSGS_WAVE 64
+#define FSGS_PX_PER_LANE 4  // one wave owns a 16x16 tile: lane = (x, y0), rows y0, y0+4, y0+8, y0+12
+
+namespace fsgs {
+
+// ---- scalar broadcast of one lane's value (v_readlane_b32: the index must be wave-uniform) ----
+__device__ __forceinline__ float readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// ---- DPP wave64 reductions -------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __int_as_float(t);
+}
+// Sum over the 64 lanes; the total is valid in lane 63 only.
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);       // row_half_mirror
+  v = dpp_add<0x140>(v);       // row_mirror      -> every lane holds its 16-lane row sum
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15    -> rows 1,3 += previous row
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31    -> rows 2,3 += lanes 0..31
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return readlane(wave_sum_lane63(v), 63); }
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_max_i(int v) {
+  int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+  return max(v, t);
+}
+__device__ __forceinline__ int wave_max(int v) {
+  v = dpp_max_i<0xB1>(v);
+  v = dpp_max_i<0x4E>(v);
+  v = dpp_max_i<0x141>(v);
+  v = dpp_max_i<0x140>(v);
+  v = dpp_max_i<0x142, 0xA>(v);
+  v = dpp_max_i<0x143, 0xC>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---- the one definition of "does Gaussian g touch pixel p" ---------------------------------------
+// Forward and backward must take bit-identical skip decisions, so both call this and nothing
+// here may be re-associated or contracted differently between kernels (explicit *_rn ops).
+// power = -1/2 (A dx^2 + C dy^2) - B dx dy; skip power > 0; alpha = min(.99, o e^power);
+// skip alpha < 1/255.
+struct SplatEval {
+  float dx, dy, G, alpha;
+};
+__device__ __forceinline__ bool splat_alpha(float gx, float gy, float A, float B, float Cc, float o, float px,
+                                            float py, SplatEval &e) {
+  e.dx = __fsub_rn(gx, px);
+  e.dy = __fsub_rn(gy, py);
+  float q = __fmaf_rn(__fmul_rn(Cc, e.dy), e.dy, __fmul_rn(__fmul_rn(A, e.dx), e.dx));
+  float power = __fmaf_rn(__fmul_rn(-B, e.dx), e.dy, __fmul_rn(-0.5f, q));
+  if (power > 0.0f) return false;
+  e.G = __expf(power);
+  e.alpha = fminf(0.99f, __fmul_rn(o, e.G));
+  return e.alpha >= (1.0f / 255.0f);
+}
+
+// ---- per-Gaussian geometry --------------------------------------------------------
+struct Mat3 {
+  float m[9];
+};
+// rotation of an UN-normalised quaternion (r,x,y,z), row-major
+__device__ __forceinline__ Mat3 quat_to_R(const float4 q) {
+  float r = q.x, x = q.y, y = q.z, z = q.w;
+  Mat3 R;
+  R.m[0] = 1.f - 2.f * (y * y + z * z); R.m[1] = 2.f * (x * y - r * z);       R.m[2] = 2.f * (x * z + r * y);
+  R.m[3] = 2.f * (x * y + r * z);       R.m[4] = 1.f - 2.f * (x * x + z * z); R.m[5] = 2.f * (y * z - r * x);
+  R.m[6] = 2.f * (x * z - r * y);       R.m[7] = 2.f * (y * z + r * x);       R.m[8] = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+// Sigma = R diag(s)^2 R^T -> (xx,xy,xz,yy,yz,zz)
+__device__ __forceinline__ void cov3d(const float3 s, const Mat3 &R, float *c6) {
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    M[3 * i] = R.m[3 * i] * s.x; M[3 * i + 1] = R.m[3 * i + 1] * s.y; M[3 * i + 2] = R.m[3 * i + 2] * s.z;
+  }
+  c6[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+  c6[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+  c6[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+  c6[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+  c6[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+  c6[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+
+// Everything the EWA projection needs, computed once and reused by forward and backward.
+struct Ewa {
+  float tx, ty, tz;        // clamped view-space mean (t~)
+  float chix, chiy;        // 0 where the 1.3*tanfov clamp was active
+  float M0[3], M1[3];      // rows of M = J * Wv
+  float SM0[3], SM1[3];    // Sigma * M0, Sigma * M1
+  float a, b, c;           // dilated cov2D
+};
+// V: view matrix in transposed storage (V[4*c + r] = maths V[r][c]); t = view-space mean.
+__device__ __forceinline__ void ewa_project(const float *V, const float3 t, const float *c6, float fx, float fy,
+                                            float tanfovx, float tanfovy, Ewa &e) {
+  float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  float txtz = t.x / t.z, tytz = t.y / t.z;
+  e.tx = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  e.ty = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  e.tz = t.z;
+  e.chix = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  e.chiy = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  float J00 = fx / t.z, J02 = -(fx * e.tx) / (t.z * t.z);
+  float J11 = fy / t.z, J12 = -(fy * e.ty) / (t.z * t.z);
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    e.M0[c] = J00 * V[4 * c + 0] + J02 * V[4 * c + 2];
+    e.M1[c] = J11 * V[4 * c + 1] + J12 * V[4 * c + 2];
+  }
+  const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    e.SM0[r] = S[3 * r] * e.M0[0] + S[3 * r + 1] * e.M0[1] + S[3 * r + 2] * e.M0[2];
+    e.SM1[r] = S[3 * r] * e.M1[0] + S[3 * r + 1] * e.M1[1] + S[3 * r + 2] * e.M1[2];
+  }
+  e.a = e.M0[0] * e.SM0[0] + e.M0[1] * e.SM0[1] + e.M0[2] * e.SM0[2] + 0.3f;
+  e.b = e.M0[0] * e.SM1[0] + e.M0[1] * e.SM1[1] + e.M0[2] * e.SM1[2];
+  e.c = e.M1[0] * e.SM1[0] + e.M1[1] * e.SM1[1] + e.M1[2] * e.SM1[2] + 0.3f;
+}
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8 (observed, speed only).
+// Give every XCD one contiguous run of virtual blocks so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
+  const int NXCD = 8;
+  int per = nblocks / NXCD;
+  int lim = per * NXCD;
+  if (bid >= lim) return bid;  // ragged tail stays in place
+  return (bid % NXCD) * per + bid / NXCD;
+}
+
+}  // namespace fsgs

@@ -1,0 +1,120 @@
+"""ctypes binding of libfsgs_hip.so (C ABI declared in include/fsgs.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, the op raises.
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfsgs_hip.so")
+
+FSGS_OK = 0
+FSGS_ERR_INVALID = -1
+FSGS_ERR_CAPACITY = -2
+FSGS_ERR_HIP = -3
+FSGS_ERR_STATE = -4
+MAX_CHANNELS = 8
+
+_ERR_NAMES = {
+    FSGS_ERR_INVALID: "FSGS_ERR_INVALID (bad argument)",
+    FSGS_ERR_CAPACITY: "FSGS_ERR_CAPACITY (buffer too small)",
+    FSGS_ERR_HIP: "FSGS_ERR_HIP (HIP runtime / launch failure)",
+    FSGS_ERR_STATE: "FSGS_ERR_STATE (state buffer does not match)",
+}
+
+
+class FsgsRasterCfg(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32),
+        ("image_width", C.c_int32),
+        ("channels", C.c_int32),
+        ("flags", C.c_int32),
+        ("tanfovx", C.c_float),
+        ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float),
+        ("reserved0", C.c_float),
+        ("bg", C.c_float * MAX_CHANNELS),
+        ("viewmatrix", C.c_float * 16),
+        ("projmatrix", C.c_float * 16),
+    ]
+
+
+class FsgsError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s failed: %s" % (where, _ERR_NAMES.get(code, "error %d" % code))
+        if detail:
+            msg += " -- " + detail
+        super().__init__(msg)
+
+
+_lock = threading.Lock()
+_lib = None
+
+# every exported symbol of include/fsgs.h: (restype, argtypes)
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_PROTOTYPES = {
+    "fsgs_version": (C.c_char_p, []),
+    "fsgs_last_error": (C.c_char_p, []),
+    "fsgs_raster_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
+    "fsgs_raster_forward": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
+         C.POINTER(_i64), _vp],
+    ),
+    "fsgs_raster_backward": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+         _vp, _vp, _sz, _vp],
+    ),
+    "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+}
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (python free-surgs_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libfsgs_hip.so is missing (%s). Build it with `python free-surgs_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for this path." % LIB_PATH
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code, where):
+    if code != FSGS_OK:
+        detail = ""
+        if code == FSGS_ERR_HIP:
+            detail = (load().fsgs_last_error() or b"").decode("utf-8", "replace")
+        raise FsgsError(code, where, detail)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,67 @@
+"""Optical-flow reprojection loss of the tracking step (scene/pose_optimizer.py:42-73,164-218).
+
+The loss splits into a pose-INDEPENDENT part (back-projection of the previous frame's depth,
+duplicate/origin rejection) that the reference recomputes in each of the 50 tracking iterations,
+and a pose-dependent part (transform, project, border mask, L1 against the forward flow).
+`FlowTargets` caches the first per frame; `flow_pose_loss` is the second.
+"""
+import numpy as np
+import torch
+
+
+def backproject_previous(depth_prev, K, w2c_prev, rigid_mask=None):
+    """get_pointcloud over the valid pixels of the previous depth (scene/pose_optimizer.py:42-73,
+    171-181).  Returns world points [M,3] and their pixel indices [M,2] = (v, u)."""
+    depth = depth_prev.float()
+    dm = depth[0]
+    if rigid_mask is not None:
+        dm = dm * rigid_mask
+    idx = torch.stack(torch.where(dm > 0), dim=1)  # (v, u)
+    fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    xx = (idx[:, 1] - cx) / fx
+    yy = (idx[:, 0] - cy) / fy
+    z = depth[0, idx[:, 0], idx[:, 1]]
+    pts_cam = torch.stack((xx * z, yy * z, z), dim=-1)
+    pts4 = torch.cat([pts_cam, torch.ones_like(pts_cam[:, :1])], dim=1)
+    w2c_prev = torch.as_tensor(np.asarray(w2c_prev), dtype=torch.float32, device=depth.device) \
+        if not torch.is_tensor(w2c_prev) else w2c_prev.float()
+    pts = (torch.inverse(w2c_prev) @ pts4.T).T[:, :3]
+    # drop rows whose |round(.,4)| equals another row's or the origin (scene/pose_optimizer.py:60-68)
+    A = torch.abs(torch.round(pts, decimals=4)).float()
+    B = torch.zeros((1, 3), dtype=A.dtype, device=A.device)
+    _, inv, counts = torch.cat([A, B], dim=0).unique(dim=0, return_inverse=True, return_counts=True)
+    dup = torch.isin(inv, torch.where(counts.gt(1))[0])[: len(A)]
+    keep = ~dup
+    return pts[keep], idx[keep]
+
+
+def flow_pose_loss_torch(pts_world, pix_vu, w2c_cur, K, flow_fw, width, height, edge=20):
+    """transform by the current (differentiable) pose, project with K, keep the border-safe points in
+    front of the camera, L1 between (projection - pixel) and the forward flow
+    (scene/pose_optimizer.py:183-216).  flow_fw [2,H,W]: channel 0 = du, 1 = dv."""
+    dev = pts_world.device
+    pts4 = torch.cat([pts_world, torch.ones_like(pts_world[:, :1])], dim=1)
+    cam = (w2c_cur @ pts4.T).T[:, :3]
+    Kt = torch.as_tensor(np.asarray(K), dtype=torch.float32, device=dev) if not torch.is_tensor(K) else K.float()
+    p = (Kt @ cam.T).T
+    pz = p[:, 2:] + 1e-5
+    p = p / pz
+    uv = p[:, :2]
+    m = (uv[:, 0] < width - edge) & (uv[:, 0] > edge) & (uv[:, 1] < height - edge) & (uv[:, 1] > edge) & (pz[:, 0] > 0)
+    uv = uv[m]
+    vu = pix_vu[m]
+    if uv.numel() == 0 or vu.numel() == 0:
+        return torch.tensor(0.0, device=dev)
+    uv_src = vu[:, [1, 0]]
+    proj_flow = uv - uv_src.float()
+    gt = flow_fw[:, uv_src[:, 1], uv_src[:, 0]].permute(1, 0)
+    if torch.isnan(proj_flow).any() or torch.isnan(gt).any():
+        return torch.tensor(0.0, device=dev)
+    return (proj_flow - gt).abs().mean()
+
+
+def projection_flow_loss_torch(depth_prev, w2c_prev, w2c_cur, K, flow_fw, rigid_mask=None):
+    """the whole reference function in one call (scene/pose_optimizer.py:164-218)."""
+    H, W = depth_prev.shape[1], depth_prev.shape[2]
+    pts, vu = backproject_previous(depth_prev, K, w2c_prev, rigid_mask)
+    return flow_pose_loss_torch(pts, vu, w2c_cur, K, flow_fw.float(), W, H)

@@ -1,0 +1,215 @@
+"""Host side of the rasteriser operator: the Python surface of the un-vendored
+`diff_gaussian_rasterization` package, bound to the HIP C ABI.
+
+Reference call sites: gaussian_renderer/__init__.py:68-69,131 (forward, 3 return values),
+scene/pose_optimizer.py:619-632 (settings tuple), train.py:337 (`._replace`).
+"""
+from typing import NamedTuple
+
+import ctypes as C
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---- host copies of the tiny camera tensors, cached so a render does not sync on them ----------
+_host_cache = {}
+
+
+def _host_floats(t, n):
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+    hit = _host_cache.get(key)
+    if hit is None:
+        if len(_host_cache) > 256:
+            _host_cache.clear()
+        hit = [float(x) for x in t.detach().reshape(-1).to("cpu", torch.float32).tolist()]
+        _host_cache[key] = hit
+    if len(hit) < n:
+        raise ValueError("camera tensor has %d elements, expected >= %d" % (len(hit), n))
+    return hit
+
+
+def make_cfg(settings, channels):
+    cfg = _lib.FsgsRasterCfg()
+    cfg.image_height = int(settings.image_height)
+    cfg.image_width = int(settings.image_width)
+    cfg.channels = int(channels)
+    cfg.flags = 0
+    cfg.tanfovx = float(settings.tanfovx)
+    cfg.tanfovy = float(settings.tanfovy)
+    cfg.scale_modifier = float(settings.scale_modifier)
+    bg = _host_floats(settings.bg, 1)
+    for i in range(_lib.MAX_CHANNELS):
+        # channels beyond len(bg) (fused depth/silhouette planes) share the last background value
+        cfg.bg[i] = bg[i] if i < len(bg) else bg[-1]
+    vm = _host_floats(settings.viewmatrix, 16)
+    pm = _host_floats(settings.projmatrix, 16)
+    for i in range(16):
+        cfg.viewmatrix[i] = vm[i]
+        cfg.projmatrix[i] = pm[i]
+    return cfg
+
+
+# ---- (tile, Gaussian) pair capacity: grow-only estimate per problem shape ----------------------
+_capacity = {}
+
+
+def _capacity_for(P, W, H):
+    return _capacity.get((P, W, H), max(1 << 16, 8 * P))
+
+
+def _f32c(t):
+    return t.detach().contiguous().to(torch.float32)
+
+
+class RasterState:
+    """What forward leaves behind for backward (UPSTREAM: geom/binning/img buffers + num_rendered)."""
+
+    __slots__ = ("buf", "state_bytes", "max_pairs", "num_rendered", "cfg", "P")
+
+
+def raster_forward(cfg, means3D, colors, opacities, scales, rotations):
+    """Launch fsgs_raster_forward; returns (color, depth, radii, RasterState)."""
+    lib = _lib.load()
+    if not means3D.is_cuda:
+        raise RuntimeError("fsgs rasteriser needs CUDA/HIP tensors; there is no CPU fallback")
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W, Cc = cfg.image_height, cfg.image_width, cfg.channels
+    out_color = torch.empty((Cc, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    cap = _capacity_for(P, W, H)
+    nr = C.c_int64(0)
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream()
+        for _attempt in range(3):
+            sb, xb = C.c_size_t(0), C.c_size_t(0)
+            _lib.check(lib.fsgs_raster_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_raster_sizes")
+            state = torch.empty((sb.value,), dtype=torch.uint8, device=dev)
+            scratch = torch.empty((xb.value,), dtype=torch.uint8, device=dev)
+            rc = lib.fsgs_raster_forward(
+                C.byref(cfg), P, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opacities), _lib.ptr(scales),
+                _lib.ptr(rotations), _lib.ptr(out_color), _lib.ptr(out_depth), _lib.ptr(radii), _lib.ptr(state),
+                sb.value, _lib.ptr(scratch), xb.value, cap, C.byref(nr), stream,
+            )
+            if rc == _lib.FSGS_ERR_CAPACITY and nr.value > cap:
+                cap = int(nr.value * 1.25) + 1024
+                _capacity[(P, W, H)] = cap
+                continue
+            _lib.check(rc, "fsgs_raster_forward")
+            break
+        else:
+            raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_raster_forward")
+    st = RasterState()
+    st.buf, st.state_bytes, st.max_pairs, st.num_rendered, st.cfg, st.P = state, sb.value, cap, int(nr.value), cfg, P
+    return out_color, out_depth, radii, st
+
+
+def raster_backward(st, means3D, colors, scales, rotations, radii, grad_color):
+    lib = _lib.load()
+    dev = means3D.device
+    P, Cc = st.P, st.cfg.channels
+    z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    dmeans2D, dcolors, dopac = z(P, 3), z(P, Cc), z(P, 1)
+    dmeans3D, dscales, drots = z(P, 3), z(P, 3), z(P, 4)
+    if P == 0:
+        return dmeans2D, dcolors, dopac, dmeans3D, dscales, drots
+    scratch = torch.empty((P * 32 + 256,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.fsgs_raster_backward(
+            C.byref(st.cfg), P, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(scales), _lib.ptr(rotations),
+            _lib.ptr(radii), _lib.ptr(st.buf), st.state_bytes, st.max_pairs, st.num_rendered, _lib.ptr(grad_color),
+            _lib.ptr(dmeans2D), _lib.ptr(dcolors), _lib.ptr(dopac), _lib.ptr(dmeans3D), _lib.ptr(dscales),
+            _lib.ptr(drots), _lib.ptr(scratch), scratch.numel(), _lib.current_stream(),
+        )
+    _lib.check(rc, "fsgs_raster_backward")
+    return dmeans2D, dcolors, dopac, dmeans3D, dscales, drots
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        if sh is not None and sh.numel() != 0:
+            raise NotImplementedError(
+                "SH evaluation inside the rasteriser is not on the Free-SurGS path "
+                "(shs=None, scene/gaussian_model.py:325); pass colors_precomp")
+        if cov3Ds_precomp is not None and cov3Ds_precomp.numel() != 0:
+            raise NotImplementedError(
+                "cov3D_precomp is not on the Free-SurGS path (cov3D_precomp=None, "
+                "scene/gaussian_model.py:309); pass scales and rotations")
+        P = means3D.shape[0]
+        m3, col = _f32c(means3D), _f32c(colors_precomp).reshape(P, -1)
+        op, sc, rot = _f32c(opacities).reshape(P), _f32c(scales), _f32c(rotations)
+        cfg = make_cfg(raster_settings, col.shape[1] if P > 0 else 3)
+        color, depth, radii, st = raster_forward(cfg, m3, col, op, sc, rot)
+        ctx.st = st
+        ctx.save_for_backward(m3, col, sc, rot, radii)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth):
+        # the depth-fork's third output is not back-propagated; Free-SurGS never puts it in a loss
+        # (gaussian_renderer/__init__.py:68-70)
+        m3, col, sc, rot, radii = ctx.saved_tensors
+        gc = _f32c(grad_color)
+        dm2, dcol, dop, dm3, dsc, drot = raster_backward(ctx.st, m3, col, sc, rot, radii, gc)
+        ctx.st = None
+        return dm3, dm2, None, dcol, dop, dsc, drot, None, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """View-frustum test of UPSTREAM R10 (not called by Free-SurGS): z > 0.2 in view space."""
+        with torch.no_grad():
+            V = self.raster_settings.viewmatrix.reshape(4, 4)
+            p = positions @ V[:3, :3] + V[3, :3]
+            return p[:, 2] > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None
+        ):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        return rasterize_gaussians(
+            means3D, means2D,
+            empty if shs is None else shs,
+            empty if colors_precomp is None else colors_precomp,
+            opacities,
+            empty if scales is None else scales,
+            empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp,
+            self.raster_settings,
+        )

@@ -1,0 +1,116 @@
+/*
+ * fsgs.h -- C ABI of libfsgs_hip.so, the MI355X-native (gfx950) replacement of the
+ * native operators on Free-SurGS's splat + pose-optimisation hot path.
+ *
+ * Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ * unless marked [host].  Nothing is allocated, freed or kept between calls by the
+ * library; all calls are asynchronous on `stream` except where noted and are
+ * re-entrant (two Python threads -- trainer and viewer -- may interleave,
+ * train.py:150,166-200,227-231).  Return value: 0 on success, negative FSGS_ERR_*.
+ *
+ * Reference interfaces replaced (file:line in /root/reference; "UPSTREAM" = the
+ * un-vendored diff_gaussian_rasterization package, requirements.txt:26):
+ *   fsgs_raster_forward / _backward   <- UPSTREAM _C.rasterize_gaussians[_backward],
+ *                                        called via GaussianRasterizer at
+ *                                        gaussian_renderer/__init__.py:68-69,131
+ *   fsgs_knn_meandist2                <- simple_knn._C.distCUDA2,
+ *                                        submodules/simple-knn/ext.cpp:15-17,
+ *                                        spatial.cu:15-26, simple_knn.cu:185-221
+ *   fsgs_render_forward / _backward   <- gaussian_renderer.render() body,
+ *                                        gaussian_renderer/__init__.py:49-92 (fused:
+ *                                        transform_to_frame + activations + eval_sh +
+ *                                        both rasteriser passes in one binning)
+ *   fsgs_photometric_loss_*           <- utils/loss_utils.py:41-96 (rgb_loss_func)
+ *   fsgs_pearson_*                    <- utils/loss_utils.py:98-127
+ *   fsgs_flow_pose_loss_*             <- scene/pose_optimizer.py:164-218
+ *   fsgs_adam_step                    <- torch.optim.Adam steps of train.py:194,272
+ */
+#ifndef FSGS_H
+#define FSGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *fsgs_stream_t; /* hipStream_t */
+
+enum {
+  FSGS_OK = 0,
+  FSGS_ERR_INVALID = -1,   /* bad argument (null pointer, channel count, size) */
+  FSGS_ERR_CAPACITY = -2,  /* state/scratch buffer too small; *num_rendered holds the need */
+  FSGS_ERR_HIP = -3,       /* a HIP runtime call or kernel launch failed */
+  FSGS_ERR_STATE = -4      /* state buffer does not belong to a completed forward */
+};
+
+#define FSGS_MAX_CHANNELS 8
+
+/* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
+ * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
+ * m[4*k + j] = M[j][k] (scene/pose_optimizer.py:604,617-618). */
+typedef struct FsgsRasterCfg {
+  int32_t image_height;
+  int32_t image_width;
+  int32_t channels;        /* colour channels of colors_precomp: 1..FSGS_MAX_CHANNELS (reference: 3) */
+  int32_t flags;           /* reserved, 0 */
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  float reserved0;
+  float bg[FSGS_MAX_CHANNELS];
+  float viewmatrix[16];
+  float projmatrix[16];
+} FsgsRasterCfg;
+
+/* Library / build identification. */
+const char *fsgs_version(void);
+const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP */
+
+/* ---- rasteriser (drop-in operator boundary) -------------------------------- */
+
+/* Bytes of the per-call buffers for P Gaussians, a W x H image and room for
+ * `max_pairs` (tile, Gaussian) pairs.  `state` must stay alive and untouched from
+ * forward to its backward (it plays the role of UPSTREAM's geomBuffer /
+ * binningBuffer / imgBuffer); `scratch` is only used during forward. */
+int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs,
+                      size_t *state_bytes, size_t *scratch_bytes);
+
+/* Forward: kernels R1-R6 of SURVEY.md s2.1.
+ *  means3D[P,3] colors[P,C] opacities[P] scales[P,3] rotations[P,4] (r,x,y,z), fp32 row-major.
+ *  out_color[C,H,W] planar, out_depth[H,W] (depth-fork third output), radii[P] int32.
+ *  num_rendered [host]: receives R = sum of tiles touched.  The call synchronises the
+ *  stream once to read R (as UPSTREAM does); if R > max_pairs it returns
+ *  FSGS_ERR_CAPACITY without rendering and the caller retries with bigger buffers. */
+int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P,
+                        const float *means3D, const float *colors, const float *opacities,
+                        const float *scales, const float *rotations,
+                        float *out_color, float *out_depth, int32_t *radii,
+                        void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
+                        int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream);
+
+/* Backward: kernels R7-R9.  dL_dcolor[C,H,W].  Outputs are overwritten:
+ *  dmeans2D[P,3] (NDC-scaled screen gradient, z = 0), dcolors[P,C], dopacities[P],
+ *  dmeans3D[P,3], dscales[P,3], drotations[P,4].  `scratch` >= P*16 bytes. */
+int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P,
+                         const float *means3D, const float *colors,
+                         const float *scales, const float *rotations, const int32_t *radii,
+                         const void *state, size_t state_bytes,
+                         int64_t max_pairs, int64_t num_rendered, /* as passed to / returned by forward */
+                         const float *dL_dcolor,
+                         float *dmeans2D, float *dcolors, float *dopacities,
+                         float *dmeans3D, float *dscales, float *drotations,
+                         void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+
+/* ---- simple-knn -------------------------------------------------------------- */
+
+/* Mean squared distance to the 3 nearest neighbours, exact (distCUDA2).
+ * points[P,3] -> out[P].  Call with scratch == NULL to query *scratch_bytes. */
+int fsgs_knn_meandist2(int P, const float *points, float *out,
+                       void *scratch, size_t *scratch_bytes, fsgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSGS_H */

@@ -1,0 +1,135 @@
+"""The host-side restatements (torch statements of the reference's glue maths) against golden
+vectors captured from the reference's own Python (tests/golden/make_golden.py).
+These statements are the numerics references of the fused HIP kernels' GPU tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd import flow, losses, model, pose, sh
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+T = lambda a: torch.tensor(np.asarray(a))
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_eval_sh_and_its_gradients(deg):
+    g = _load("eval_sh.npz")
+    s = T(g["sh"]).requires_grad_(True)
+    d = T(g["dirs"]).requires_grad_(True)
+    rgb = torch.clamp_min(sh.eval_sh(deg, s, d) + 0.5, 0.0)
+    (rgb * T(g["w"])).sum().backward()
+    np.testing.assert_allclose(rgb.detach().numpy(), g[f"rgb{deg}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.grad.numpy(), g[f"dsh{deg}"], rtol=1e-5, atol=1e-6)
+    if deg > 0:
+        np.testing.assert_allclose(d.grad.numpy(), g[f"ddir{deg}"], rtol=1e-4, atol=2e-5)
+
+
+def test_rgb_loss_ssim_l1():
+    g = _load("rgb_loss.npz")
+    gt = T(g["gt"])
+    for tag, m in (("nomask", None), ("mask", T(g["mask"]))):
+        x = T(g["img"]).requires_grad_(True)
+        l = losses.rgb_loss_torch(x, gt, mask=m)
+        l.backward()
+        np.testing.assert_allclose(l.item(), g[f"loss_{tag}"], rtol=1e-5)
+        np.testing.assert_allclose(x.grad.numpy(), g[f"grad_{tag}"], rtol=1e-4, atol=1e-8)
+    x = T(g["img"]).requires_grad_(True)
+    s = losses.ssim_torch(x, gt)
+    s.backward()
+    np.testing.assert_allclose(s.item(), g["ssim"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["ssim_grad"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(losses.l1_loss(T(g["img"]), gt).item(), g["l1"], rtol=1e-6)
+
+
+def test_pearson_and_local_pearson():
+    g = _load("pearson.npz")
+    src = T(g["src"])
+    x = T(g["tgt"]).requires_grad_(True)
+    l = losses.pearson_torch(src, x)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["pearson"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["pearson_grad_tgt"], rtol=1e-4, atol=1e-9)
+    x = T(g["src"]).requires_grad_(True)
+    losses.pearson_torch(x, T(g["tgt"])).backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["pearson_grad_src"], rtol=1e-4, atol=1e-9)
+    # local: same corners the reference drew; also our draw consumes the RNG identically
+    x = T(g["tgt"]).requires_grad_(True)
+    corners = (T(g["lp_x0"]), T(g["lp_y0"]))
+    l = losses.local_pearson_torch(src, x, int(g["lp_box"]), float(g["lp_p"]), corners)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["lp_loss"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["lp_grad_tgt"], rtol=1e-4, atol=1e-9)
+    torch.manual_seed(3)
+    x0, y0 = losses.draw_patch_corners(src.shape[0], src.shape[1], int(g["lp_box"]), float(g["lp_p"]), "cpu")
+    np.testing.assert_array_equal(x0.numpy(), g["lp_x0"])
+    np.testing.assert_array_equal(y0.numpy(), g["lp_y0"])
+
+
+def test_learnpose_forward_and_gradients():
+    g = _load("pose_glue.npz")
+    for cam in range(g["r"].shape[2]):
+        r = T(g["r"]).requires_grad_(True)
+        t = T(g["t"]).requires_grad_(True)
+        w2c = pose.pose_to_w2c(r, t, cam)
+        (w2c * T(g["wsum"])).sum().backward()
+        np.testing.assert_allclose(w2c.detach().numpy(), g[f"w2c_{cam}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r.grad.numpy(), g[f"dr_{cam}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(t.grad.numpy(), g[f"dt_{cam}"], rtol=1e-5, atol=1e-7)
+
+
+def test_transform_to_frame_detach_semantics():
+    g = _load("pose_glue.npz")
+    for gg, cg in ((True, True), (True, False), (False, True)):
+        a = T(g["ttf_xyz"]).requires_grad_(True)
+        m = T(g["ttf_w2c"]).requires_grad_(True)
+        y = pose.transform_to_frame(a, m, gg, cg)
+        (y * torch.linspace(-1, 1, y.numel()).reshape(y.shape)).sum().backward()
+        key = f"{int(gg)}{int(cg)}"
+        np.testing.assert_allclose(y.detach().numpy(), g["ttf_" + key], rtol=1e-5, atol=1e-6)
+        dx = a.grad.numpy() if a.grad is not None else np.zeros((64, 3), np.float32)
+        dm = m.grad.numpy() if m.grad is not None else np.zeros((4, 4), np.float32)
+        np.testing.assert_allclose(dx, g["ttf_dx_" + key], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dm[:3], g["ttf_dm_" + key][:3], rtol=1e-4, atol=1e-5)
+
+
+def test_small_helpers():
+    g = _load("pose_glue.npz")
+    from fsgs_amd import synth
+
+    for q, R in zip(g["br_q"], g["br_R"]):
+        np.testing.assert_allclose(synth.quat_to_rot(q), R, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(model.inverse_sigmoid(T(g["inv_sigmoid_in"])).numpy(), g["inv_sigmoid_out"], rtol=1e-6)
+    lr = [model.expon_lr(int(s), 1.6e-4 * 5, 1.6e-6 * 5, 30000) for s in g["lr_steps"]]
+    np.testing.assert_allclose(lr, g["lr_vals"], rtol=1e-12)
+
+
+def test_projection_flow_loss():
+    g = _load("flow_loss.npz")
+    for tag, rm in (("rigid", T(g["rigid"])), ("norigid", None)):
+        r = T(g["q"]).reshape(1, 4, 1).clone().requires_grad_(True)
+        t = T(g["t"]).reshape(3, 1).clone().requires_grad_(True)
+        w2c = pose.pose_to_w2c(r, t, 0)
+        w2c.retain_grad()
+        l = flow.projection_flow_loss_torch(T(g["depth_prev"]), g["w2c_prev"], w2c, g["K"], T(g["flow"])[0], rm)
+        l.backward()
+        np.testing.assert_allclose(l.item(), g[f"loss_{tag}"], rtol=1e-5)
+        np.testing.assert_allclose(w2c.grad.numpy()[:3], g[f"dw2c_{tag}"][:3], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(r.grad.numpy(), g[f"dr_{tag}"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(t.grad.numpy(), g[f"dt_{tag}"], rtol=1e-3, atol=1e-4)
+
+
+def test_depth_silhouette_pseudo_colours_use_the_stored_matrix_rows():
+    g = _load("depth_sil.npz")
+    pts = T(g["pts"])
+    V = T(g["viewmatrix_stored"])
+    z = (pts @ V[2, :3].reshape(3, 1) + V[2, 3]).reshape(-1)
+    np.testing.assert_allclose(z.numpy(), g["ds_stored"][:, 0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose((z * z).numpy(), g["ds_stored"][:, 2], rtol=1e-5, atol=1e-6)
+    assert (g["ds_stored"][:, 1] == 1).all()
+    np.testing.assert_allclose(pts[:, 2].numpy(), g["ds_identity"][:, 0], rtol=1e-6)
