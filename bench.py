@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native Free-SurGS hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): train iterations/s at 1280x1024 with 300k Gaussians (config C2).
+A "step" is one mapping iteration of the reference (train.py:236-272, global_run view = 1):
+render (RGB pass + depth/silhouette pass) -> 5*rgb_loss + 0.05*pearson + 0.15*local_pearson ->
+backward through both passes -> densification statistics -> Adam step on all 59 floats/Gaussian.
+With N ranks every rank optimises its own camera of the sequence over the shared cloud and the
+Gaussian gradients are all-reduced (RCCL) each step: N views per step, weak scaling.
+
+One JSON line on rank 0, with `roofline` (dominant kernel: blend_bwd, HIP events on the launching
+stream) and `cpu_baseline` (the CPU oracle's rasteriser fwd+bwd, rank 0 / N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "free-surgs_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (W, H, P, scene)
+    "C1": (640, 512, 20_000, "init"),
+    "C2": (1280, 1024, 300_000, "trained"),
+    "C4": (1920, 1080, 1_000_000, "trained"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_problem(cfg_name, device, rank, world, n_frames=8):
+    from fsgs_amd import synth
+    from fsgs_amd.model import GaussianCloud
+    from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
+    from simple_knn._C import distCUDA2
+
+    W, H, P, kind = CONFIGS[cfg_name]
+    knn = lambda pts: distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
+    if kind == "init":
+        sc = synth.init_scene(W, H, P, seed=0, knn_fn=knn)
+    else:
+        sc = synth.trained_like_scene(W, H, P, seed=0, knn_fn=knn)
+    cam = synth.make_camera(W, H)
+    pc = GaussianCloud(sc, sh_degree=3, device=device, scene_radius=float(sc["depth_map"].max()) / 2.0)
+    pc.cam = settings_from_cam(cam, device)
+    pc.active_sh_degree = 3 if kind == "trained" else 0
+    pc.training_setup(eps=1e-8)  # global_run re-creates Adam with default eps (scene/gaussian_model.py:378)
+    poses = PoseTrack(n_frames, device)
+    rng = np.random.default_rng(1234)
+    for i in range(1, n_frames):  # a short camera sweep around frame 0
+        q = np.array([1.0, 0, 0, 0]) + 0.01 * rng.standard_normal(4)
+        poses.set_pose(i, q, 0.02 * rng.standard_normal(3))
+    # per-frame targets resident in HBM: a colour image and a mono-depth map
+    img = torch.tensor(sc["image"], device=device)
+    dep = torch.tensor(sc["depth_map"], device=device)
+    frames = FrameData([img + 0.01 * i for i in range(n_frames)], [dep * (1 + 0.01 * i) for i in range(n_frames)])
+    return pc, poses, frames, cam, sc
+
+
+def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
+    """The oracle (kind "port": the reference has no CPU path and its rasteriser source is absent) timed on
+    the host cores: rasteriser fwd + bwd of the RGB pass and of the depth/silhouette pass = the
+    rasteriser part of ONE step (losses and Adam are left out, which only flatters the CPU)."""
+    from fsgs_amd import synth
+    from oracle.fsgs_oracle import Oracle
+
+    o = Oracle(np.float32)
+    o.set_threads(0)
+    cores = o.max_threads()
+    s, r, op = synth.activate(sc)
+    col = np.clip(sc["_features_dc"][:, 0, :] * synth.SH_C0 + 0.5, 0, None).astype(np.float32)
+    z = sc["_xyz"][:, 2:3]
+    dcol = np.concatenate([z, np.ones_like(z), z * z], 1).astype(np.float32)
+    H, W = cam["image_height"], cam["image_width"]
+    dL = (np.random.default_rng(0).uniform(-1, 1, (3, H, W)) / (3 * H * W)).astype(np.float32)
+    t0 = time.time()
+    n = 0
+    R = 0
+    while True:
+        for c in (col, dcol):
+            img, dep, radii, st = o.raster_forward(cam, sc["_xyz"], c, op.reshape(-1), s, r)
+            o.raster_backward(st, dL)
+            R = st.num_rendered
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": "%d full step(s) of the rasteriser part only (2 passes fwd+bwd, %dx%d, P=%d, R=%d), "
+                      "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--two-pass", action="store_true", help="unfused render (two rasteriser calls)")
+    ap.add_argument("--torch-losses", action="store_true", help="plain-PyTorch losses instead of the HIP kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
+    args = ap.parse_args()
+
+    from fsgs_amd import _lib, dist as fdist
+    from fsgs_amd.trainer import mapping_step
+
+    rank, world, local = fdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    _lib.load()
+
+    pc, poses, frames, cam, sc = build_problem(args.config, device, rank, world)
+    W, H, P, _ = CONFIGS[args.config]
+    fused = not args.two_pass
+    hip_losses = not args.torch_losses
+    # which implementation pieces exist in this build (recorded in the JSON, never silently swapped)
+    try:
+        from fsgs_amd import render_ops  # noqa: F401
+    except ImportError:
+        fused = False
+    try:
+        from fsgs_amd import loss_ops  # noqa: F401
+    except ImportError:
+        hip_losses = False
+
+    bucket = fdist.GradBucket(pc) if world > 1 else None
+    n_frames = len(frames.colors)
+
+    def one_step(it):
+        ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
+        if bucket is not None:
+            bucket.attach(pc)
+        sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None
+        return mapping_step(pc, poses, frames, [ts], fused=fused, hip_losses=hip_losses, grad_sync=sync)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        one_step(it)
+    barrier()
+    dominant = "blend_bwd"
+    _lib.profile_enable(None if args.profile_all else [dominant, "blend_fwd"])
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss, pkg = one_step(args.warmup + it)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable([])
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel (per-unit bytes stated in DESIGN.md) ----
+    from fsgs_amd import rasterizer
+
+    R = int(getattr(rasterizer, "last_num_rendered", 0) or 0)
+    C = 6 if fused else 3
+    ms_total, launches = prof.get(dominant, (0.0, 0))
+    roofline = None
+    if launches:
+        # blend_bwd algorithmic bytes per launch: R*(4 idx + 24 xy/conic/opacity + 4C colour) +
+        # HW*(4C dL/dpixel + 8 final_T/n_contrib) + P*4*(6 + C) accumulated gradients
+        b_alg = R * (4 + 24 + 4 * C) + H * W * (4 * C + 8) + P * 4 * (6 + C)
+        avg_s = ms_total / launches / 1e3
+        ach = b_alg / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": ms_total / launches,
+                    "launches": launches, "algorithmic_bytes": b_alg, "num_rendered": R, "channels": C}
+    kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sc, cam, pc.active_sh_degree)
+
+    if rank == 0:
+        iters = args.steps * world
+        out = {
+            "metric": "train_iters_per_sec", "value": iters / dt, "unit": "iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: mapping iteration, %dx%d, %d Gaussians (%s scene), 1 camera/rank" % (
+                args.config, W, H, P, CONFIGS[args.config][3]),
+                "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
+                "parallelism": "dp%d" % world, "loss": float(loss)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,9 @@
 // common.hip -- version string and error plumbing of libfsgs_hip.so
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "fsgs_host.h"
 
 namespace fsgs {
@@ -15,9 +18,76 @@ int fsgs_fail_hip(hipError_t e, const char *expr, const char *file, int line) {
   (void)hipGetLastError();
   return FSGS_ERR_HIP;
 }
+
+// ---- profiler ---------------------------------------------------------------------------------
+static const char *kProfNames[PROF_COUNT] = {
+    "preprocess_fwd", "sort_depth", "scan_tiles", "emit_pairs", "sort_tile", "tile_ranges", "blend_fwd",
+    "blend_bwd", "preprocess_bwd", "knn", "loss_rgb_fwd", "loss_rgb_bwd", "pearson", "adam", "render_pre_fwd",
+    "render_pre_bwd", "flow_loss"};
+struct ProfRec {
+  int id;
+  hipEvent_t a, b;
+  bool closed;
+};
+static std::mutex g_prof_mu;
+static uint64_t g_prof_mask = 0;
+static std::vector<ProfRec> g_prof_recs;
+static double g_prof_ms[PROF_COUNT];
+static long long g_prof_n[PROF_COUNT];
+
+bool prof_enabled(int id) { return (g_prof_mask >> id) & 1ull; }
+void prof_record(int id, hipStream_t s, bool begin) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (begin) {
+    ProfRec r;
+    r.id = id;
+    r.closed = false;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, s);
+    g_prof_recs.push_back(r);
+  } else {
+    for (size_t i = g_prof_recs.size(); i-- > 0;)
+      if (g_prof_recs[i].id == id && !g_prof_recs[i].closed) {
+        hipEventRecord(g_prof_recs[i].b, s);
+        g_prof_recs[i].closed = true;
+        break;
+      }
+  }
+}
+static void prof_drain() {
+  for (auto &r : g_prof_recs) {
+    if (r.closed && hipEventSynchronize(r.b) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        g_prof_ms[r.id] += ms;
+        g_prof_n[r.id] += 1;
+      }
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof_recs.clear();
+}
 }  // namespace fsgs
 
 extern "C" {
+int fsgs_profile_enable(uint64_t mask) {
+  std::lock_guard<std::mutex> lk(fsgs::g_prof_mu);
+  fsgs::prof_drain();
+  for (int i = 0; i < fsgs::PROF_COUNT; i++) { fsgs::g_prof_ms[i] = 0; fsgs::g_prof_n[i] = 0; }
+  fsgs::g_prof_mask = mask;
+  return FSGS_OK;
+}
+int fsgs_profile_count(void) { return fsgs::PROF_COUNT; }
+const char *fsgs_profile_name(int id) { return (id >= 0 && id < fsgs::PROF_COUNT) ? fsgs::kProfNames[id] : ""; }
+int fsgs_profile_read(int id, double *total_ms, int64_t *launches) {
+  if (id < 0 || id >= fsgs::PROF_COUNT || !total_ms || !launches) return FSGS_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(fsgs::g_prof_mu);
+  fsgs::prof_drain();
+  *total_ms = fsgs::g_prof_ms[id];
+  *launches = fsgs::g_prof_n[id];
+  return FSGS_OK;
+}
 const char *fsgs_version(void) { return "fsgs-hip 0.1 (gfx950)"; }
 const char *fsgs_last_error(void) { return fsgs::last_error_buffer(); }
 }

@@ -24,6 +24,41 @@ struct Carver {
   size_t total() const { return off + 256; }
 };
 
+// ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline) ----
+enum ProfId {
+  PROF_PREPROCESS_FWD = 0,
+  PROF_SORT_DEPTH,
+  PROF_SCAN,
+  PROF_EMIT,
+  PROF_SORT_TILE,
+  PROF_RANGES,
+  PROF_BLEND_FWD,
+  PROF_BLEND_BWD,
+  PROF_PREPROCESS_BWD,
+  PROF_KNN,
+  PROF_LOSS_RGB_FWD,
+  PROF_LOSS_RGB_BWD,
+  PROF_PEARSON,
+  PROF_ADAM,
+  PROF_RENDER_PRE_FWD,
+  PROF_RENDER_PRE_BWD,
+  PROF_FLOW,
+  PROF_COUNT
+};
+bool prof_enabled(int id);
+void prof_record(int id, hipStream_t s, bool begin);
+struct ProfScope {
+  int id;
+  hipStream_t s;
+  bool on;
+  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(prof_enabled(id_)) {
+    if (on) prof_record(id, s, true);
+  }
+  ~ProfScope() {
+    if (on) prof_record(id, s, false);
+  }
+};
+
 }  // namespace fsgs
 
 #define FSGS_HIP(expr)                                                         \

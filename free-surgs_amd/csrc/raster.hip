@@ -629,27 +629,46 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   FSGS_HIP(hipMemsetAsync(ranges, 0, sizeof(int2) * (size_t)ntiles, stream));
   uint32_t R = 0;
   if (P > 0) {
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, opacities,
-                       scales, rotations, xy, co, depth, radii, tiles, rect, key_a, idx_a);
+    {
+      ProfScope ps(PROF_PREPROCESS_FWD, stream);
+      hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D,
+                         opacities, scales, rotations, xy, co, depth, radii, tiles, rect, key_a, idx_a);
+    }
     FSGS_HIP(hipGetLastError());
-    FSGS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, key_a, key_b, idx_a, idx_b, (size_t)P, 0, 32, stream));
+    {
+      ProfScope ps(PROF_SORT_DEPTH, stream);
+      FSGS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, key_a, key_b, idx_a, idx_b, (size_t)P, 0, 32, stream));
+    }
     TilesInDepthOrder f{tiles};
     auto it = rocprim::make_transform_iterator(idx_b, f);
-    FSGS_HIP(rocprim::inclusive_scan(temp, temp_bytes, it, incl, (size_t)P, rocprim::plus<uint32_t>(), stream));
+    {
+      ProfScope ps(PROF_SCAN, stream);
+      FSGS_HIP(rocprim::inclusive_scan(temp, temp_bytes, it, incl, (size_t)P, rocprim::plus<uint32_t>(), stream));
+    }
     FSGS_HIP(hipMemcpyAsync(&R, incl + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     FSGS_HIP(hipStreamSynchronize(stream));  // the one host sync (UPSTREAM R2 does the same)
   }
   *num_rendered = (int64_t)R;
   if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
   if (R > 0) {
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, idx_b, incl, tiles,
-                       rect, pk_a, pv_a);
+    {
+      ProfScope ps(PROF_EMIT, stream);
+      hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, idx_b, incl,
+                         tiles, rect, pk_a, pv_a);
+    }
     FSGS_HIP(hipGetLastError());
-    FSGS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, pk_a, pk_b, pv_a, plist, (size_t)R, 0, tile_bits(ntiles),
-                                       stream));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, pk_b, ranges);
+    {
+      ProfScope ps(PROF_SORT_TILE, stream);
+      FSGS_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, pk_a, pk_b, pv_a, plist, (size_t)R, 0, tile_bits(ntiles),
+                                         stream));
+    }
+    {
+      ProfScope ps(PROF_RANGES, stream);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, pk_b, ranges);
+    }
     FSGS_HIP(hipGetLastError());
   }
+  ProfScope ps_blend(PROF_BLEND_FWD, stream);
   switch (C) {
     case 1: launch_blend_fwd<1>(cam, ntiles, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_depth, stream); break;
     case 3: launch_blend_fwd<3>(cam, ntiles, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_depth, stream); break;
@@ -690,6 +709,7 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   FSGS_HIP(hipMemsetAsync(grad_acc, 0, (size_t)P * kAccStride * sizeof(float), stream));
   FSGS_HIP(hipMemsetAsync(dcolors, 0, (size_t)P * C * sizeof(float), stream));
   if (num_rendered > 0) {
+    ProfScope ps(PROF_BLEND_BWD, stream);
     switch (C) {
       case 1: launch_blend_bwd<1>(cam, ntiles, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, grad_acc, dcolors, stream); break;
       case 3: launch_blend_bwd<3>(cam, ntiles, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, grad_acc, dcolors, stream); break;
@@ -697,8 +717,11 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
     }
     FSGS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, scales,
-                     rotations, radii, grad_acc, dmeans2D, dopacities, dmeans3D, dscales, drotations);
+  {
+    ProfScope ps(PROF_PREPROCESS_BWD, stream);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, scales,
+                       rotations, radii, grad_acc, dmeans2D, dopacities, dmeans3D, dscales, drotations);
+  }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
 }

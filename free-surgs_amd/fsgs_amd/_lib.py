@@ -58,6 +58,10 @@ _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 _PROTOTYPES = {
     "fsgs_version": (C.c_char_p, []),
     "fsgs_last_error": (C.c_char_p, []),
+    "fsgs_profile_enable": (_i, [C.c_uint64]),
+    "fsgs_profile_count": (_i, []),
+    "fsgs_profile_name": (C.c_char_p, [_i]),
+    "fsgs_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "fsgs_raster_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
     "fsgs_raster_forward": (
         _i,
@@ -118,3 +122,28 @@ def current_stream():
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_enable(names=None):
+    """Enable HIP-event timing for the named kernels (None = all, [] = off)."""
+    lib = load()
+    n = lib.fsgs_profile_count()
+    all_names = [lib.fsgs_profile_name(i).decode() for i in range(n)]
+    mask = 0
+    for i, nm in enumerate(all_names):
+        if names is None or nm in names:
+            mask |= 1 << i
+    lib.fsgs_profile_enable(mask)
+    return all_names
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} for every kernel that ran while enabled."""
+    lib = load()
+    out = {}
+    for i in range(lib.fsgs_profile_count()):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        lib.fsgs_profile_read(i, C.byref(ms), C.byref(cnt))
+        if cnt.value:
+            out[lib.fsgs_profile_name(i).decode()] = (ms.value, cnt.value)
+    return out

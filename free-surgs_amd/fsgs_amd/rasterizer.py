@@ -66,6 +66,8 @@ def make_cfg(settings, channels):
     return cfg
 
 
+last_num_rendered = 0  # R of the most recent forward (bench.py reports it)
+
 # ---- (tile, Gaussian) pair capacity: grow-only estimate per problem shape ----------------------
 _capacity = {}
 
@@ -117,6 +119,8 @@ def raster_forward(cfg, means3D, colors, opacities, scales, rotations):
             break
         else:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_raster_forward")
+    global last_num_rendered
+    last_num_rendered = int(nr.value)
     st = RasterState()
     st.buf, st.state_bytes, st.max_pairs, st.num_rendered, st.cfg, st.P = state, sb.value, cap, int(nr.value), cfg, P
     return out_color, out_depth, radii, st

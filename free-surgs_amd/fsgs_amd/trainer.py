@@ -82,15 +82,19 @@ class FrameData:
         self.monodeps = monodeps
 
 
-def mapping_loss(pkg, gt_image, mono_dep, corners=None):
+def mapping_loss(pkg, gt_image, mono_dep, corners=None, hip_losses=True):
     """5 * rgb + 0.05 * pearson + 0.15 * local_pearson(128, 0.5)   (train.py:253-259)."""
-    rgb = losses.rgb_loss_func(pkg["render"], gt_image) * LOSS_W_MAPPING["rgb"]
-    pear = losses.pearson_depth_loss(mono_dep, pkg["render_dep"])
-    lp = losses.local_pearson_loss(mono_dep, pkg["render_dep"], 128, 0.5, corners)
+    if hip_losses:
+        rgb_f, pe_f, lp_f = losses.rgb_loss_func, losses.pearson_depth_loss, losses.local_pearson_loss
+    else:  # the plain-PyTorch statement of the same maths (numerics reference of the fused kernels)
+        rgb_f, pe_f, lp_f = losses.rgb_loss_torch, losses.pearson_torch, losses.local_pearson_torch
+    rgb = rgb_f(pkg["render"], gt_image) * LOSS_W_MAPPING["rgb"]
+    pear = pe_f(mono_dep, pkg["render_dep"])
+    lp = lp_f(mono_dep, pkg["render_dep"], 128, 0.5, corners)
     return rgb + pear * LOSS_W_MAPPING["pearson"] + lp * LOSS_W_MAPPING["local_pearson"]
 
 
-def mapping_step(pc, poses, frames, timesteps, fused=True, step_optimizer=True):
+def mapping_step(pc, poses, frames, timesteps, fused=True, step_optimizer=True, hip_losses=True, grad_sync=None):
     """One mapping iteration over `timesteps` views with SUMMED loss (train.py:236-272).
     Densification statistics come from view 0 only (train.py:260-263)."""
     rend = render if fused else render_two_pass
@@ -98,10 +102,12 @@ def mapping_step(pc, poses, frames, timesteps, fused=True, step_optimizer=True):
     first = None
     for k, ts in enumerate(timesteps):
         pkg = rend(poses, ts, pc, gs_grad=True, cam_grad=False)
-        loss = loss + mapping_loss(pkg, frames.colors[ts], frames.monodeps[ts])
+        loss = loss + mapping_loss(pkg, frames.colors[ts], frames.monodeps[ts], hip_losses=hip_losses)
         if k == 0:
             first = pkg
     loss.backward()
+    if grad_sync is not None:  # frame-sharded data parallel: sum the Gaussian gradients over ranks
+        grad_sync(pc)
     with torch.no_grad():
         vis = first["visibility_filter"]
         mr = pc.variables["max_radii2D"]

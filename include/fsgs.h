@@ -68,6 +68,14 @@ typedef struct FsgsRasterCfg {
 const char *fsgs_version(void);
 const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP */
 
+/* Optional per-kernel timing with HIP events recorded on the launching stream.
+ * mask: bit i enables kernel id i (ids: fsgs_profile_name); 0 disables.  Enabling resets totals.
+ * fsgs_profile_read synchronises the pending events of that id and returns the running totals. */
+int fsgs_profile_enable(uint64_t mask);
+int fsgs_profile_count(void);
+const char *fsgs_profile_name(int id);
+int fsgs_profile_read(int id, double *total_ms, int64_t *launches);
+
 /* ---- rasteriser (drop-in operator boundary) -------------------------------- */
 
 /* Bytes of the per-call buffers for P Gaussians, a W x H image and room for
