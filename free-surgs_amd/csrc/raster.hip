@@ -344,15 +344,22 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
         s_op = fmaf(e.G, dL_dalpha, s_op);
       }
       if (__ballot(any) == 0ull) continue;  // wave-uniform: nobody in the tile is touched
-      const bool mine = lane == j;          // lane j keeps the tile total of Gaussian j
-      o_mx = mine ? wave_sum(s_mx) : o_mx;
-      o_my = mine ? wave_sum(s_my) : o_my;
-      o_A = mine ? wave_sum(s_A) : o_A;
-      o_B = mine ? wave_sum(s_B) : o_B;
-      o_C = mine ? wave_sum(s_C) : o_C;
-      o_op = mine ? wave_sum(s_op) : o_op;
+      // NB: the reductions must run with the whole wave active -- evaluate them BEFORE the select
+      // (a C++ `mine ? wave_sum(x) : o` would execute the DPP ops in lane j only).
+      const float t_mx = wave_sum(s_mx), t_my = wave_sum(s_my), t_A = wave_sum(s_A), t_B = wave_sum(s_B);
+      const float t_C = wave_sum(s_C), t_op = wave_sum(s_op);
+      float t_col[C];
 #pragma unroll
-      for (int ch = 0; ch < C; ch++) o_col[ch] = mine ? wave_sum(s_col[ch]) : o_col[ch];
+      for (int ch = 0; ch < C; ch++) t_col[ch] = wave_sum(s_col[ch]);
+      const bool mine = lane == j;  // lane j keeps the tile total of Gaussian j
+      o_mx = mine ? t_mx : o_mx;
+      o_my = mine ? t_my : o_my;
+      o_A = mine ? t_A : o_A;
+      o_B = mine ? t_B : o_B;
+      o_C = mine ? t_C : o_C;
+      o_op = mine ? t_op : o_op;
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) o_col[ch] = mine ? t_col[ch] : o_col[ch];
     }
     if (lane < n) {
       float *ga = grad_acc + (size_t)gid * kAccStride;
@@ -590,6 +597,14 @@ int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
   // backward needs P * 8 floats of accumulators; make one scratch size serve both directions
   size_t bwd = (size_t)(P > 0 ? P : 1) * kAccStride * sizeof(float) + 256;
   *scratch_bytes = sl.total > bwd ? sl.total : bwd;
+  return FSGS_OK;
+}
+
+int fsgs_raster_state_layout(int P, int width, int height, int64_t max_pairs, size_t offsets[7]) {
+  if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !offsets) return FSGS_ERR_INVALID;
+  StateLayout L = state_layout(P, width, height, max_pairs);
+  offsets[0] = L.xy; offsets[1] = L.conic_op; offsets[2] = L.depth; offsets[3] = L.ranges;
+  offsets[4] = L.final_T; offsets[5] = L.n_contrib; offsets[6] = L.plist;
   return FSGS_OK;
 }
 

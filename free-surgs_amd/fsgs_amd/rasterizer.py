@@ -126,6 +126,30 @@ def raster_forward(cfg, means3D, colors, opacities, scales, rotations):
     return out_color, out_depth, radii, st
 
 
+def state_views(st):
+    """Typed views into a RasterState buffer (tests / debugging): what UPSTREAM keeps in its geom /
+    binning / image buffers."""
+    lib = _lib.load()
+    H, W, P = st.cfg.image_height, st.cfg.image_width, st.P
+    off = (C.c_size_t * 7)()
+    _lib.check(lib.fsgs_raster_state_layout(P, W, H, st.max_pairs, off), "fsgs_raster_state_layout")
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def view(i, dtype, count, shape):
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return st.buf[off[i]:off[i] + nbytes].view(dtype).reshape(shape)
+
+    return {
+        "xy": view(0, torch.float32, 2 * P, (P, 2)),
+        "conic_opacity": view(1, torch.float32, 4 * P, (P, 4)),
+        "depth": view(2, torch.float32, P, (P,)),
+        "ranges": view(3, torch.int32, 2 * ntiles, (ntiles, 2)),
+        "final_T": view(4, torch.float32, H * W, (H, W)),
+        "n_contrib": view(5, torch.int32, H * W, (H, W)),
+        "point_list": view(6, torch.int32, st.num_rendered, (st.num_rendered,)),
+    }
+
+
 def raster_backward(st, means3D, colors, scales, rotations, radii, grad_color):
     lib = _lib.load()
     dev = means3D.device
@@ -160,7 +184,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 "cov3D_precomp is not on the Free-SurGS path (cov3D_precomp=None, "
                 "scene/gaussian_model.py:309); pass scales and rotations")
         P = means3D.shape[0]
-        m3, col = _f32c(means3D), _f32c(colors_precomp).reshape(P, -1)
+        m3 = _f32c(means3D)
+        col = _f32c(colors_precomp)
+        col = col.reshape(P, -1) if P > 0 else col.reshape(0, 3)
         op, sc, rot = _f32c(opacities).reshape(P), _f32c(scales), _f32c(rotations)
         cfg = make_cfg(raster_settings, col.shape[1] if P > 0 else 3)
         color, depth, radii, st = raster_forward(cfg, m3, col, op, sc, rot)

@@ -85,6 +85,11 @@ int fsgs_profile_read(int id, double *total_ms, int64_t *launches);
 int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs,
                       size_t *state_bytes, size_t *scratch_bytes);
 
+/* Byte offsets of the sub-buffers inside `state` (for tests / debugging / a viewer):
+ * [0] xy float2[P], [1] conic+opacity float4[P], [2] depth float[P], [3] tile ranges int2[tiles],
+ * [4] final_T float[H*W], [5] n_contrib uint32[H*W], [6] sorted Gaussian ids uint32[max_pairs]. */
+int fsgs_raster_state_layout(int P, int width, int height, int64_t max_pairs, size_t offsets[7]);
+
 /* Forward: kernels R1-R6 of SURVEY.md s2.1.
  *  means3D[P,3] colors[P,C] opacities[P] scales[P,3] rotations[P,4] (r,x,y,z), fp32 row-major.
  *  out_color[C,H,W] planar, out_depth[H,W] (depth-fork third output), radii[P] int32.

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from fsgs_amd import synth
-from tests.util import c1_poses, norm_err, sh0_colors, to_camera_frame
+from tests.util import assert_close_flip_aware, c1_poses, sh0_colors, to_camera_frame
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -40,25 +40,29 @@ def _run_hip(cam, xyz, col, op, sc, rot, dL):
     return n(img), n(depth)[0], n(radii), {k: n(v) for k, v in g.items()}
 
 
-def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, grad_tol=1e-4, img_tol=1e-4):
+def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False):
+    """HIP vs the fp32 oracle on the same inputs.  Tolerances per SURVEY.md s8d (1e-4; radii and
+    visibility exact) with the flip budget explained in tests/util.py:assert_close_flip_aware;
+    strict=True (small scenes) allows no outliers at all."""
     H, W = cam["image_height"], cam["image_width"]
     Cc = np.asarray(col).shape[1]
+    P = len(xyz)
     dL = (np.random.default_rng(seed).uniform(-1, 1, (Cc, H, W)) / (Cc * H * W)).astype(np.float32)
     img, dep, radii, g = _run_hip(cam, xyz, col, op, sc, rot, dL)
     oi, od, orad, st = oracle.raster_forward(cam, xyz, col, op, sc, rot)
     og = oracle.raster_backward(st, dL)
-    mism = int((radii != orad).sum())
-    assert mism <= max(1, len(orad) // 20000), "radii mismatch on %d of %d" % (mism, len(orad))
-    assert ((radii > 0) != (orad > 0)).sum() <= mism
-    if mism == 0:
-        e_img = np.max(np.abs(img - oi) / np.maximum(np.abs(oi), 1e-2))
-        assert e_img <= img_tol, "image rel err %g" % e_img
-        assert np.max(np.abs(dep - od) / np.maximum(np.abs(od), 1e-2)) <= img_tol
-    else:  # a radius flipped on a ceil() boundary: compare robustly
-        assert np.mean(np.abs(img - oi)) < 1e-5
+    kw = dict(max_frac=0.0, min_budget=0) if strict else {}
+    mism = int((radii != orad).sum())  # ceil(3 sigma) may flip on an exact boundary
+    assert mism <= (0 if strict else max(1, P // 10000)), "radii mismatch on %d of %d" % (mism, P)
+    assert int(((radii > 0) != (orad > 0)).sum()) == 0, "visibility filter differs"
+    assert_close_flip_aware(img, oi, "image", floor=1.0, **kw)  # colours live in [0,1]: abs 1e-4 of full scale
+    assert_close_flip_aware(dep, od, "depth", floor=1.0, **kw)
+    # an analytically-zero gradient (d/drotation of an isotropic Gaussian) is cancellation round-off of
+    # terms of size ~|dL/dscale|*|scale| in both implementations: floor each norm at 1e-3 of the largest
+    # gradient tensor, i.e. an absolute tolerance of 1e-7 of that for such tensors
+    floor = 1e-3 * max(float(np.abs(v).max()) for v in og.values())
     for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
-        e = norm_err(g[k], og[k])
-        assert e <= grad_tol, "%s: err/inf-norm = %g" % (k, e)
+        assert_close_flip_aware(g[k].reshape(P, -1), og[k].reshape(P, -1), k, floor=floor, rows=P, **kw)
     return st.num_rendered
 
 
@@ -93,7 +97,7 @@ def test_six_channel_fused_layout(oracle32):
     cam = synth.make_camera(W, H)
     xyz, col, op, s, r = synth.random_small_scene(P, cam, seed=4, channels=6)
     _compare(oracle32, cam, xyz.astype(np.float32), col.astype(np.float32), op, s.astype(np.float32),
-             r.astype(np.float32), seed=3)
+             r.astype(np.float32), seed=3, strict=True)
 
 
 def test_edge_cases_empty_ragged_and_culled(oracle32):
@@ -151,7 +155,7 @@ def test_full_size_properties_c2():
     c2 = T(rng.uniform(0, 1, (P, 3)).astype(np.float32))
     ones = torch.ones_like(c1).requires_grad_(True)
     sil, radii, _ = rast(means3D=m3, means2D=m2, opacities=o_t, colors_precomp=ones, scales=sc_t, rotations=r_t)
-    assert float((sil - 1).abs().max()) < 2e-5  # bg = 1 -> every plane is exactly 1
+    assert float((sil.detach() - 1).abs().max()) < 2e-5  # bg = 1 -> every plane is exactly 1
     i1, _, _ = rast(means3D=m3, means2D=m2, opacities=o_t, colors_precomp=c1, scales=sc_t, rotations=r_t)
     i2, _, _ = rast(means3D=m3, means2D=m2, opacities=o_t, colors_precomp=c2, scales=sc_t, rotations=r_t)
     i3, _, _ = rast(means3D=m3, means2D=m2, opacities=o_t, colors_precomp=0.25 * c1 + 0.75 * c2, scales=sc_t,
