@@ -1,0 +1,386 @@
+// loss.hip -- fused photometric and depth-correlation losses for gfx950 (MI355X).
+//
+// Replaces the ~600 small PyTorch kernels per mapping iteration that
+// utils/loss_utils.py:41-127 launches (5 depthwise 11x11 conv2d forward + backward for SSIM,
+// 40 x (~12 reductions + 4 host syncs) for local_pearson_loss):
+//   * photometric_forward : ONE pass over the images builds the five 11x11 Gaussian moments of
+//     every pixel (separable, LDS-tiled 32x32 + 5 halo), the SSIM map, the L1 term, their
+//     reductions AND the three d(ssim)/d(moment) maps the backward needs.
+//   * photometric_backward: one more separable pass turns those maps into dL/dimg.
+//   * pearson_stats / pearson_backward: the global Pearson loss and all random 128x128 patches
+//     share one reduction launch (region 0 = whole image) and one elementwise gradient launch;
+//     patch corners are read from device memory, so nothing ever syncs with the host.
+// All of these kernels are HBM-bound streaming passes (36-40 B/px).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsgs.h"
+#include "fsgs_device.h"
+#include "fsgs_host.h"
+
+using namespace fsgs;
+
+namespace {
+
+constexpr int SS_TILE = 32;            // output tile edge
+constexpr int SS_HALO = 5;             // 11-tap window
+constexpr int SS_IN = SS_TILE + 2 * SS_HALO;  // 42
+constexpr float SS_C1 = 0.01f * 0.01f;
+constexpr float SS_C2 = 0.03f * 0.03f;
+
+// exp(-(i-5)^2 / (2*1.5^2)) normalised, i = 0..10 (utils/loss_utils.py:56-58), computed in double
+__constant__ float kGauss[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.1093606895f, 0.2130055377f,
+                                 0.2660117249f, 0.2130055377f, 0.1093606895f, 0.0360007721f, 0.0075987581f,
+                                 0.0010283801f};
+
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+  // 4 waves: DPP wave sums, then one LDS hop
+  float w = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = w;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// photometric forward
+// sums[0] += sum |x-y| ; sums[1] += sum ssim_map          (doubles, zeroed by the caller)
+// maps: [3][C][H][W] = d ssim / d m1, d ssim / d e11, d ssim / d e12   (m1 = G*x, e11 = G*x^2, e12 = G*xy)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                              const float *__restrict__ gt,
+                                                              const float *__restrict__ mask,
+                                                              float *__restrict__ maps, double *__restrict__ sums) {
+  __shared__ float sx[SS_IN][SS_IN + 1];
+  __shared__ float sy[SS_IN][SS_IN + 1];
+  __shared__ float hz[5][SS_IN][SS_TILE + 1];
+  __shared__ float red[4];
+  const int ch = blockIdx.z;
+  const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
+  const size_t plane = (size_t)H * W;
+  const float *ip = img + ch * plane, *gp = gt + ch * plane;
+  for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
+    int ly = i / SS_IN, lx = i - ly * SS_IN;
+    int gy = y0 + ly - SS_HALO, gx = x0 + lx - SS_HALO;
+    float a = 0.f, b = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {  // zero padding (F.conv2d padding=5)
+      size_t p = (size_t)gy * W + gx;
+      float m = mask ? mask[p] : 1.0f;
+      a = ip[p] * m;
+      b = gp[p] * m;
+    }
+    sx[ly][lx] = a;
+    sy[ly][lx] = b;
+  }
+  __syncthreads();
+  // horizontal 11-tap pass of the five moments
+  for (int i = threadIdx.x; i < SS_IN * SS_TILE; i += 256) {
+    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      float g = kGauss[k], a = sx[ly][lx + k], b = sy[ly][lx + k];
+      m1 = fmaf(g, a, m1);
+      m2 = fmaf(g, b, m2);
+      e11 = fmaf(g, a * a, e11);
+      e22 = fmaf(g, b * b, e22);
+      e12 = fmaf(g, a * b, e12);
+    }
+    hz[0][ly][lx] = m1; hz[1][ly][lx] = m2; hz[2][ly][lx] = e11; hz[3][ly][lx] = e22; hz[4][ly][lx] = e12;
+  }
+  __syncthreads();
+  float l1_acc = 0.f, ss_acc = 0.f;
+  const size_t cplane = (size_t)C * plane;
+  for (int i = threadIdx.x; i < SS_TILE * SS_TILE; i += 256) {
+    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
+    int gy = y0 + ly, gx = x0 + lx;
+    if (gy >= H || gx >= W) continue;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      float g = kGauss[k];
+      m1 = fmaf(g, hz[0][ly + k][lx], m1);
+      m2 = fmaf(g, hz[1][ly + k][lx], m2);
+      e11 = fmaf(g, hz[2][ly + k][lx], e11);
+      e22 = fmaf(g, hz[3][ly + k][lx], e22);
+      e12 = fmaf(g, hz[4][ly + k][lx], e12);
+    }
+    float A1 = 2.f * m1 * m2 + SS_C1;
+    float A2 = 2.f * (e12 - m1 * m2) + SS_C2;
+    float B1 = m1 * m1 + m2 * m2 + SS_C1;
+    float B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + SS_C2;
+    float inv = 1.0f / (B1 * B2);
+    float S = A1 * A2 * inv;
+    ss_acc += S;
+    float a = sx[ly + SS_HALO][lx + SS_HALO], b = sy[ly + SS_HALO][lx + SS_HALO];
+    l1_acc += fabsf(a - b);
+    size_t p = ch * plane + (size_t)gy * W + gx;
+    maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/dm1
+    maps[cplane + p] = -S / B2;                                                       // d/de11
+    maps[2 * cplane + p] = 2.f * A1 * inv;                                            // d/de12
+  }
+  float t1 = block_sum_256(l1_acc, red);
+  float t2 = block_sum_256(ss_acc, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], (double)t1);
+    atomicAdd(&sums[1], (double)t2);
+  }
+}
+
+// loss = (1-l) * L1mean + l * (1 - SSIMmean);  out[0] = loss, out[1] = L1 mean, out[2] = SSIM mean
+__global__ void photometric_finish_kernel(const double *sums, double n, float lambda_dssim, float *out) {
+  double l1 = sums[0] / n, ss = sums[1] / n;
+  out[0] = (float)((1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss));
+  out[1] = (float)l1;
+  out[2] = (float)ss;
+}
+
+// dL/dimg = upstream * [ (1-l)/N sign(x-y) - l/N ( G*dm1 + 2x G*de11 + y G*de12 ) ] * mask
+__global__ __launch_bounds__(256) void photometric_bwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                              const float *__restrict__ gt,
+                                                              const float *__restrict__ mask,
+                                                              const float *__restrict__ maps,
+                                                              const float *__restrict__ upstream, float lambda_dssim,
+                                                              float *__restrict__ dimg) {
+  __shared__ float sm[3][SS_IN][SS_IN + 1];
+  __shared__ float hz[3][SS_IN][SS_TILE + 1];
+  const int ch = blockIdx.z;
+  const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
+  const size_t plane = (size_t)H * W, cplane = (size_t)C * plane;
+  for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
+    int ly = i / SS_IN, lx = i - ly * SS_IN;
+    int gy = y0 + ly - SS_HALO, gx = x0 + lx - SS_HALO;
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      size_t p = ch * plane + (size_t)gy * W + gx;
+      a = maps[p];
+      b = maps[cplane + p];
+      c = maps[2 * cplane + p];
+    }
+    sm[0][ly][lx] = a; sm[1][ly][lx] = b; sm[2][ly][lx] = c;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SS_IN * SS_TILE; i += 256) {
+    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      float g = kGauss[k];
+      a = fmaf(g, sm[0][ly][lx + k], a);
+      b = fmaf(g, sm[1][ly][lx + k], b);
+      c = fmaf(g, sm[2][ly][lx + k], c);
+    }
+    hz[0][ly][lx] = a; hz[1][ly][lx] = b; hz[2][ly][lx] = c;
+  }
+  __syncthreads();
+  const float up = upstream ? upstream[0] : 1.0f;
+  const float invN = 1.0f / ((float)C * (float)H * (float)W);
+  const float k_l1 = up * (1.0f - lambda_dssim) * invN, k_ss = -up * lambda_dssim * invN;
+  for (int i = threadIdx.x; i < SS_TILE * SS_TILE; i += 256) {
+    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
+    int gy = y0 + ly, gx = x0 + lx;
+    if (gy >= H || gx >= W) continue;
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      float g = kGauss[k];
+      a = fmaf(g, hz[0][ly + k][lx], a);
+      b = fmaf(g, hz[1][ly + k][lx], b);
+      c = fmaf(g, hz[2][ly + k][lx], c);
+    }
+    size_t pp = (size_t)gy * W + gx, p = ch * plane + pp;
+    float m = mask ? mask[pp] : 1.0f;
+    float x = img[p] * m, y = gt[p] * m;
+    float d = x - y;
+    float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dimg[p] = m * (k_l1 * sgn + k_ss * (a + 2.f * x * b + y * c));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pearson correlation losses (utils/loss_utils.py:98-127)
+// region 0 = whole image; regions 1..n = box x box patches with top-left (row0[r-1], col0[r-1]).
+// stats[r][0..4] = sum s, sum t, sum s^2, sum t^2, sum s*t   (doubles, zeroed by the caller)
+// ---------------------------------------------------------------------------------------------------
+constexpr int PE_CHUNK = 4096;  // pixels per workgroup
+
+__global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int box, const int64_t *__restrict__ row0,
+                                                            const int64_t *__restrict__ col0,
+                                                            const float *__restrict__ src,
+                                                            const float *__restrict__ tgt, double *__restrict__ stats) {
+  __shared__ float red[4];
+  const int r = blockIdx.y;
+  int ry = 0, rx = 0, rh = H, rw = W;
+  if (r > 0) {
+    ry = (int)row0[r - 1]; rx = (int)col0[r - 1]; rh = box; rw = box;
+  }
+  const int n = rh * rw;
+  const int begin = blockIdx.x * PE_CHUNK;
+  if (begin >= n) return;
+  const int end = min(n, begin + PE_CHUNK);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  for (int i = begin + threadIdx.x; i < end; i += 256) {
+    int y = i / rw, x = i - y * rw;
+    size_t p = (size_t)(ry + y) * W + (rx + x);
+    float s = src[p], t = tgt[p];
+    a0 += s; a1 += t;
+    a2 = fmaf(s, s, a2); a3 = fmaf(t, t, a3); a4 = fmaf(s, t, a4);
+  }
+  float t0 = block_sum_256(a0, red), t1 = block_sum_256(a1, red), t2 = block_sum_256(a2, red);
+  float t3 = block_sum_256(a3, red), t4 = block_sum_256(a4, red);
+  if (threadIdx.x == 0) {
+    double *st = stats + 5 * r;
+    atomicAdd(st + 0, (double)t0); atomicAdd(st + 1, (double)t1); atomicAdd(st + 2, (double)t2);
+    atomicAdd(st + 3, (double)t3); atomicAdd(st + 4, (double)t4);
+  }
+}
+
+// per region: coefficients of the gradient + the loss value
+//   co = cov / ((sd_s+eps)(sd_t+eps)), cov = E[st]-E[s]E[t] (biased, mean()), sd unbiased
+//   coef[r] = {mean_s, mean_t, 1/(N*D), cov/(D*(sd_t+eps)*(N-1)*sd_t), cov/(D*(sd_s+eps)*(N-1)*sd_s), loss}
+__global__ void pearson_finish_kernel(int H, int W, int box, int nregions, const double *__restrict__ stats,
+                                      float *__restrict__ coef, float *__restrict__ out) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nregions) {
+    double N = r == 0 ? (double)H * W : (double)box * box;
+    const double *st = stats + 5 * r;
+    double ms = st[0] / N, mt = st[1] / N;
+    double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
+    vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
+    double sds = sqrt(vs), sdt = sqrt(vt);
+    double cov = st[4] / N - ms * mt;
+    double D = (sds + 1e-6) * (sdt + 1e-6);
+    float *c = coef + 8 * r;
+    c[0] = (float)ms; c[1] = (float)mt; c[2] = (float)(1.0 / (N * D));
+    c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
+    c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
+    c[5] = (float)(1.0 - cov / D);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = coef[5];  // global loss  (written by this block's thread 0 above when r == 0)
+  }
+}
+__global__ void pearson_local_mean_kernel(int nregions, const float *__restrict__ coef, float *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float acc = 0.f;
+    for (int r = 1; r < nregions; r++) acc += coef[8 * r + 5];  // sequential like the reference's python loop
+    out[1] = nregions > 1 ? acc / (float)(nregions - 1) : 0.f;
+  }
+}
+
+// d(loss_r)/d tgt_i = -(s_i-ms)/(N D) + cov/(D (sd_t+eps) (N-1) sd_t) (t_i - mt), weighted by weight[r]
+// (weight[0] = upstream of the global loss, weight[r>0] = upstream_local / n_patches); wrt_src swaps roles.
+__global__ __launch_bounds__(256) void pearson_bwd_kernel(int H, int W, int box, int nregions,
+                                                          const int64_t *__restrict__ row0,
+                                                          const int64_t *__restrict__ col0,
+                                                          const float *__restrict__ src, const float *__restrict__ tgt,
+                                                          const float *__restrict__ coef,
+                                                          const float *__restrict__ weight, int wrt_src,
+                                                          float *__restrict__ grad) {
+  __shared__ float s_coef[65][8];
+  __shared__ int s_rect[65][2];
+  for (int i = threadIdx.x; i < nregions * 8; i += 256) s_coef[i / 8][i % 8] = coef[i] * ((i % 8) >= 2 && (i % 8) <= 4 ? weight[i / 8] : 1.f);
+  for (int i = threadIdx.x; i < nregions; i += 256) {
+    s_rect[i][0] = i == 0 ? 0 : (int)row0[i - 1];
+    s_rect[i][1] = i == 0 ? 0 : (int)col0[i - 1];
+  }
+  __syncthreads();
+  const size_t n = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
+    int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    float s = src[p], t = tgt[p];
+    float g = 0.f;
+    {
+      const float *c = s_coef[0];
+      float a = s - c[0], b = t - c[1];
+      g += wrt_src ? (-b * c[2] + c[4] * a) : (-a * c[2] + c[3] * b);
+    }
+    for (int r = 1; r < nregions; r++) {
+      int dy = y - s_rect[r][0], dx = x - s_rect[r][1];
+      if ((unsigned)dy < (unsigned)box && (unsigned)dx < (unsigned)box) {
+        const float *c = s_coef[r];
+        float a = s - c[0], b = t - c[1];
+        g += wrt_src ? (-b * c[2] + c[4] * a) : (-a * c[2] + c[3] * b);
+      }
+    }
+    grad[p] = g;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                  float lambda_dssim, float *maps, double *sums2, float *out3,
+                                  fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3) return FSGS_ERR_INVALID;
+  FSGS_HIP(hipMemsetAsync(sums2, 0, 2 * sizeof(double), stream));
+  dim3 grid((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
+  {
+    ProfScope ps(PROF_LOSS_RGB_FWD, stream);
+    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, maps, sums2);
+    hipLaunchKernelGGL(photometric_finish_kernel, dim3(1), dim3(1), 0, stream, sums2, (double)C * H * W, lambda_dssim,
+                       out3);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                   const float *maps, const float *upstream, float lambda_dssim, float *dimg,
+                                   fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !dimg) return FSGS_ERR_INVALID;
+  dim3 grid((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
+  {
+    ProfScope ps(PROF_LOSS_RGB_BWD, stream);
+    hipLaunchKernelGGL(photometric_bwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, maps, upstream,
+                       lambda_dssim, dimg);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_pearson_forward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
+                         const float *src, const float *tgt, double *stats, float *coef, float *out2,
+                         fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (H <= 0 || W <= 0 || n_patches < 0 || n_patches > 64 || !src || !tgt || !stats || !coef || !out2)
+    return FSGS_ERR_INVALID;
+  if (n_patches > 0 && (!patch_row0 || !patch_col0 || box <= 1 || box > H || box > W)) return FSGS_ERR_INVALID;
+  const int nreg = n_patches + 1;
+  FSGS_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 5 * nreg, stream));
+  {
+    ProfScope ps(PROF_PEARSON, stream);
+    dim3 grid((H * W + PE_CHUNK - 1) / PE_CHUNK, nreg);
+    hipLaunchKernelGGL(pearson_stats_kernel, grid, dim3(256), 0, stream, H, W, box, patch_row0, patch_col0, src, tgt,
+                       stats);
+    hipLaunchKernelGGL(pearson_finish_kernel, dim3(1), dim3(128), 0, stream, H, W, box, nreg, stats, coef, out2);
+    hipLaunchKernelGGL(pearson_local_mean_kernel, dim3(1), dim3(64), 0, stream, nreg, coef, out2);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_pearson_backward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
+                          const float *src, const float *tgt, const float *coef, const float *region_weight,
+                          int wrt_src, float *grad, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (H <= 0 || W <= 0 || n_patches < 0 || n_patches > 64 || !src || !tgt || !coef || !region_weight || !grad)
+    return FSGS_ERR_INVALID;
+  {
+    ProfScope ps(PROF_PEARSON, stream);
+    int blocks = (int)(((size_t)H * W + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pearson_bwd_kernel, dim3(blocks), dim3(256), 0, stream, H, W, box, n_patches + 1, patch_row0,
+                       patch_col0, src, tgt, coef, region_weight, wrt_src, grad);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+}  // extern "C"

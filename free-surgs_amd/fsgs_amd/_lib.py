@@ -75,6 +75,10 @@ _PROTOTYPES = {
          _vp, _vp, _sz, _vp],
     ),
     "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+    "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "fsgs_photometric_loss_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
+    "fsgs_pearson_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsgs_pearson_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 

@@ -123,6 +123,34 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P,
 int fsgs_knn_meandist2(int P, const float *points, float *out,
                        void *scratch, size_t *scratch_bytes, fsgs_stream_t stream);
 
+/* ---- photometric loss: 0.8 L1 + 0.2 (1 - SSIM)  (utils/loss_utils.py:41-96) ------------------- */
+
+/* img, gt [C,H,W]; mask [H,W] or NULL (multiplies both images, utils/loss_utils.py:48-50).
+ * maps [3,C,H,W] (kept for backward), sums2 double[2] scratch, out3 float[3] = {loss, L1, SSIM}
+ * on the DEVICE (no host sync). */
+int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                  float lambda_dssim, float *maps, double *sums2, float *out3,
+                                  fsgs_stream_t stream);
+/* dimg [C,H,W] = upstream[0] * dloss/dimg; upstream is a DEVICE scalar (NULL = 1). */
+int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                   const float *maps, const float *upstream, float lambda_dssim, float *dimg,
+                                   fsgs_stream_t stream);
+
+/* ---- Pearson depth losses (utils/loss_utils.py:98-127) ------------------------------------------- */
+
+/* Global loss over the whole [H,W] image and the mean loss over n_patches (<= 64) box x box patches
+ * whose top-left corners (row, col) are int64 DEVICE arrays (what torch.randint produced).
+ * stats double[5*(n_patches+1)] scratch, coef float[8*(n_patches+1)] (kept for backward),
+ * out2 float[2] = {global loss, mean patch loss} on the device. */
+int fsgs_pearson_forward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
+                         const float *src, const float *tgt, double *stats, float *coef, float *out2,
+                         fsgs_stream_t stream);
+/* grad [H,W] = sum_r region_weight[r] * dloss_r/d(tgt or src); region_weight float[n_patches+1] on the
+ * device (r = 0 global).  wrt_src = 0: gradient w.r.t. tgt (the rendered depth, train.py:256-257). */
+int fsgs_pearson_backward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
+                          const float *src, const float *tgt, const float *coef, const float *region_weight,
+                          int wrt_src, float *grad, fsgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""GPU parity of the fused loss kernels (csrc/loss.hip) against (a) the golden vectors captured from
+the reference's Python and (b) the plain PyTorch fp32 statement of the same op at C1/C2 sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd import losses
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+T = lambda a: torch.tensor(np.asarray(a), device=DEV)
+
+
+def test_rgb_loss_matches_reference_golden():
+    g = np.load(os.path.join(G, "rgb_loss.npz"))
+    gt = T(g["gt"])
+    for tag, m in (("nomask", None), ("mask", T(g["mask"]))):
+        x = T(g["img"]).requires_grad_(True)
+        l = losses.rgb_loss_func(x, gt, mask=m)
+        l.backward()
+        np.testing.assert_allclose(l.item(), g[f"loss_{tag}"], rtol=2e-5)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"grad_{tag}"], rtol=1e-3, atol=2e-8)
+
+
+def test_pearson_matches_reference_golden():
+    g = np.load(os.path.join(G, "pearson.npz"))
+    src = T(g["src"])
+    x = T(g["tgt"]).requires_grad_(True)
+    l = losses.pearson_depth_loss(src, x)
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["pearson"], rtol=1e-4)
+    scale = np.abs(g["pearson_grad_tgt"]).max()
+    assert np.abs(x.grad.cpu().numpy() - g["pearson_grad_tgt"]).max() <= 1e-4 * scale
+    x = T(g["src"]).requires_grad_(True)
+    losses.pearson_depth_loss(x, T(g["tgt"])).backward()
+    scale = np.abs(g["pearson_grad_src"]).max()
+    assert np.abs(x.grad.cpu().numpy() - g["pearson_grad_src"]).max() <= 1e-4 * scale
+    x = T(g["tgt"]).requires_grad_(True)
+    l = losses.local_pearson_loss(src, x, int(g["lp_box"]), float(g["lp_p"]), (T(g["lp_x0"]), T(g["lp_y0"])))
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["lp_loss"], rtol=1e-4)
+    scale = np.abs(g["lp_grad_tgt"]).max()
+    assert np.abs(x.grad.cpu().numpy() - g["lp_grad_tgt"]).max() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("shape", [(3, 512, 640), (3, 1024, 1280), (3, 77, 45)])
+def test_rgb_loss_matches_torch_statement(shape):
+    torch.manual_seed(0)
+    gt = torch.rand(shape, device=DEV)
+    img = (gt + 0.1 * torch.randn(shape, device=DEV)).clamp(0, 1)
+    mask = (torch.rand((1,) + shape[1:], device=DEV) > 0.2)
+    for m in (None, mask):
+        a = img.clone().requires_grad_(True)
+        b = img.clone().requires_grad_(True)
+        (3.0 * losses.rgb_loss_func(a, gt, mask=m)).backward()
+        (3.0 * losses.rgb_loss_torch(b, gt, mask=m)).backward()
+        la, lb = losses.rgb_loss_func(a, gt, mask=m).item(), losses.rgb_loss_torch(b, gt, mask=m).item()
+        assert abs(la - lb) <= 2e-5 * abs(lb)
+        scale = b.grad.abs().max().item()
+        assert (a.grad - b.grad).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("hw", [(512, 640), (1024, 1280)])
+def test_pearson_losses_match_torch_statement(hw):
+    torch.manual_seed(1)
+    H, W = hw
+    mono = torch.rand(H, W, device=DEV) + 0.5
+    dep = (mono * 0.8 + 0.3 * torch.rand(H, W, device=DEV)).contiguous()
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    assert len(corners[0]) == int(0.5 * (H // 128) * (W // 128))  # 10 at C1, 40 at C2
+    a = dep.clone().requires_grad_(True)
+    b = dep.clone().requires_grad_(True)
+    la = 0.05 * losses.pearson_depth_loss(mono, a) + 0.15 * losses.local_pearson_loss(mono, a, 128, 0.5, corners)
+    lb = 0.05 * losses.pearson_torch(mono, b) + 0.15 * losses.local_pearson_torch(mono, b, 128, 0.5, corners)
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-4 * abs(lb.item())
+    scale = b.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 2e-4 * scale
+
+
+def test_local_pearson_consumes_rng_like_the_reference():
+    """two randint draws on the device, in this order (utils/loss_utils.py:120-121)."""
+    H, W = 512, 640
+    torch.manual_seed(7)
+    x0 = torch.randint(0, H - 128, size=(10,), device=DEV)
+    y0 = torch.randint(0, W - 128, size=(10,), device=DEV)
+    torch.manual_seed(7)
+    c = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    assert torch.equal(c[0], x0) and torch.equal(c[1], y0)
+
+
+def test_full_size_properties():
+    """size-independent properties at C2: loss(x, x) = 0 for rgb; Pearson is invariant to positive affine
+    maps of either argument; gradient of the Pearson loss is orthogonal to constants and to tgt-mean shifts."""
+    torch.manual_seed(3)
+    H, W = 1024, 1280
+    img = torch.rand(3, H, W, device=DEV)
+    assert abs(losses.rgb_loss_func(img, img.clone()).item()) < 1e-6
+    mono = torch.rand(H, W, device=DEV) + 0.5
+    dep = (mono + 0.2 * torch.rand(H, W, device=DEV)).requires_grad_(True)
+    l1 = losses.pearson_depth_loss(mono, dep)
+    l2 = losses.pearson_depth_loss(3.0 * mono + 2.0, 0.5 * dep.detach() + 7.0)
+    assert abs(l1.item() - l2.item()) < 2e-5
+    l1.backward()
+    assert abs(dep.grad.sum().item()) < 1e-6 * dep.grad.abs().sum().item()
