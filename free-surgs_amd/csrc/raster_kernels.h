@@ -1,0 +1,724 @@
+// raster_kernels.h -- kernels and host helpers shared by raster.hip (operator boundary) and
+// render.hip (fused render).  See raster.hip for the design notes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/fsgs.h"
+#include "fsgs_device.h"
+#include "fsgs_host.h"
+
+namespace {
+using namespace fsgs;
+
+
+// ------------------------------------------------------------------------------------------------
+// device-side parameter block (passed by value)
+// ------------------------------------------------------------------------------------------------
+struct CamParams {
+  int W, H, gx, gy;
+  float tanfovx, tanfovy, fx, fy, scale_modifier;
+  float V[16];
+  float PM[16];
+  float bg[FSGS_MAX_CHANNELS];
+};
+
+// ------------------------------------------------------------------------------------------------
+// R1  per-Gaussian preprocess, shared by the operator boundary and the fused render
+// ------------------------------------------------------------------------------------------------
+struct Projected {
+  int radius;
+  uint32_t ntile, key;
+  ushort4 rect;
+  float2 xy;
+  float4 conic_op;
+  float tz;
+};
+// mean: Gaussian centre in the raster camera's world frame; s: activated scale * modifier;
+// q: quaternion as handed over (no re-normalisation); opacity: activated.
+__device__ __forceinline__ Projected project_gaussian(const CamParams &cam, float mx, float my, float mz, float3 s,
+                                                      float4 q, float opacity) {
+  Projected o;
+  o.radius = 0;
+  o.ntile = 0;
+  o.key = 0xFFFFFFFFu;
+  o.rect = make_ushort4(0, 0, 0, 0);
+  o.xy = make_float2(0.f, 0.f);
+  o.conic_op = make_float4(0.f, 0.f, 0.f, 0.f);
+  o.tz = 0.f;
+  const float *V = cam.V, *PM = cam.PM;
+  float3 t;
+  t.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+  t.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+  t.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+  if (!(t.z > 0.2f)) return o;  // near-plane cull
+  float h0 = PM[0] * mx + PM[4] * my + PM[8] * mz + PM[12];
+  float h1 = PM[1] * mx + PM[5] * my + PM[9] * mz + PM[13];
+  float h3 = PM[3] * mx + PM[7] * my + PM[11] * mz + PM[15];
+  float pw = 1.0f / (h3 + 0.0000001f);
+  float ndcx = h0 * pw, ndcy = h1 * pw;
+  Mat3 R = quat_to_R(q);
+  float c6[6];
+  cov3d(s, R, c6);
+  Ewa e;
+  ewa_project(V, t, c6, cam.fx, cam.fy, cam.tanfovx, cam.tanfovy, e);
+  float det = e.a * e.c - e.b * e.b;
+  if (det == 0.0f) return o;
+  float det_inv = 1.0f / det;
+  float mid = 0.5f * (e.a + e.c);
+  float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+  float lam = fmaxf(mid + sq, mid - sq);
+  int r_ = (int)ceilf(3.0f * sqrtf(lam));
+  float px = ((ndcx + 1.0f) * cam.W - 1.0f) * 0.5f;
+  float py = ((ndcy + 1.0f) * cam.H - 1.0f) * 0.5f;
+  int minx = min(cam.gx, max(0, (int)((px - r_) / FSGS_TILE)));
+  int miny = min(cam.gy, max(0, (int)((py - r_) / FSGS_TILE)));
+  int maxx = min(cam.gx, max(0, (int)((px + r_ + FSGS_TILE - 1) / FSGS_TILE)));
+  int maxy = min(cam.gy, max(0, (int)((py + r_ + FSGS_TILE - 1) / FSGS_TILE)));
+  int area = (maxx - minx) * (maxy - miny);
+  if (area <= 0) return o;
+  o.radius = r_;
+  o.ntile = (uint32_t)area;
+  o.rect = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
+  o.xy = make_float2(px, py);
+  o.conic_op = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacity);
+  o.tz = t.z;
+  o.key = __float_as_uint(t.z);  // positive float: the bit pattern is order preserving
+  return o;
+}
+
+struct GeomOut {  // per-Gaussian arrays written by every preprocess kernel
+  float2 *xy;
+  float4 *conic_op;
+  float *depth;
+  int32_t *radii;
+  uint32_t *tiles;
+  ushort4 *rect;
+  uint32_t *depthkey;
+  uint32_t *index;
+};
+__device__ __forceinline__ void store_projected(const GeomOut &g, int i, const Projected &o) {
+  g.radii[i] = o.radius;
+  g.tiles[i] = o.ntile;
+  g.rect[i] = o.rect;
+  g.xy[i] = o.xy;
+  g.conic_op[i] = o.conic_op;
+  g.depth[i] = o.tz;
+  g.depthkey[i] = o.key;
+  g.index[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams cam, const float *__restrict__ means3D,
+                                                             const float *__restrict__ opac,
+                                                             const float *__restrict__ scales,
+                                                             const float *__restrict__ rots, GeomOut g) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float3 s = make_float3(cam.scale_modifier * scales[3 * i], cam.scale_modifier * scales[3 * i + 1],
+                         cam.scale_modifier * scales[3 * i + 2]);
+  float4 q = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
+  Projected o = project_gaussian(cam, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], s, q, opac[i]);
+  store_projected(g, i, o);
+}
+
+// tiles touched, read through the depth order (input of the prefix sum)
+struct TilesInDepthOrder {
+  const uint32_t *tiles;
+  __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return tiles[g]; }
+};
+
+// R3  emit (tile id, Gaussian) pairs, walking the Gaussians in depth order
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, int gx, const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ incl,
+                                                         const uint32_t *__restrict__ tiles,
+                                                         const ushort4 *__restrict__ rect,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  uint32_t g = order[i];
+  uint32_t n = tiles[g];
+  if (n == 0) return;
+  uint32_t off = incl[i] - n;
+  ushort4 rc = rect[g];
+  for (int y = rc.y; y < rc.w; y++)
+    for (int x = rc.x; x < rc.z; x++) {
+      keys[off] = (uint32_t)(y * gx + x);
+      vals[off] = g;
+      off++;
+    }
+}
+
+// R5  [start,end) of every tile's run in the sorted pair list
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ keys,
+                                                          int2 *__restrict__ ranges) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= R) return;
+  uint32_t t = keys[k];
+  if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
+  if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R6  forward blend: one wave per 16x16 tile, 4 pixels per lane
+// ------------------------------------------------------------------------------------------------
+// out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
+// silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
+template <int C, bool WITH_DEPTH>
+__global__ __launch_bounds__(256) void blend_fwd_kernel(
+    CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
+    const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ depth,
+    const float *__restrict__ colors, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+    float *__restrict__ out_color, float *__restrict__ out_color2, float *__restrict__ out_depth) {
+  const int lane = threadIdx.x & 63;
+  const int vb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile = vb * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int W = cam.W, H = cam.H;
+  const int px_i = (tile % cam.gx) * FSGS_TILE + (lane & 15);
+  const int py_i = (tile / cam.gx) * FSGS_TILE + (lane >> 4);
+  const float px = (float)px_i;
+  float py[4];
+  bool done[4];
+  float T[4], D[4], acc[4][C];
+  uint32_t last[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    py[k] = (float)(py_i + 4 * k);
+    done[k] = !(px_i < W && (py_i + 4 * k) < H);
+    T[k] = 1.0f;
+    D[k] = 0.0f;
+    last[k] = 0;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) acc[k][ch] = 0.0f;
+  }
+  const int2 rg = ranges[tile];
+  for (int base = rg.x; base < rg.y; base += 64) {
+    bool all_done = done[0] && done[1] && done[2] && done[3];
+    if (__ballot(!all_done) == 0ull) break;
+    const int n = min(64, rg.y - base);
+    // lane j gathers record j of this batch
+    uint32_t g = plist[base + (lane < n ? lane : 0)];
+    float2 gxy = xy[g];
+    float4 gco = conic_op[g];
+    float gz = WITH_DEPTH ? depth[g] : 0.f;
+    float gcol[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)g * C + ch];
+    for (int j = 0; j < n; j++) {
+      const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
+      const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
+      const float bo = readlane(gco.w, j), bz = WITH_DEPTH ? readlane(gz, j) : 0.f;
+      float bcol[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
+      const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (done[k]) continue;
+        SplatEval e;
+        if (!splat_alpha(bx, by, bA, bB, bC, bo, px, py[k], e)) continue;
+        float test_T = T[k] * (1.0f - e.alpha);
+        if (test_T < 0.0001f) {
+          done[k] = true;
+          continue;
+        }
+        float w = e.alpha * T[k];
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) acc[k][ch] = fmaf(bcol[ch], w, acc[k][ch]);
+        if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
+        T[k] = test_T;
+        last[k] = pos;
+      }
+    }
+  }
+  const size_t HW = (size_t)H * W;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int y = py_i + 4 * k;
+    if (px_i < W && y < H) {
+      size_t pix = (size_t)y * W + px_i;
+      final_T[pix] = T[k];
+      n_contrib[pix] = last[k];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) {
+        float v = fmaf(T[k], cam.bg[ch], acc[k][ch]);
+        if (ch < 3) out_color[ch * HW + pix] = v;
+        else out_color2[(ch - 3) * HW + pix] = v;
+      }
+      if (WITH_DEPTH) out_depth[pix] = D[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R7  backward blend
+// ------------------------------------------------------------------------------------------------
+// grad_acc layout per Gaussian (floats): [0,1] dmean2D x,y (pixel units), [2,3,4] dconic A,B,C (true
+// partials), [5] dopacity  -> 8 floats stride;  dcolors go straight to the output tensor.
+constexpr int kAccStride = 8;
+
+// SPLIT (fused 6-channel pass): channels 0..2 are the RGB pass, 3..5 the depth/silhouette pass of the
+// reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
+// `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
+template <int C, bool SPLIT>
+__global__ __launch_bounds__(256) void blend_bwd_kernel(
+    CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
+    const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ colors,
+    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+    const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
+    float *__restrict__ dcolors) {
+  const int lane = threadIdx.x & 63;
+  const int vb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile = vb * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int W = cam.W, H = cam.H;
+  const size_t HW = (size_t)H * W;
+  const int px_i = (tile % cam.gx) * FSGS_TILE + (lane & 15);
+  const int py_i = (tile / cam.gx) * FSGS_TILE + (lane >> 4);
+  const float px = (float)px_i;
+  float py[4], T[4], Tfin[4], bgdot[4], bgdot_rgb[4], aprev[4], g[4][C], acc[4][C], cprev[4][C];
+  int last[4];
+  int mylast = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int y = py_i + 4 * k;
+    py[k] = (float)y;
+    bool inside = px_i < W && y < H;
+    size_t pix = inside ? (size_t)y * W + px_i : 0;
+    Tfin[k] = inside ? final_T[pix] : 0.0f;
+    T[k] = Tfin[k];
+    last[k] = inside ? (int)n_contrib[pix] : 0;
+    mylast = max(mylast, last[k]);
+    aprev[k] = 0.0f;
+    bgdot[k] = 0.0f;
+    bgdot_rgb[k] = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+      // channels >= 3 of the fused pass come from their own tensor; a missing tensor is a zero gradient
+      const float *gp = ch < 3 ? dL_dcolor : dL_dcolor2;
+      g[k][ch] = (inside && gp) ? gp[(ch < 3 ? ch : ch - 3) * HW + pix] : 0.0f;
+      bgdot[k] = fmaf(cam.bg[ch], g[k][ch], bgdot[k]);
+      if (SPLIT && ch < 3) bgdot_rgb[k] = fmaf(cam.bg[ch], g[k][ch], bgdot_rgb[k]);
+      acc[k][ch] = 0.0f;
+      cprev[k][ch] = 0.0f;
+    }
+  }
+  const int2 rg = ranges[tile];
+  int hi = wave_max(mylast);  // nothing behind the deepest contributor matters to anyone in the tile
+  while (hi > 0) {
+    const int lo = max(0, hi - 64);
+    const int n = hi - lo;
+    uint32_t gid = plist[rg.x + lo + (lane < n ? lane : 0)];
+    float2 gxy = xy[gid];
+    float4 gco = conic_op[gid];
+    float gcol[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
+    // lane j will hold the tile's total for Gaussian j
+    float o_mx = 0.f, o_my = 0.f, o_A = 0.f, o_B = 0.f, o_C = 0.f, o_op = 0.f, o_mxr = 0.f, o_myr = 0.f;
+    float o_col[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) o_col[ch] = 0.f;
+    for (int j = n - 1; j >= 0; j--) {
+      const int pos = lo + j;  // 0-based index in the tile list
+      const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
+      const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
+      const float bo = readlane(gco.w, j);
+      float bcol[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
+      float s_mx = 0.f, s_my = 0.f, s_A = 0.f, s_B = 0.f, s_C = 0.f, s_op = 0.f, s_mxr = 0.f, s_myr = 0.f;
+      float s_col[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) s_col[ch] = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (pos >= last[k]) continue;
+        SplatEval e;
+        if (!splat_alpha(bx, by, bA, bB, bC, bo, px, py[k], e)) continue;
+        any = true;
+        float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
+        T[k] = T[k] * inv1ma;
+        float wgt = e.alpha * T[k];
+        float dL_dalpha = 0.0f, dL_dalpha_rgb = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) {
+          acc[k][ch] = fmaf(aprev[k], cprev[k][ch], (1.0f - aprev[k]) * acc[k][ch]);
+          cprev[k][ch] = bcol[ch];
+          dL_dalpha = fmaf(bcol[ch] - acc[k][ch], g[k][ch], dL_dalpha);
+          if (SPLIT && ch == 2) dL_dalpha_rgb = dL_dalpha;
+          s_col[ch] = fmaf(wgt, g[k][ch], s_col[ch]);
+        }
+        dL_dalpha *= T[k];
+        aprev[k] = e.alpha;
+        const float bgw = -Tfin[k] * inv1ma;
+        dL_dalpha = fmaf(bgw, bgdot[k], dL_dalpha);
+        float dL_dG = bo * dL_dalpha;
+        float gdx = e.G * e.dx, gdy = e.G * e.dy;
+        float dG_ddx = -gdx * bA - gdy * bB;
+        float dG_ddy = -gdy * bC - gdx * bB;
+        s_mx = fmaf(dL_dG, dG_ddx, s_mx);
+        s_my = fmaf(dL_dG, dG_ddy, s_my);
+        if (SPLIT) {
+          float dG_rgb = bo * fmaf(bgw, bgdot_rgb[k], dL_dalpha_rgb * T[k]);
+          s_mxr = fmaf(dG_rgb, dG_ddx, s_mxr);
+          s_myr = fmaf(dG_rgb, dG_ddy, s_myr);
+        }
+        s_A = fmaf(-0.5f * gdx * e.dx, dL_dG, s_A);
+        s_B = fmaf(-gdx * e.dy, dL_dG, s_B);
+        s_C = fmaf(-0.5f * gdy * e.dy, dL_dG, s_C);
+        s_op = fmaf(e.G, dL_dalpha, s_op);
+      }
+      if (__ballot(any) == 0ull) continue;  // wave-uniform: nobody in the tile is touched
+      // NB: the reductions must run with the whole wave active -- evaluate them BEFORE the select
+      // (a C++ `mine ? wave_sum(x) : o` would execute the DPP ops in lane j only).
+      const float t_mx = wave_sum(s_mx), t_my = wave_sum(s_my), t_A = wave_sum(s_A), t_B = wave_sum(s_B);
+      const float t_C = wave_sum(s_C), t_op = wave_sum(s_op);
+      const float t_mxr = SPLIT ? wave_sum(s_mxr) : 0.f, t_myr = SPLIT ? wave_sum(s_myr) : 0.f;
+      float t_col[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) t_col[ch] = wave_sum(s_col[ch]);
+      const bool mine = lane == j;  // lane j keeps the tile total of Gaussian j
+      o_mx = mine ? t_mx : o_mx;
+      o_my = mine ? t_my : o_my;
+      o_A = mine ? t_A : o_A;
+      o_B = mine ? t_B : o_B;
+      o_C = mine ? t_C : o_C;
+      o_op = mine ? t_op : o_op;
+      if (SPLIT) {
+        o_mxr = mine ? t_mxr : o_mxr;
+        o_myr = mine ? t_myr : o_myr;
+      }
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) o_col[ch] = mine ? t_col[ch] : o_col[ch];
+    }
+    if (lane < n) {
+      float *ga = grad_acc + (size_t)gid * kAccStride;
+      if (o_mx != 0.f) atomicAdd(ga + 0, o_mx);
+      if (o_my != 0.f) atomicAdd(ga + 1, o_my);
+      if (o_A != 0.f) atomicAdd(ga + 2, o_A);
+      if (o_B != 0.f) atomicAdd(ga + 3, o_B);
+      if (o_C != 0.f) atomicAdd(ga + 4, o_C);
+      if (o_op != 0.f) atomicAdd(ga + 5, o_op);
+      if (SPLIT) {
+        if (o_mxr != 0.f) atomicAdd(ga + 6, o_mxr);
+        if (o_myr != 0.f) atomicAdd(ga + 7, o_myr);
+      }
+#pragma unroll
+      for (int ch = 0; ch < C; ch++)
+        if (o_col[ch] != 0.f) atomicAdd(dcolors + (size_t)gid * C + ch, o_col[ch]);
+    }
+    hi = lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R8 + R9  per-Gaussian backward chain, shared like project_gaussian
+// ------------------------------------------------------------------------------------------------
+struct GeomGrad {
+  float m2x, m2y;  // dL/dmean2D in NDC units (what add_densification_stats norms)
+  float dop;       // dL/d(activated opacity)
+  float dm[3];     // dL/dmean3D
+  float ds[3];     // dL/d(activated scale)
+  float dq[4];     // dL/d(quaternion as handed over)
+};
+// ga: the 8-float accumulator row of this Gaussian written by blend_bwd (pixel-unit mean2D, true conic
+// partials, opacity).  Only call for radii > 0.
+__device__ __forceinline__ GeomGrad geom_backward(const CamParams &cam, float mx, float my, float mz, float3 s_in,
+                                                  float4 q, const float *ga) {
+  GeomGrad out;
+  {
+    out.m2x = ga[0] * (0.5f * cam.W);
+    out.m2y = ga[1] * (0.5f * cam.H);
+    const float gA = ga[2], gB = ga[3], gC = ga[4];
+    out.dop = ga[5];
+    const float *V = cam.V, *PM = cam.PM;
+    float3 t;
+    t.x = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+    t.y = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+    t.z = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    const float mod = cam.scale_modifier;
+    float3 s = make_float3(mod * s_in.x, mod * s_in.y, mod * s_in.z);
+    Mat3 R = quat_to_R(q);
+    float c6[6];
+    cov3d(s, R, c6);
+    Ewa e;
+    ewa_project(V, t, c6, cam.fx, cam.fy, cam.tanfovx, cam.tanfovy, e);
+    // A.5 conic -> cov2D
+    float a = e.a, b = e.b, c = e.c;
+    float D = a * c - b * b;
+    float D2 = 1.0f / (D * D + 0.0000001f);
+    float dL_da = D2 * (-c * c * gA + b * c * gB + (D - a * c) * gC);
+    float dL_dc = D2 * (-a * a * gC + a * b * gB + (D - a * c) * gA);
+    float dL_db = D2 * (2.f * b * c * gA - (D + 2.f * b * b) * gB + 2.f * a * b * gC);
+    float hb = 0.5f * dL_db;
+    // A.6 dL/dSigma = M^T G2 M
+    float G3[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        G3[3 * r + cc] = e.M0[r] * (dL_da * e.M0[cc] + hb * e.M1[cc]) + e.M1[r] * (hb * e.M0[cc] + dL_dc * e.M1[cc]);
+    float dM0[3], dM1[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      dM0[cc] = 2.f * (dL_da * e.SM0[cc] + hb * e.SM1[cc]);
+      dM1[cc] = 2.f * (hb * e.SM0[cc] + dL_dc * e.SM1[cc]);
+    }
+    // Wv[r][c] = V[4*c + r]
+    float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
+    float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
+    float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
+    float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
+    float itz = 1.0f / e.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    float dtx = e.chix * -cam.fx * itz2 * dJ02;
+    float dty = e.chiy * -cam.fy * itz2 * dJ12;
+    float dtz = -cam.fx * itz2 * dJ00 - cam.fy * itz2 * dJ11 + (2.f * cam.fx * e.tx) * itz3 * dJ02 +
+                (2.f * cam.fy * e.ty) * itz3 * dJ12;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) out.dm[cc] = V[4 * cc + 0] * dtx + V[4 * cc + 1] * dty + V[4 * cc + 2] * dtz;
+    // A.7 projection
+    float h0 = PM[0] * mx + PM[4] * my + PM[8] * mz + PM[12];
+    float h1 = PM[1] * mx + PM[5] * my + PM[9] * mz + PM[13];
+    float h3 = PM[3] * mx + PM[7] * my + PM[11] * mz + PM[15];
+    float mw = 1.0f / (h3 + 0.0000001f);
+    float mul1 = h0 * mw * mw, mul2 = h1 * mw * mw;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float P0k = PM[4 * k + 0], P1k = PM[4 * k + 1], P3k = PM[4 * k + 3];
+      out.dm[k] += (P0k * mw - P3k * mul1) * out.m2x + (P1k * mw - P3k * mul2) * out.m2y;
+    }
+    // A.8 Sigma -> scale, quaternion
+    float GR[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        GR[3 * r + cc] = G3[3 * r] * R.m[cc] + G3[3 * r + 1] * R.m[3 + cc] + G3[3 * r + 2] * R.m[6 + cc];
+    const float sv[3] = {s.x, s.y, s.z};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float rtgr = R.m[j] * GR[j] + R.m[3 + j] * GR[3 + j] + R.m[6 + j] * GR[6 + j];
+      out.ds[j] = 2.f * sv[j] * rtgr * mod;
+    }
+    float dR[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) dR[3 * r + cc] = 2.f * GR[3 * r + cc] * sv[cc] * sv[cc];
+    const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+    out.dq[0] = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+    out.dq[1] = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] -
+                   2.f * qx * dR[8]);
+    out.dq[2] = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] -
+                   2.f * qy * dR[8]);
+    out.dq[3] = 2.f * (-2.f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.f * qz * dR[4] + qy * dR[5] +
+                   qx * dR[6] + qy * dR[7]);
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    int P, CamParams cam, const float *__restrict__ means3D, const float *__restrict__ scales,
+    const float *__restrict__ rots, const int32_t *__restrict__ radii, const float *__restrict__ grad_acc,
+    float *__restrict__ dmeans2D, float *__restrict__ dopac, float *__restrict__ dmeans3D,
+    float *__restrict__ dscales, float *__restrict__ drots) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  GeomGrad r;
+  r.m2x = r.m2y = r.dop = 0.f;
+  r.dm[0] = r.dm[1] = r.dm[2] = 0.f;
+  r.ds[0] = r.ds[1] = r.ds[2] = 0.f;
+  r.dq[0] = r.dq[1] = r.dq[2] = r.dq[3] = 0.f;
+  if (radii[i] > 0) {
+    float3 s = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
+    float4 q = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
+    r = geom_backward(cam, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], s, q,
+                      grad_acc + (size_t)i * kAccStride);
+  }
+  dmeans2D[3 * i] = r.m2x; dmeans2D[3 * i + 1] = r.m2y; dmeans2D[3 * i + 2] = 0.f;
+  dopac[i] = r.dop;
+  dmeans3D[3 * i] = r.dm[0]; dmeans3D[3 * i + 1] = r.dm[1]; dmeans3D[3 * i + 2] = r.dm[2];
+  dscales[3 * i] = r.ds[0]; dscales[3 * i + 1] = r.ds[1]; dscales[3 * i + 2] = r.ds[2];
+  drots[4 * i] = r.dq[0]; drots[4 * i + 1] = r.dq[1]; drots[4 * i + 2] = r.dq[2]; drots[4 * i + 3] = r.dq[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+CamParams make_cam(const FsgsRasterCfg *cfg) {
+  CamParams c;
+  c.W = cfg->image_width;
+  c.H = cfg->image_height;
+  c.gx = (c.W + FSGS_TILE - 1) / FSGS_TILE;
+  c.gy = (c.H + FSGS_TILE - 1) / FSGS_TILE;
+  c.tanfovx = cfg->tanfovx;
+  c.tanfovy = cfg->tanfovy;
+  c.fx = c.W / (2.0f * cfg->tanfovx);
+  c.fy = c.H / (2.0f * cfg->tanfovy);
+  c.scale_modifier = cfg->scale_modifier;
+  memcpy(c.V, cfg->viewmatrix, sizeof(c.V));
+  memcpy(c.PM, cfg->projmatrix, sizeof(c.PM));
+  memcpy(c.bg, cfg->bg, sizeof(c.bg));
+  return c;
+}
+
+int tile_bits(int ntiles) {
+  int b = 1;
+  while ((1 << b) < ntiles) b++;
+  return b;
+}
+
+struct StateLayout {
+  size_t xy, conic_op, depth, ranges, final_T, n_contrib, plist, colors, flags, total;
+};
+// keep_channels > 0: the fused render also keeps colours[P, keep_channels] and a flag byte per Gaussian
+StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0) {
+  StateLayout L;
+  Carver c;
+  int ntiles = ((W + FSGS_TILE - 1) / FSGS_TILE) * ((H + FSGS_TILE - 1) / FSGS_TILE);
+  L.xy = c.take(sizeof(float2) * (size_t)P);
+  L.conic_op = c.take(sizeof(float4) * (size_t)P);
+  L.depth = c.take(sizeof(float) * (size_t)P);
+  L.ranges = c.take(sizeof(int2) * (size_t)ntiles);
+  L.final_T = c.take(sizeof(float) * (size_t)W * H);
+  L.n_contrib = c.take(sizeof(uint32_t) * (size_t)W * H);
+  L.plist = c.take(sizeof(uint32_t) * (size_t)cap);
+  L.colors = L.flags = 0;
+  if (keep_channels > 0) {
+    L.colors = c.take(sizeof(float) * (size_t)P * keep_channels);
+    L.flags = c.take((size_t)P * 4);
+  }
+  L.total = c.total();
+  return L;
+}
+
+struct ScratchLayout {
+  size_t tiles, rect, key_a, key_b, idx_a, idx_b, incl, pk_a, pk_b, pv_a, temp, temp_bytes, total;
+};
+int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
+  Carver c;
+  size_t Pn = (size_t)(P > 0 ? P : 1), Rn = (size_t)(cap > 0 ? cap : 1);
+  L.tiles = c.take(4 * Pn);
+  L.rect = c.take(8 * Pn);
+  L.key_a = c.take(4 * Pn);
+  L.key_b = c.take(4 * Pn);
+  L.idx_a = c.take(4 * Pn);
+  L.idx_b = c.take(4 * Pn);
+  L.incl = c.take(4 * Pn);
+  L.pk_a = c.take(4 * Rn);
+  L.pk_b = c.take(4 * Rn);
+  L.pv_a = c.take(4 * Rn);
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  uint32_t *nu = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, t1, nu, nu, nu, nu, Pn, 0, 32, (hipStream_t)0) != hipSuccess) return -1;
+  if (rocprim::radix_sort_pairs(nullptr, t2, nu, nu, nu, nu, Rn, 0, 20, (hipStream_t)0) != hipSuccess) return -1;
+  TilesInDepthOrder f{nullptr};
+  auto it = rocprim::make_transform_iterator(nu, f);
+  if (rocprim::inclusive_scan(nullptr, t3, it, nu, Pn, rocprim::plus<uint32_t>(), (hipStream_t)0) != hipSuccess)
+    return -1;
+  L.temp_bytes = t1 > t2 ? t1 : t2;
+  if (t3 > L.temp_bytes) L.temp_bytes = t3;
+  L.temp_bytes += 256;
+  L.temp = c.take(L.temp_bytes);
+  L.total = c.total();
+  return 0;
+}
+
+struct FwdBuffers {
+  float2 *xy; float4 *co; float *depth; int2 *ranges; float *final_T; uint32_t *n_contrib; uint32_t *plist;
+  float *colors; uint32_t *flags;
+  uint32_t *tiles; ushort4 *rect; uint32_t *key_a, *key_b, *idx_a, *idx_b, *incl, *pk_a, *pk_b, *pv_a;
+  void *temp; size_t temp_bytes;
+};
+int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channels, void *state, size_t state_bytes,
+                         void *scratch, size_t scratch_bytes, FwdBuffers &B) {
+  StateLayout SL = state_layout(P, W, H, max_pairs, keep_channels);
+  ScratchLayout XL;
+  if (scratch_layout(P, W, H, max_pairs, XL) != 0) return fsgs_fail("rocprim size query");
+  if (state_bytes < SL.total || scratch_bytes < XL.total) return FSGS_ERR_CAPACITY;
+  char *sb = (char *)state, *xb = (char *)scratch;
+  B.xy = (float2 *)(sb + SL.xy); B.co = (float4 *)(sb + SL.conic_op); B.depth = (float *)(sb + SL.depth);
+  B.ranges = (int2 *)(sb + SL.ranges); B.final_T = (float *)(sb + SL.final_T);
+  B.n_contrib = (uint32_t *)(sb + SL.n_contrib); B.plist = (uint32_t *)(sb + SL.plist);
+  B.colors = keep_channels ? (float *)(sb + SL.colors) : nullptr;
+  B.flags = keep_channels ? (uint32_t *)(sb + SL.flags) : nullptr;
+  B.tiles = (uint32_t *)(xb + XL.tiles); B.rect = (ushort4 *)(xb + XL.rect);
+  B.key_a = (uint32_t *)(xb + XL.key_a); B.key_b = (uint32_t *)(xb + XL.key_b);
+  B.idx_a = (uint32_t *)(xb + XL.idx_a); B.idx_b = (uint32_t *)(xb + XL.idx_b);
+  B.incl = (uint32_t *)(xb + XL.incl);
+  B.pk_a = (uint32_t *)(xb + XL.pk_a); B.pk_b = (uint32_t *)(xb + XL.pk_b); B.pv_a = (uint32_t *)(xb + XL.pv_a);
+  B.temp = xb + XL.temp; B.temp_bytes = XL.temp_bytes;
+  return FSGS_OK;
+}
+// everything between the preprocess kernel and the blend: depth sort, tile-count scan, the one host sync
+// that reads R, pair emission, stable sort by tile, tile ranges.  ranges must be zeroed by the caller.
+int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, int64_t *num_rendered,
+                hipStream_t stream) {
+  const int ntiles = cam.gx * cam.gy;
+  uint32_t R = 0;
+  if (P > 0) {
+    {
+      ProfScope ps(PROF_SORT_DEPTH, stream);
+      FSGS_HIP(rocprim::radix_sort_pairs(B.temp, B.temp_bytes, B.key_a, B.key_b, B.idx_a, B.idx_b, (size_t)P, 0, 32,
+                                         stream));
+    }
+    TilesInDepthOrder f{B.tiles};
+    auto it = rocprim::make_transform_iterator(B.idx_b, f);
+    {
+      ProfScope ps(PROF_SCAN, stream);
+      FSGS_HIP(rocprim::inclusive_scan(B.temp, B.temp_bytes, it, B.incl, (size_t)P, rocprim::plus<uint32_t>(),
+                                       stream));
+    }
+    FSGS_HIP(hipMemcpyAsync(&R, B.incl + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FSGS_HIP(hipStreamSynchronize(stream));  // the one host sync (UPSTREAM R2 does the same)
+  }
+  *num_rendered = (int64_t)R;
+  if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
+  if (R > 0) {
+    {
+      ProfScope ps(PROF_EMIT, stream);
+      hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.idx_b, B.incl,
+                         B.tiles, B.rect, B.pk_a, B.pv_a);
+    }
+    FSGS_HIP(hipGetLastError());
+    {
+      ProfScope ps(PROF_SORT_TILE, stream);
+      FSGS_HIP(rocprim::radix_sort_pairs(B.temp, B.temp_bytes, B.pk_a, B.pk_b, B.pv_a, B.plist, (size_t)R, 0,
+                                         tile_bits(ntiles), stream));
+    }
+    {
+      ProfScope ps(PROF_RANGES, stream);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, B.pk_b, B.ranges);
+    }
+    FSGS_HIP(hipGetLastError());
+  }
+  return FSGS_OK;
+}
+
+template <int C, bool WITH_DEPTH = true>
+int launch_blend_fwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
+                     const float4 *co, const float *depth, const float *colors, float *final_T, uint32_t *n_contrib,
+                     float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
+  int blocks = (ntiles + 3) / 4;
+  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(blocks), dim3(256), 0, s, cam, ntiles, ranges, plist, xy,
+                     co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
+  return 0;
+}
+template <int C, bool SPLIT = false>
+int launch_blend_bwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
+                     const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
+                     const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
+  int blocks = (ntiles + 3) / 4;
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(blocks), dim3(256), 0, s, cam, ntiles, ranges, plist, xy, co,
+                     colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
+  return 0;
+}
+
+}  // namespace

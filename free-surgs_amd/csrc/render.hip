@@ -1,0 +1,372 @@
+// render.hip -- the fused render op behind `render(viewpoint_camera, index, pc, gs_grad, cam_grad)`
+// (gaussian_renderer/__init__.py:49-92) for gfx950.
+//
+// The reference issues ~40 small PyTorch kernels and TWO full rasteriser invocations per call
+// (RGB pass; depth / silhouette / depth^2 pass, gaussian_renderer/__init__.py:68-69).  Both passes
+// see the same geometry, so here ONE preprocess, ONE binning and ONE 6-channel blend produce both
+// images, and the per-Gaussian glue runs inside the preprocess kernels:
+//   forward : transform_to_frame (scene/pose_optimizer.py:960-989), exp / sigmoid / normalize
+//             (scene/gaussian_model.py:38-46), eval_sh + clamp_min(+0.5)
+//             (scene/gaussian_model.py:316-320, utils/sh_utils.py:57-112), the (z, 1, z^2)
+//             pseudo-colours (scene/gaussian_model.py:260-275) and the EWA projection;
+//   backward: their adjoints, including the camera-pose gradient
+//             dL/dw2c[:3,:4] = sum_i g_i [x_i;1]^T reduced in-kernel (wave DPP + one atomic per block).
+// `viewspace_points.grad` is the RGB pass's own mean2D gradient (blend_bwd SPLIT slots 6,7).
+#include "raster_kernels.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+// basis values b[k] and their gradients w.r.t. the unit direction (x,y,z), reference ordering/signs
+// (utils/sh_utils.py:74-104).  deg <= 3 -> 16 functions.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float *b) {
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+      b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+      if (deg > 2) {
+        b[9] = SH_C3[0] * y * (3.f * xx - yy); b[10] = SH_C3[1] * xy * z;
+        b[11] = SH_C3[2] * y * (4.f * zz - xx - yy); b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = SH_C3[4] * x * (4.f * zz - xx - yy); b[14] = SH_C3[5] * z * (xx - yy);
+        b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float *bx, float *by, float *bz) {
+  bx[0] = by[0] = bz[0] = 0.f;
+  if (deg > 0) {
+    bx[1] = 0.f; by[1] = -SH_C1; bz[1] = 0.f;
+    bx[2] = 0.f; by[2] = 0.f; bz[2] = SH_C1;
+    bx[3] = -SH_C1; by[3] = 0.f; bz[3] = 0.f;
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z;
+      bx[4] = SH_C2[0] * y; by[4] = SH_C2[0] * x; bz[4] = 0.f;
+      bx[5] = 0.f; by[5] = SH_C2[1] * z; bz[5] = SH_C2[1] * y;
+      bx[6] = SH_C2[2] * -2.f * x; by[6] = SH_C2[2] * -2.f * y; bz[6] = SH_C2[2] * 4.f * z;
+      bx[7] = SH_C2[3] * z; by[7] = 0.f; bz[7] = SH_C2[3] * x;
+      bx[8] = SH_C2[4] * 2.f * x; by[8] = SH_C2[4] * -2.f * y; bz[8] = 0.f;
+      if (deg > 2) {
+        bx[9] = SH_C3[0] * 6.f * x * y; by[9] = SH_C3[0] * (3.f * xx - 3.f * yy); bz[9] = 0.f;
+        bx[10] = SH_C3[1] * y * z; by[10] = SH_C3[1] * x * z; bz[10] = SH_C3[1] * x * y;
+        bx[11] = SH_C3[2] * -2.f * x * y; by[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); bz[11] = SH_C3[2] * 8.f * y * z;
+        bx[12] = SH_C3[3] * -6.f * x * z; by[12] = SH_C3[3] * -6.f * y * z; bz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+        bx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); by[13] = SH_C3[4] * -2.f * x * y; bz[13] = SH_C3[4] * 8.f * x * z;
+        bx[14] = SH_C3[5] * 2.f * x * z; by[14] = SH_C3[5] * -2.f * y * z; bz[14] = SH_C3[5] * (xx - yy);
+        bx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); by[15] = SH_C3[6] * -6.f * x * y; bz[15] = 0.f;
+      }
+    }
+  }
+}
+
+struct RenderDev {  // FsgsRenderArgs on the device side
+  const float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation, *w2c, *cam_center;
+  int deg, K;  // active degree, coefficients per channel of the stored features ((max_deg+1)^2)
+};
+
+struct Activated {
+  float xc, yc, zc;   // camera-frame mean (transform_to_frame)
+  float3 scale;       // exp
+  float4 q;           // normalised quaternion
+  float qnorm;        // max(||raw||, 1e-12)
+  float op;           // sigmoid
+};
+__device__ __forceinline__ Activated activate(const RenderDev &a, int i) {
+  Activated o;
+  const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+  const float *w = a.w2c;  // wave-uniform address -> scalar loads
+  o.xc = w[0] * x + w[1] * y + w[2] * z + w[3];
+  o.yc = w[4] * x + w[5] * y + w[6] * z + w[7];
+  o.zc = w[8] * x + w[9] * y + w[10] * z + w[11];
+  o.scale = make_float3(expf(a.scaling[3 * i]), expf(a.scaling[3 * i + 1]), expf(a.scaling[3 * i + 2]));
+  float4 r = make_float4(a.rotation[4 * i], a.rotation[4 * i + 1], a.rotation[4 * i + 2], a.rotation[4 * i + 3]);
+  o.qnorm = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);  // F.normalize eps
+  float inv = 1.0f / o.qnorm;
+  o.q = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+  o.op = 1.0f / (1.0f + expf(-a.opacity[i]));
+  return o;
+}
+
+__global__ __launch_bounds__(256) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
+                                                             float *__restrict__ colors6,
+                                                             uint32_t *__restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  Activated act = activate(a, i);
+  // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
+  float dx = a.xyz[3 * i] - a.cam_center[0], dy = a.xyz[3 * i + 1] - a.cam_center[1],
+        dz = a.xyz[3 * i + 2] - a.cam_center[2];
+  float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= inv_n; dy *= inv_n; dz *= inv_n;
+  float b[16];
+  sh_basis(a.deg, dx, dy, dz, b);
+  const int nk = (a.deg + 1) * (a.deg + 1);
+  float rgb[3];
+  uint32_t fl = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float v = b[0] * a.f_dc[3 * i + c];
+    for (int k = 1; k < nk; k++) v = fmaf(b[k], a.f_rest[((size_t)i * (a.K - 1) + (k - 1)) * 3 + c], v);
+    v += 0.5f;
+    if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
+    rgb[c] = v;
+  }
+  // depth pseudo-colours: row 2 of cam.viewmatrix[0] AS STORED times [x_cam;1] (scene/gaussian_model.py:266-271)
+  const float *V = cam.V;
+  float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
+  float *c6 = colors6 + (size_t)i * 6;
+  c6[0] = rgb[0]; c6[1] = rgb[1]; c6[2] = rgb[2]; c6[3] = zq; c6[4] = 1.0f; c6[5] = zq * zq;
+  flags[i] = fl;
+  float3 s = make_float3(cam.scale_modifier * act.scale.x, cam.scale_modifier * act.scale.y,
+                         cam.scale_modifier * act.scale.z);
+  Projected o = project_gaussian(cam, act.xc, act.yc, act.zc, s, act.q, act.op);
+  store_projected(g, i, o);
+}
+
+struct RenderGradsDev {
+  float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation, *means2D, *w2c;
+};
+
+// mode bits
+constexpr int MODE_GS_GRAD = 1;     // means3D gradient flows to _xyz (gs_grad=True)
+constexpr int MODE_CAM_GRAD = 2;    // reduce dL/dw2c (cam_grad=True)
+constexpr int MODE_PARAM_GRAD = 4;  // gradients of features / opacity / scaling / rotation (+ _xyz through the SH direction)
+
+__global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
+                                                             const int32_t *__restrict__ radii,
+                                                             const float *__restrict__ grad_acc,
+                                                             const float *__restrict__ dcolors6,
+                                                             const uint32_t *__restrict__ flags, int mode,
+                                                             RenderGradsDev out) {
+  __shared__ float red[12][4];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float gxc[3] = {0.f, 0.f, 0.f};  // dL/dx_cam
+  float xw[3] = {0.f, 0.f, 0.f};
+  float dxyz[3] = {0.f, 0.f, 0.f};
+  const bool live = i < P && radii[i] > 0;
+  if (i < P) {
+    xw[0] = a.xyz[3 * i]; xw[1] = a.xyz[3 * i + 1]; xw[2] = a.xyz[3 * i + 2];
+  }
+  float m2x = 0.f, m2y = 0.f;
+  if (live) {
+    Activated act = activate(a, i);
+    const float *ga = grad_acc + (size_t)i * kAccStride;
+    GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
+    m2x = ga[6] * (0.5f * cam.W);
+    m2y = ga[7] * (0.5f * cam.H);
+    const float *dc = dcolors6 + (size_t)i * 6;
+    const float *V = cam.V;
+    float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
+    float dzq = dc[3] + 2.f * zq * dc[5];
+    gxc[0] = gg.dm[0] + V[8] * dzq;
+    gxc[1] = gg.dm[1] + V[9] * dzq;
+    gxc[2] = gg.dm[2] + V[10] * dzq;
+    if (mode & MODE_GS_GRAD) {
+      const float *w = a.w2c;
+      dxyz[0] = w[0] * gxc[0] + w[4] * gxc[1] + w[8] * gxc[2];
+      dxyz[1] = w[1] * gxc[0] + w[5] * gxc[1] + w[9] * gxc[2];
+      dxyz[2] = w[2] * gxc[0] + w[6] * gxc[1] + w[10] * gxc[2];
+    }
+    if (mode & MODE_PARAM_GRAD) {
+      // activations
+      out.scaling[3 * i] = gg.ds[0] * act.scale.x;
+      out.scaling[3 * i + 1] = gg.ds[1] * act.scale.y;
+      out.scaling[3 * i + 2] = gg.ds[2] * act.scale.z;
+      float qd = act.q.x * gg.dq[0] + act.q.y * gg.dq[1] + act.q.z * gg.dq[2] + act.q.w * gg.dq[3];
+      float inv = 1.0f / act.qnorm;
+      out.rotation[4 * i] = (gg.dq[0] - act.q.x * qd) * inv;
+      out.rotation[4 * i + 1] = (gg.dq[1] - act.q.y * qd) * inv;
+      out.rotation[4 * i + 2] = (gg.dq[2] - act.q.z * qd) * inv;
+      out.rotation[4 * i + 3] = (gg.dq[3] - act.q.w * qd) * inv;
+      out.opacity[i] = gg.dop * act.op * (1.0f - act.op);
+      // SH colour
+      float vx = xw[0] - a.cam_center[0], vy = xw[1] - a.cam_center[1], vz = xw[2] - a.cam_center[2];
+      float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      float dx = vx * inv_n, dy = vy * inv_n, dz = vz * inv_n;
+      float b[16], bx[16], by[16], bz[16];
+      sh_basis(a.deg, dx, dy, dz, b);
+      sh_basis_grad(a.deg, dx, dy, dz, bx, by, bz);
+      const int nk = (a.deg + 1) * (a.deg + 1);
+      const uint32_t fl = flags[i];
+      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
+        out.f_dc[3 * i + c] = b[0] * gcol;
+        for (int k = 1; k < a.K; k++) {
+          size_t at = ((size_t)i * (a.K - 1) + (k - 1)) * 3 + c;
+          if (k < nk) {
+            float coef = a.f_rest[at];
+            out.f_rest[at] = b[k] * gcol;
+            ddx = fmaf(gcol * coef, bx[k], ddx);
+            ddy = fmaf(gcol * coef, by[k], ddy);
+            ddz = fmaf(gcol * coef, bz[k], ddz);
+          } else {
+            out.f_rest[at] = 0.f;
+          }
+        }
+      }
+      // d = v/|v|  ->  dv = (dd - d (d.dd)) / |v|
+      float dot = dx * ddx + dy * ddy + dz * ddz;
+      dxyz[0] += (ddx - dx * dot) * inv_n;
+      dxyz[1] += (ddy - dy * dot) * inv_n;
+      dxyz[2] += (ddz - dz * dot) * inv_n;
+    }
+  } else if (i < P && (mode & MODE_PARAM_GRAD)) {
+    out.scaling[3 * i] = out.scaling[3 * i + 1] = out.scaling[3 * i + 2] = 0.f;
+    out.rotation[4 * i] = out.rotation[4 * i + 1] = out.rotation[4 * i + 2] = out.rotation[4 * i + 3] = 0.f;
+    out.opacity[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) out.f_dc[3 * i + c] = 0.f;
+    for (int k = 0; k < (a.K - 1) * 3; k++) out.f_rest[(size_t)i * (a.K - 1) * 3 + k] = 0.f;
+  }
+  if (i < P) {
+    out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f;
+    if (out.xyz) { out.xyz[3 * i] = dxyz[0]; out.xyz[3 * i + 1] = dxyz[1]; out.xyz[3 * i + 2] = dxyz[2]; }
+  }
+  if (mode & MODE_CAM_GRAD) {  // dL/dw2c[r][c] = sum_i g_r [x;1]_c   (scene/pose_optimizer.py:985-987 adjoint)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float x4[4] = {xw[0], xw[1], xw[2], 1.0f};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float t = wave_sum(gxc[r] * x4[c]);
+        if (lane == 0) red[4 * r + c][wid] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+      float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+      if (t != 0.f) atomicAdd(out.w2c + threadIdx.x, t);
+    }
+  }
+}
+
+RenderDev to_dev(const FsgsRenderArgs *a) {
+  RenderDev d;
+  d.xyz = a->xyz; d.f_dc = a->features_dc; d.f_rest = a->features_rest; d.opacity = a->opacity;
+  d.scaling = a->scaling; d.rotation = a->rotation; d.w2c = a->w2c; d.cam_center = a->cam_center;
+  d.deg = a->active_sh_degree;
+  d.K = (a->max_sh_degree + 1) * (a->max_sh_degree + 1);
+  return d;
+}
+bool args_ok(const FsgsRenderArgs *a, int P) {
+  if (!a) return false;
+  if (a->active_sh_degree < 0 || a->active_sh_degree > 3 || a->max_sh_degree < a->active_sh_degree ||
+      a->max_sh_degree > 3)
+    return false;
+  if (P == 0) return true;
+  if (!a->xyz || !a->features_dc || !a->opacity || !a->scaling || !a->rotation || !a->w2c || !a->cam_center)
+    return false;
+  if (a->max_sh_degree > 0 && !a->features_rest) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *state_bytes, size_t *scratch_bytes) {
+  if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !state_bytes || !scratch_bytes) return FSGS_ERR_INVALID;
+  *state_bytes = state_layout(P, width, height, max_pairs, 6).total;
+  ScratchLayout sl;
+  if (scratch_layout(P, width, height, max_pairs, sl) != 0) return fsgs_fail("rocprim size query");
+  size_t bwd = (size_t)(P > 0 ? P : 1) * (kAccStride + 6) * sizeof(float) + 512;
+  *scratch_bytes = sl.total > bwd ? sl.total : bwd;
+  return FSGS_OK;
+}
+
+int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                        float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
+                        size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cfg || P < 0 || !out_image || !out_depth_sil || !state || !scratch || !num_rendered || max_pairs < 0)
+    return FSGS_ERR_INVALID;
+  if (!args_ok(args, P) || (P > 0 && !radii)) return FSGS_ERR_INVALID;
+  const int W = cfg->image_width, H = cfg->image_height;
+  if (W <= 0 || H <= 0) return FSGS_ERR_INVALID;
+  CamParams cam = make_cam(cfg);
+  for (int ch = 3; ch < 6; ch++) cam.bg[ch] = cfg->bg[ch - 3];  // the second pass uses the same bg tensor
+  const int ntiles = cam.gx * cam.gy;
+  FwdBuffers B;
+  int rc = bind_forward_buffers(P, W, H, max_pairs, 6, state, state_bytes, scratch, scratch_bytes, B);
+  if (rc != FSGS_OK) return rc;
+  FSGS_HIP(hipMemsetAsync(B.ranges, 0, sizeof(int2) * (size_t)ntiles, stream));
+  if (P > 0) {
+    ProfScope ps(PROF_RENDER_PRE_FWD, stream);
+    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.key_a, B.idx_a};
+    hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), g,
+                       B.colors, B.flags);
+  }
+  FSGS_HIP(hipGetLastError());
+  rc = run_binning(cam, P, B, max_pairs, num_rendered, stream);
+  if (rc != FSGS_OK) return rc;
+  {
+    ProfScope ps(PROF_BLEND_FWD, stream);
+    launch_blend_fwd<6, false>(cam, ntiles, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T, B.n_contrib,
+                               out_image, out_depth_sil, nullptr, stream);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                         const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                         const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
+                         int param_grads, const FsgsRenderGrads *grads, void *scratch, size_t scratch_bytes,
+                         fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
+  if (P == 0) return FSGS_OK;
+  if (!args_ok(args, P) || !radii || !scratch || !grads->means2D) return FSGS_ERR_INVALID;
+  if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
+  if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
+  if (param_grads && (!grads->features_dc || !grads->opacity || !grads->scaling || !grads->rotation ||
+                      (args->max_sh_degree > 0 && !grads->features_rest)))
+    return FSGS_ERR_INVALID;
+  const int W = cfg->image_width, H = cfg->image_height;
+  if (max_pairs < 0 || num_rendered < 0 || num_rendered > max_pairs) return FSGS_ERR_STATE;
+  StateLayout SL = state_layout(P, W, H, max_pairs, 6);
+  if (state_bytes < SL.total) return FSGS_ERR_STATE;
+  const size_t need = (size_t)P * (kAccStride + 6) * sizeof(float);
+  if (scratch_bytes < need) return FSGS_ERR_CAPACITY;
+  CamParams cam = make_cam(cfg);
+  for (int ch = 3; ch < 6; ch++) cam.bg[ch] = cfg->bg[ch - 3];
+  const int ntiles = cam.gx * cam.gy;
+  const char *sb = (const char *)state;
+  float *grad_acc = (float *)scratch;
+  float *dcolors6 = grad_acc + (size_t)P * kAccStride;
+  FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
+  if (cam_grad) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
+  if (num_rendered > 0 && (dL_dimage || dL_ddepth_sil)) {
+    ProfScope ps(PROF_BLEND_BWD, stream);
+    launch_blend_bwd<6, true>(cam, ntiles, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
+                              (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),
+                              (const float *)(sb + SL.colors), (const float *)(sb + SL.final_T),
+                              (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
+                              stream);
+  }
+  FSGS_HIP(hipGetLastError());
+  int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);
+  RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
+                     grads->rotation, grads->means2D, grads->w2c};
+  {
+    ProfScope ps(PROF_RENDER_PRE_BWD, stream);
+    hipLaunchKernelGGL(render_pre_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), radii,
+                       grad_acc, dcolors6, (const uint32_t *)(sb + SL.flags), mode, out);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+}  // extern "C"

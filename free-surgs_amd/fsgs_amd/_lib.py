@@ -41,6 +41,17 @@ class FsgsRasterCfg(C.Structure):
     ]
 
 
+class FsgsRenderArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation",
+                                          "w2c", "cam_center")] + [("active_sh_degree", C.c_int32),
+                                                                   ("max_sh_degree", C.c_int32)]
+
+
+class FsgsRenderGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation",
+                                          "means2D", "w2c")]
+
+
 class FsgsError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -73,6 +84,17 @@ _PROTOTYPES = {
         _i,
         [C.POINTER(FsgsRasterCfg), _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
          _vp, _vp, _sz, _vp],
+    ),
+    "fsgs_render_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
+    "fsgs_render_forward": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
+         C.POINTER(_i64), _vp],
+    ),
+    "fsgs_render_backward": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _i, _i, _i,
+         C.POINTER(FsgsRenderGrads), _vp, _sz, _vp],
     ),
     "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
     "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),

@@ -116,6 +116,51 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P,
                          float *dmeans3D, float *dscales, float *drotations,
                          void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
 
+/* ---- fused render (gaussian_renderer.render body) ------------------------------------------------- */
+
+/* Raw GaussianModel.params tensors (scene/gaussian_model.py:350-357) + the current pose.  All DEVICE
+ * pointers, fp32, contiguous.  w2c is row-major [4,4] (the tensor PoseModel.get_pose returns);
+ * cam_center [3] is PoseModel.cam_center (scene/pose_optimizer.py:603). */
+typedef struct FsgsRenderArgs {
+  const float *xyz;           /* [P,3]   */
+  const float *features_dc;   /* [P,1,3] */
+  const float *features_rest; /* [P,(max_sh_degree+1)^2-1,3] */
+  const float *opacity;       /* [P,1] raw (pre-sigmoid)     */
+  const float *scaling;       /* [P,3] raw (log)             */
+  const float *rotation;      /* [P,4] raw (un-normalised)   */
+  const float *w2c;           /* [4,4] */
+  const float *cam_center;    /* [3]   */
+  int32_t active_sh_degree;   /* 0..3 */
+  int32_t max_sh_degree;      /* 0..3 */
+} FsgsRenderArgs;
+
+/* Gradient outputs of fsgs_render_backward, same layouts as FsgsRenderArgs; overwritten.
+ * means2D [P,3] = the RGB pass's NDC-scaled screen gradient (`viewspace_points.grad`).
+ * w2c [4,4]: rows 0..2 = dL/dw2c, row 3 = 0. */
+typedef struct FsgsRenderGrads {
+  float *xyz, *features_dc, *features_rest, *opacity, *scaling, *rotation, *means2D, *w2c;
+} FsgsRenderGrads;
+
+int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *state_bytes, size_t *scratch_bytes);
+
+/* out_image [3,H,W] = the RGB pass; out_depth_sil [3,H,W] = (depth, silhouette, depth^2) pass of
+ * gaussian_renderer/__init__.py:68-73; radii [P].  cfg->channels is ignored; cfg->bg[0..2] is used for
+ * both passes (scene/pose_optimizer.py:624).  Synchronises once like fsgs_raster_forward. */
+int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args,
+                        float *out_image, float *out_depth_sil, int32_t *radii,
+                        void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
+                        int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream);
+
+/* dL_dimage / dL_ddepth_sil [3,H,W] or NULL (= zero).  gs_grad / cam_grad as in render(...):
+ * gs_grad routes the mean gradient to xyz, cam_grad reduces dL/dw2c.  param_grads = 0 skips the
+ * gradients of features / opacity / scaling / rotation (pose-only backward of the tracking step,
+ * observationally equivalent because train.py:220 discards them; SURVEY.md a1 note v). */
+int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                         const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                         const float *dL_dimage, const float *dL_ddepth_sil,
+                         int gs_grad, int cam_grad, int param_grads, const FsgsRenderGrads *grads,
+                         void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+
 /* ---- simple-knn -------------------------------------------------------------- */
 
 /* Mean squared distance to the 3 nearest neighbours, exact (distCUDA2).

@@ -1,0 +1,103 @@
+"""The fused render op (csrc/render.hip) against the reference's own call sequence executed with
+plain torch glue around TWO calls of the rasteriser drop-in (fsgs_amd.render.render_two_pass, whose
+torch statements are pinned by tests/test_golden_host.py).  Outputs and every gradient, all three
+(gs_grad, cam_grad) modes of gaussian_renderer.render(), SH degrees 0..3."""
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd import synth
+from fsgs_amd.model import PARAM_NAMES, GaussianCloud
+from fsgs_amd.render import render, render_two_pass
+from fsgs_amd.trainer import PoseTrack, settings_from_cam
+from tests.util import assert_close_flip_aware
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(W, H, P, deg, seed=0, kind="trained"):
+    cam = synth.make_camera(W, H)
+    sc = (synth.trained_like_scene if kind == "trained" else synth.init_scene)(W, H, P, seed=seed)
+    if kind == "trained":
+        sc = dict(sc)
+    pc = GaussianCloud(sc, sh_degree=3, device=DEV)
+    pc.cam = settings_from_cam(cam, DEV)
+    pc.active_sh_degree = deg
+    poses = PoseTrack(3, DEV)
+    poses.set_pose(1, **{"q": synth.PERTURBED_POSE["q"], "t": synth.PERTURBED_POSE["t"]})
+    return pc, poses
+
+
+def _run(fn, pc, poses, gs_grad, cam_grad, wi, wd, ws):
+    for k in PARAM_NAMES:
+        pc.params[k].grad = None
+    poses.r.grad = None
+    poses.t.grad = None
+    pkg = fn(poses, 1, pc, gs_grad=gs_grad, cam_grad=cam_grad)
+    loss = (pkg["render"] * wi).sum() + (pkg["render_dep"] * wd).sum() + (pkg["render_opacity"] * ws).sum()
+    loss.backward()
+    n = lambda t: None if t is None else t.detach().cpu().numpy().copy()
+    out = {"render": n(pkg["render"]), "render_dep": n(pkg["render_dep"]), "sil": n(pkg["render_opacity"]),
+           "unc": n(pkg["uncertainty"]), "radii": n(pkg["radii"]), "vis": n(pkg["visibility_filter"]),
+           "presence": n(pkg["presence_mask"])}
+    grads = {k: n(pc.params[k].grad) for k in PARAM_NAMES}
+    grads["viewspace"] = n(pkg["viewspace_points"].grad) if gs_grad else None
+    grads["r"] = n(poses.r.grad)
+    grads["t"] = n(poses.t.grad)
+    return out, grads
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [(True, False), (False, True), (True, True)])
+def test_fused_render_equals_two_pass(deg, mode):
+    gs_grad, cam_grad = mode
+    W, H, P = 320, 256, 5000
+    pc, poses = _setup(W, H, P, deg, seed=deg)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    ref_o, ref_g = _run(render_two_pass, pc, poses, gs_grad, cam_grad, wi, wd, ws)
+    # the fused path computes parameter gradients only when gs_grad (pose-only backward otherwise)
+    got_o, got_g = _run(render, pc, poses, gs_grad, cam_grad, wi, wd, ws)
+    assert (got_o["radii"] != ref_o["radii"]).sum() <= 1
+    assert (got_o["vis"] != ref_o["vis"]).sum() == 0
+    for k in ("render", "render_dep", "sil", "unc"):
+        assert_close_flip_aware(got_o[k], ref_o[k], k, floor=1.0)
+    assert (got_o["presence"] != ref_o["presence"]).mean() < 1e-4
+    if cam_grad:
+        for k in ("r", "t"):
+            a, b = got_g[k], ref_g[k]
+            assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() + 1e-9, (k, a, b)  # 300k-term fp32 reductions
+    else:
+        assert got_g["r"] is None or not np.any(got_g["r"])
+    if gs_grad:
+        floor = 1e-3 * max(float(np.abs(ref_g[k]).max()) for k in PARAM_NAMES)
+        for k in PARAM_NAMES + ("viewspace",):
+            assert_close_flip_aware(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1), k, floor=floor, rows=P)
+
+
+def test_viewspace_gradient_excludes_the_depth_pass():
+    """`viewspace_points` is the RGB pass's means2D only (SURVEY.md a1 note i): a loss on the depth
+    pass alone must leave it exactly zero while still moving the Gaussians."""
+    W, H, P = 160, 128, 1500
+    pc, poses = _setup(W, H, P, 0)
+    pkg = render(poses, 1, pc, gs_grad=True, cam_grad=False)
+    pkg["render_dep"].sum().backward()
+    assert float(pkg["viewspace_points"].grad.abs().max()) == 0.0
+    assert float(pc.params["_xyz"].grad.abs().max()) > 0.0
+
+
+def test_render_side_effects_and_dict_keys():
+    """the 10 keys of gaussian_renderer/__init__.py:83-92 and pc.variables updates (:77-80)."""
+    W, H, P = 160, 128, 1500
+    pc, poses = _setup(W, H, P, 0)
+    pkg = render(poses, 0, pc, gs_grad=True, cam_grad=False)
+    assert set(pkg) == {"render", "render_dep", "render_w2c", "render_opacity", "nan_mask", "presence_mask",
+                        "uncertainty", "viewspace_points", "visibility_filter", "radii"}
+    assert pkg["render"].shape == (3, H, W) and pkg["render_dep"].shape == (H, W)
+    assert pkg["uncertainty"].shape == (1, H, W) and not pkg["uncertainty"].requires_grad
+    assert torch.equal(pc.variables["seen"], pkg["radii"] > 0)
+    assert torch.equal(pc.variables["max_radii2D"][pkg["radii"] > 0], pkg["radii"][pkg["radii"] > 0].float())
+    assert pc.variables["means2D"] is pkg["viewspace_points"]
