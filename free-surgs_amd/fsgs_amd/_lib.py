@@ -52,6 +52,11 @@ class FsgsRenderGrads(C.Structure):
                                           "means2D", "w2c")]
 
 
+class FsgsAdamGroup(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("step", C.c_int32)]
+
+
 class FsgsError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -100,6 +105,8 @@ _PROTOTYPES = {
     "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "fsgs_photometric_loss_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "fsgs_pearson_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsgs_adam_step": (_i, [_i, C.POINTER(FsgsAdamGroup), C.c_float, C.c_float, C.c_float, _vp]),
+    "fsgs_densify_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pearson_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 

@@ -80,13 +80,19 @@ class GaussianCloud:
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
 
-    def training_setup(self, opt=OptimizationParams, eps=1e-15):
-        """Adam with the reference's per-group learning rates (scene/gaussian_model.py:382-409)."""
+    def training_setup(self, opt=OptimizationParams, eps=1e-15, fused=True):
+        """Adam with the reference's per-group learning rates (scene/gaussian_model.py:382-409).
+        fused=True: one HIP launch per step (fsgs_amd.optim.FusedAdam); False: torch.optim.Adam."""
         lr = {"_xyz": opt.position_lr_init * self.spatial_lr_scale, "_features_dc": opt.feature_lr,
               "_features_rest": opt.feature_lr / 20.0, "_opacity": opt.opacity_lr, "_scaling": opt.scaling_lr,
               "_rotation": opt.rotation_lr}
         groups = [{"params": [self.params[k]], "lr": lr[k], "name": k} for k in PARAM_NAMES]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=eps)
+        if fused:
+            from .optim import FusedAdam
+
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=eps)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=eps)
         self.opt = opt
         return self.optimizer
 
@@ -99,7 +105,7 @@ class GaussianCloud:
         return lr
 
     def add_densification_stats(self, viewspace_grad, update_filter):
-        """scene/gaussian_model.py:678-681."""
+        """scene/gaussian_model.py:678-681 (torch statement; the trainer uses optim.densify_stats)."""
         self.variables["xyz_gradient_accum"][update_filter] += torch.norm(
             viewspace_grad[update_filter], dim=-1, keepdim=True)
         self.variables["denom"][update_filter] += 1

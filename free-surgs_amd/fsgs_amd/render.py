@@ -42,7 +42,8 @@ def _package(pc, im, radius, depth_sil, w2c, means2D):
     uncertainty = (depth_sq - depth ** 2).detach()
     seen = radius > 0
     pc.variables["means2D"] = means2D
-    pc.variables["max_radii2D"][seen] = torch.max(radius[seen].float(), pc.variables["max_radii2D"][seen])
+    # == max_radii2D[seen] = max(radius[seen], max_radii2D[seen]) (radius is 0 where unseen, maxima are >= 0)
+    pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], radius.to(torch.float32))
     pc.variables["seen"] = seen
     nan_mask = (~torch.isnan(depth)) & (~torch.isnan(uncertainty))
     return {"render": im, "render_dep": depth, "render_w2c": w2c, "render_opacity": silhouette,

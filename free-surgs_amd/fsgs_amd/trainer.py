@@ -55,8 +55,10 @@ class PoseTrack:
     def initialize_tracking_optimizer(self, tracking_iter=50):
         """Adam(lr .01, eps 1e-15) + MultiStepLR(milestones 0,16,32,48; gamma .5)
         (scene/pose_optimizer.py:489-496)."""
-        self.optimizer = torch.optim.Adam([{"params": self.r, "lr": 0.01}, {"params": self.t, "lr": 0.01}],
-                                          lr=0.001, eps=1e-15)
+        from .optim import FusedAdam
+
+        self.optimizer = FusedAdam([{"params": self.r, "lr": 0.01}, {"params": self.t, "lr": 0.01}],
+                                   lr=0.001, eps=1e-15)
         step = int(tracking_iter / 3)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=list(range(0, int(tracking_iter), step)), gamma=0.5)
@@ -109,10 +111,11 @@ def mapping_step(pc, poses, frames, timesteps, fused=True, step_optimizer=True, 
     if grad_sync is not None:  # frame-sharded data parallel: sum the Gaussian gradients over ranks
         grad_sync(pc)
     with torch.no_grad():
-        vis = first["visibility_filter"]
-        mr = pc.variables["max_radii2D"]
-        mr[vis] = torch.max(mr[vis], first["radii"][vis].float())
-        pc.add_densification_stats(first["viewspace_points"].grad, vis)
+        # densification statistics from view 0 (train.py:260-263,298-303) in one launch
+        from . import optim
+
+        optim.densify_stats(first["radii"], first["viewspace_points"].grad, pc.variables["max_radii2D"],
+                            pc.variables["xyz_gradient_accum"], pc.variables["denom"])
         if step_optimizer:
             pc.optimizer.step()
             pc.optimizer.zero_grad(set_to_none=True)

@@ -196,6 +196,29 @@ int fsgs_pearson_backward(int H, int W, int n_patches, int box, const int64_t *p
                           const float *src, const float *tgt, const float *coef, const float *region_weight,
                           int wrt_src, float *grad, fsgs_stream_t stream);
 
+/* ---- optimiser step and densification statistics -------------------------------------------------- */
+
+/* One parameter group of torch.optim.Adam (no weight decay, no amsgrad): all DEVICE pointers of n
+ * fp32 elements; step = the 1-based step count AFTER this update (torch's state['step']). */
+typedef struct FsgsAdamGroup {
+  float *param;
+  const float *grad;
+  float *exp_avg;
+  float *exp_avg_sq;
+  int64_t n;
+  float lr;
+  int32_t step;
+} FsgsAdamGroup;
+
+/* groups: HOST array of <= 8 groups, updated by ONE kernel launch (train.py:194,272). */
+int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, float beta1, float beta2, float eps,
+                   fsgs_stream_t stream);
+
+/* For every Gaussian with radii > 0: max_radii2D = max(., radii); xyz_gradient_accum += ||viewspace_grad||;
+ * denom += 1   (scene/gaussian_model.py:678-681, train.py:298-303).  viewspace_grad [P,3]. */
+int fsgs_densify_stats(int P, const int32_t *radii, const float *viewspace_grad, float *max_radii2D,
+                       float *xyz_gradient_accum, float *denom, fsgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
