@@ -1,0 +1,75 @@
+"""World-size-2 gloo test (CPU) of the frame-sharded data-parallel plumbing (fsgs_amd/dist.py,
+SURVEY.md s8e): one all-reduce over the flat gradient bucket, identical parameters after the step,
+densification statistics reduced as (SUM, SUM, MAX)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fsgs_amd.model import PARAM_NAMES, GaussianCloud
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _params(P, seed):
+    rng = np.random.default_rng(seed)
+    return {"_xyz": rng.standard_normal((P, 3)), "_features_dc": rng.standard_normal((P, 1, 3)),
+            "_features_rest": rng.standard_normal((P, 15, 3)), "_opacity": rng.standard_normal((P, 1)),
+            "_scaling": rng.standard_normal((P, 3)), "_rotation": rng.standard_normal((P, 4))}
+
+
+def _worker(rank, world, port, use_bucket, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fsgs_amd import dist as fdist
+
+    r, w, _ = fdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    P = 257
+    pc = GaussianCloud(_params(P, 0), device="cpu")  # identical replicas
+    pc.training_setup(fused=False)  # torch Adam on CPU: only the collective plumbing is under test here
+    bucket = fdist.GradBucket(pc) if use_bucket else None
+    for step in range(3):
+        if bucket is not None:
+            bucket.attach(pc)
+        # each rank "renders its own camera": a rank-dependent loss over the shared cloud
+        loss = sum(((pc.params[k] * (rank + 1 + step)) ** 2).sum() * (0.1 + i) for i, k in enumerate(PARAM_NAMES))
+        loss.backward()
+        fdist.sync_gradients(pc, bucket)
+        # the all-reduced gradient equals the sum of both ranks' gradients
+        expect = sum(2 * (q + 1 + step) ** 2 for q in range(world))
+        g = pc.params["_xyz"].grad
+        assert torch.allclose(g, pc.params["_xyz"].detach() * expect * 0.1, rtol=1e-5, atol=1e-6)
+        pc.optimizer.step()
+        if bucket is None:
+            pc.optimizer.zero_grad(set_to_none=True)
+    pc.variables["xyz_gradient_accum"] += rank + 1.0
+    pc.variables["denom"] += 1.0
+    pc.variables["max_radii2D"] += float(rank)
+    fdist.sync_densification_stats(pc)
+    assert torch.all(pc.variables["xyz_gradient_accum"] == 3.0)
+    assert torch.all(pc.variables["denom"] == 2.0)
+    assert torch.all(pc.variables["max_radii2D"] == 1.0)
+    torch.save({k: pc.params[k].detach() for k in PARAM_NAMES}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_bucket", [True, False])
+def test_two_ranks_stay_in_lockstep(tmp_path, use_bucket):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, use_bucket, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in PARAM_NAMES:
+        assert torch.equal(a[k], b[k]), k  # replicas must be bit-identical after synchronised steps
