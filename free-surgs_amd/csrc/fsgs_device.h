@@ -7,7 +7,8 @@
 
 #define FSGS_TILE 16
 #define FSGS_WAVE 64
-#define FSGS_PX_PER_LANE 4  // one wave owns a 16x16 tile: lane = (x, y0), rows y0, y0+4, y0+8, y0+12
+#define FSGS_PX_PER_LANE 4  // one wave owns a 16x16 tile = four 8x8 quadrants; lane l owns pixel (l&7, l>>3) of each
+#define FSGS_QUAD 8
 
 namespace fsgs {
 
@@ -71,6 +72,42 @@ __device__ __forceinline__ bool splat_alpha(float gx, float gy, float A, float B
   e.G = __expf(power);
   e.alpha = fminf(0.99f, __fmul_rn(o, e.G));
   return e.alpha >= (1.0f / 255.0f);
+}
+
+// ---- exact footprint culling ---------------------------------------------------------------------------
+// A Gaussian contributes to a pixel only if alpha = o*exp(-q) >= 1/255, i.e. q(d) <= tau = ln(255 o)
+// with q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy, d = centre - pixel (splat_alpha above).  A rectangle of
+// pixels can therefore be skipped as a whole when the minimum of q over the (continuous) rectangle is
+// above tau.  Skipping never changes a result -- only pairs that every pixel would have skipped anyway
+// are dropped -- so the test only has to be CONSERVATIVE (margin for the rounding of exp/log).
+// Pixel centres of the rectangle: [x0, x0+w-1] x [y0, y0+h-1].
+__device__ __forceinline__ float footprint_tau(float opacity) {
+  // o <= 1/255 can never reach alpha >= 1/255: negative tau culls the Gaussian everywhere
+  return opacity > (1.0f / 255.0f) ? __logf(255.0f * opacity) * 1.0001f + 1e-3f : -1.0f;
+}
+__device__ __forceinline__ bool rect_touched(float gx, float gy, float A, float B, float Cc, float tau, float x0,
+                                             float y0, float w, float h) {
+  if (tau < 0.f) return false;
+  // d-space box
+  const float dx_lo = gx - (x0 + w - 1.0f), dx_hi = gx - x0;
+  const float dy_lo = gy - (y0 + h - 1.0f), dy_hi = gy - y0;
+  if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;  // centre inside
+  if (!(A > 0.f && Cc > 0.f && A * Cc - B * B > 0.f)) return true;                  // not PD: do not cull
+  // convex quadratic, unconstrained minimum outside the box -> the minimum sits on the boundary
+  const float iA = 1.0f / A, iC = 1.0f / Cc;
+  float best;
+  {
+    float c = dx_lo, dy = fminf(fmaxf(-B * c * iC, dy_lo), dy_hi);
+    best = 0.5f * (A * c * c + Cc * dy * dy) + B * c * dy;
+    c = dx_hi; dy = fminf(fmaxf(-B * c * iC, dy_lo), dy_hi);
+    best = fminf(best, 0.5f * (A * c * c + Cc * dy * dy) + B * c * dy);
+    c = dy_lo;
+    float dx = fminf(fmaxf(-B * c * iA, dx_lo), dx_hi);
+    best = fminf(best, 0.5f * (A * dx * dx + Cc * c * c) + B * dx * c);
+    c = dy_hi; dx = fminf(fmaxf(-B * c * iA, dx_lo), dx_hi);
+    best = fminf(best, 0.5f * (A * dx * dx + Cc * c * c) + B * dx * c);
+  }
+  return best <= tau;
 }
 
 // ---- per-Gaussian geometry --------------------------------------------------------

@@ -82,12 +82,23 @@ __device__ __forceinline__ Projected project_gaussian(const CamParams &cam, floa
   int maxy = min(cam.gy, max(0, (int)((py + r_ + FSGS_TILE - 1) / FSGS_TILE)));
   int area = (maxx - minx) * (maxy - miny);
   if (area <= 0) return o;
-  o.radius = r_;
-  o.ntile = (uint32_t)area;
-  o.rect = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
+  // exact footprint culling: keep only the tiles of the 3-sigma rect that some pixel can actually reach
+  const float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
+  const float tau = footprint_tau(opacity);
+  int touched = 0;
+  for (int ty = miny; ty < maxy; ty++)
+    for (int tx = minx; tx < maxx; tx++)
+      touched += rect_touched(px, py, cA, cB, cC, tau, (float)(tx * FSGS_TILE), (float)(ty * FSGS_TILE),
+                              (float)FSGS_TILE, (float)FSGS_TILE)
+                     ? 1
+                     : 0;
+  o.radius = r_;  // radii / visibility keep UPSTREAM's meaning even when no tile survives
   o.xy = make_float2(px, py);
-  o.conic_op = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacity);
+  o.conic_op = make_float4(cA, cB, cC, opacity);
   o.tz = t.z;
+  if (touched == 0) return o;
+  o.ntile = (uint32_t)touched;
+  o.rect = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
   o.key = __float_as_uint(t.z);  // positive float: the bit pattern is order preserving
   return o;
 }
@@ -137,7 +148,10 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, int gx, const ui
                                                          const uint32_t *__restrict__ incl,
                                                          const uint32_t *__restrict__ tiles,
                                                          const ushort4 *__restrict__ rect,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                         const float2 *__restrict__ xy,
+                                                         const float4 *__restrict__ conic_op,
+                                                         uint32_t sentinel_tile, uint32_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   uint32_t g = order[i];
@@ -145,20 +159,35 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int P, int gx, const ui
   if (n == 0) return;
   uint32_t off = incl[i] - n;
   ushort4 rc = rect[g];
+  const float2 p = xy[g];
+  const float4 co = conic_op[g];
+  const float tau = footprint_tau(co.w);
+  const uint32_t end = off + n;
   for (int y = rc.y; y < rc.w; y++)
     for (int x = rc.x; x < rc.z; x++) {
-      keys[off] = (uint32_t)(y * gx + x);
-      vals[off] = g;
-      off++;
+      // the same (deterministic) test as the count in project_gaussian
+      if (off < end && rect_touched(p.x, p.y, co.x, co.y, co.z, tau, (float)(x * FSGS_TILE), (float)(y * FSGS_TILE),
+                                    (float)FSGS_TILE, (float)FSGS_TILE)) {
+        keys[off] = (uint32_t)(y * gx + x);
+        vals[off] = g;
+        off++;
+      }
     }
+  // belt and braces: should count and emission ever disagree, park the unused slots behind the last tile
+  for (; off < end; off++) {
+    keys[off] = sentinel_tile;
+    vals[off] = g;
+  }
 }
 
 // R5  [start,end) of every tile's run in the sorted pair list
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, uint32_t ntiles,
+                                                          const uint32_t *__restrict__ keys,
                                                           int2 *__restrict__ ranges) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= R) return;
   uint32_t t = keys[k];
+  if (t >= ntiles) return;  // sentinel slots
   if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
   if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
 }
@@ -166,6 +195,36 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 // ------------------------------------------------------------------------------------------------
 // R6  forward blend: one wave per 16x16 tile, 4 pixels per lane
 // ------------------------------------------------------------------------------------------------
+// Pixel ownership inside a 16x16 tile: four 8x8 quadrants, lane l owns pixel (l & 7, l >> 3) of each
+// quadrant k = 0..3 at offset (8*(k&1), 8*(k>>1)).  Whether a Gaussian can reach a quadrant at all is a
+// wave-uniform question answered once per pair by its owning lane (rect_touched, exact), carried as a
+// 4-bit mask and tested on the scalar unit -- on the C2 scene only ~2.2 of 4 quadrants survive.
+struct TilePix {
+  int x[4], y[4];
+};
+__device__ __forceinline__ TilePix tile_pixels(int tile, int gx, int lane) {
+  TilePix t;
+  const int x0 = (tile % gx) * FSGS_TILE + (lane & 7), y0 = (tile / gx) * FSGS_TILE + (lane >> 3);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    t.x[k] = x0 + FSGS_QUAD * (k & 1);
+    t.y[k] = y0 + FSGS_QUAD * (k >> 1);
+  }
+  return t;
+}
+__device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, float4 gco) {
+  const float tau = footprint_tau(gco.w);
+  const float x0 = (float)((tile % gx) * FSGS_TILE), y0 = (float)((tile / gx) * FSGS_TILE);
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    m |= rect_touched(gxy.x, gxy.y, gco.x, gco.y, gco.z, tau, x0 + FSGS_QUAD * (k & 1), y0 + FSGS_QUAD * (k >> 1),
+                      (float)FSGS_QUAD, (float)FSGS_QUAD)
+             ? (1u << k)
+             : 0u;
+  return m;
+}
+
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
 template <int C, bool WITH_DEPTH>
@@ -179,17 +238,16 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
   const int tile = vb * 4 + (threadIdx.x >> 6);
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
-  const int px_i = (tile % cam.gx) * FSGS_TILE + (lane & 15);
-  const int py_i = (tile / cam.gx) * FSGS_TILE + (lane >> 4);
-  const float px = (float)px_i;
-  float py[4];
+  const TilePix tp = tile_pixels(tile, cam.gx, lane);
+  float px[4], py[4];
   bool done[4];
   float T[4], D[4], acc[4][C];
   uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    py[k] = (float)(py_i + 4 * k);
-    done[k] = !(px_i < W && (py_i + 4 * k) < H);
+    px[k] = (float)tp.x[k];
+    py[k] = (float)tp.y[k];
+    done[k] = !(tp.x[k] < W && tp.y[k] < H);
     T[k] = 1.0f;
     D[k] = 0.0f;
     last[k] = 0;
@@ -198,8 +256,11 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
   }
   const int2 rg = ranges[tile];
   for (int base = rg.x; base < rg.y; base += 64) {
-    bool all_done = done[0] && done[1] && done[2] && done[3];
-    if (__ballot(!all_done) == 0ull) break;
+    // quadrants whose 64 pixels are all finished (or outside the image) need no more work
+    uint32_t alive = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) alive |= (__ballot(!done[k]) != 0ull) ? (1u << k) : 0u;
+    if (alive == 0) break;
     const int n = min(64, rg.y - base);
     // lane j gathers record j of this batch
     uint32_t g = plist[base + (lane < n ? lane : 0)];
@@ -209,7 +270,10 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
     float gcol[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)g * C + ch];
+    const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     for (int j = 0; j < n; j++) {
+      const uint32_t bm = readlane(gmask, j) & alive;  // scalar
+      if (bm == 0) continue;
       const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
       const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
       const float bo = readlane(gco.w, j), bz = WITH_DEPTH ? readlane(gz, j) : 0.f;
@@ -219,9 +283,10 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
+        if (!((bm >> k) & 1u)) continue;  // wave-uniform
         if (done[k]) continue;
         SplatEval e;
-        if (!splat_alpha(bx, by, bA, bB, bC, bo, px, py[k], e)) continue;
+        if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
         float test_T = T[k] * (1.0f - e.alpha);
         if (test_T < 0.0001f) {
           done[k] = true;
@@ -239,9 +304,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(
   const size_t HW = (size_t)H * W;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int y = py_i + 4 * k;
-    if (px_i < W && y < H) {
-      size_t pix = (size_t)y * W + px_i;
+    if (tp.x[k] < W && tp.y[k] < H) {
+      size_t pix = (size_t)tp.y[k] * W + tp.x[k];
       final_T[pix] = T[k];
       n_contrib[pix] = last[k];
 #pragma unroll
@@ -278,21 +342,20 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
   const size_t HW = (size_t)H * W;
-  const int px_i = (tile % cam.gx) * FSGS_TILE + (lane & 15);
-  const int py_i = (tile / cam.gx) * FSGS_TILE + (lane >> 4);
-  const float px = (float)px_i;
-  float py[4], T[4], Tfin[4], bgdot[4], bgdot_rgb[4], aprev[4], g[4][C], acc[4][C], cprev[4][C];
-  int last[4];
+  const TilePix tp = tile_pixels(tile, cam.gx, lane);
+  float px[4], py[4], T[4], Tfin[4], bgdot[4], bgdot_rgb[4], aprev[4], g[4][C], acc[4][C], cprev[4][C];
+  int last[4], qlast[4];
   int mylast = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int y = py_i + 4 * k;
-    py[k] = (float)y;
-    bool inside = px_i < W && y < H;
-    size_t pix = inside ? (size_t)y * W + px_i : 0;
+    px[k] = (float)tp.x[k];
+    py[k] = (float)tp.y[k];
+    bool inside = tp.x[k] < W && tp.y[k] < H;
+    size_t pix = inside ? (size_t)tp.y[k] * W + tp.x[k] : 0;
     Tfin[k] = inside ? final_T[pix] : 0.0f;
     T[k] = Tfin[k];
     last[k] = inside ? (int)n_contrib[pix] : 0;
+    qlast[k] = wave_max(last[k]);  // deepest contributor of quadrant k (scalar)
     mylast = max(mylast, last[k]);
     aprev[k] = 0.0f;
     bgdot[k] = 0.0f;
@@ -309,7 +372,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     }
   }
   const int2 rg = ranges[tile];
-  int hi = wave_max(mylast);  // nothing behind the deepest contributor matters to anyone in the tile
+  int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -319,6 +382,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     float gcol[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
+    const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     // lane j will hold the tile's total for Gaussian j
     float o_mx = 0.f, o_my = 0.f, o_A = 0.f, o_B = 0.f, o_C = 0.f, o_op = 0.f, o_mxr = 0.f, o_myr = 0.f;
     float o_col[C];
@@ -326,6 +390,11 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     for (int ch = 0; ch < C; ch++) o_col[ch] = 0.f;
     for (int j = n - 1; j >= 0; j--) {
       const int pos = lo + j;  // 0-based index in the tile list
+      uint32_t bm = readlane(gmask, j);  // scalar: quadrants this Gaussian can reach ...
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
+      if (bm == 0) continue;
       const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
       const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
       const float bo = readlane(gco.w, j);
@@ -339,9 +408,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
+        if (!((bm >> k) & 1u)) continue;  // wave-uniform
         if (pos >= last[k]) continue;
         SplatEval e;
-        if (!splat_alpha(bx, by, bA, bB, bC, bo, px, py[k], e)) continue;
+        if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
         any = true;
         float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
         T[k] = T[k] * inv1ma;
@@ -685,17 +755,18 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
     {
       ProfScope ps(PROF_EMIT, stream);
       hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.idx_b, B.incl,
-                         B.tiles, B.rect, B.pk_a, B.pv_a);
+                         B.tiles, B.rect, B.xy, B.co, (uint32_t)ntiles, B.pk_a, B.pv_a);
     }
     FSGS_HIP(hipGetLastError());
     {
       ProfScope ps(PROF_SORT_TILE, stream);
       FSGS_HIP(rocprim::radix_sort_pairs(B.temp, B.temp_bytes, B.pk_a, B.pk_b, B.pv_a, B.plist, (size_t)R, 0,
-                                         tile_bits(ntiles), stream));
+                                         tile_bits(ntiles + 1), stream));
     }
     {
       ProfScope ps(PROF_RANGES, stream);
-      hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, B.pk_b, B.ranges);
+      hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, (uint32_t)ntiles, B.pk_b,
+                         B.ranges);
     }
     FSGS_HIP(hipGetLastError());
   }

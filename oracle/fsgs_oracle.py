@@ -210,6 +210,11 @@ class OracleState:
     def n_contrib(self):
         return self._arr("oracle_state_n_contrib", (self.cfg.image_height, self.cfg.image_width), np.int32)
 
+    def ranges(self):
+        gx = (self.cfg.image_width + 15) // 16
+        gy = (self.cfg.image_height + 15) // 16
+        return self._arr("oracle_state_ranges", (gx * gy, 2), np.int32)
+
     def point_list(self):
         return self._arr("oracle_state_point_list", (self.num_rendered,), np.uint32)
 

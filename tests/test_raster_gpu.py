@@ -162,3 +162,43 @@ def test_full_size_properties_c2():
                     rotations=r_t)
     assert float((i3 - (0.25 * i1 + 0.75 * i2)).abs().max()) < 2e-5
     assert int((radii > 0).sum()) > P // 2
+
+
+def test_binning_is_upstream_order_minus_unreachable_pairs(oracle32):
+    """The HIP binning keeps UPSTREAM's (tile, depth, index) order and drops only (tile, Gaussian) pairs
+    that no pixel of the tile can reach (alpha < 1/255 everywhere): per tile the HIP list must be a
+    subsequence of the oracle's rect-based list, and every dropped pair must be unreachable."""
+    from fsgs_amd import rasterizer
+    from fsgs_amd.trainer import settings_from_cam
+
+    W, H, P = 320, 256, 6000
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=3, base_ratio=0.02)
+    s, r, o = synth.activate(sc)
+    col = np.random.default_rng(0).uniform(0, 1, (P, 3)).astype(np.float32)
+    T = lambda a: torch.tensor(a, device=DEV)
+    cfg = rasterizer.make_cfg(settings_from_cam(cam, DEV), 3)
+    img, depth, radii, st = rasterizer.raster_forward(cfg, T(sc["_xyz"]), T(col), T(o.reshape(-1)), T(s), T(r))
+    v = {k: t.cpu().numpy() for k, t in rasterizer.state_views(st).items()}
+    oi, od, orad, ost = oracle32.raster_forward(cam, sc["_xyz"], col, o.reshape(-1), s, r)
+    assert st.num_rendered < ost.num_rendered  # something was culled
+    o_ranges, o_list = ost.ranges(), ost.point_list().astype(np.int64)
+    xy, co = ost.xy().astype(np.float64), ost.conic_opacity().astype(np.float64)
+    gx = (W + 15) // 16
+    dropped_total = 0
+    yy, xx = np.mgrid[0:16, 0:16]
+    for tile in range(o_ranges.shape[0]):
+        mine = v["point_list"][v["ranges"][tile, 0]:v["ranges"][tile, 1]].astype(np.int64)
+        ref = o_list[o_ranges[tile, 0]:o_ranges[tile, 1]]
+        # subsequence check (order preserved)
+        it = iter(ref.tolist())
+        assert all(any(g == h for h in it) for g in mine.tolist()), "tile %d: not a subsequence" % tile
+        dropped = np.setdiff1d(ref, mine)
+        dropped_total += len(dropped)
+        for g in dropped[:8]:
+            dx = xy[g, 0] - ((tile % gx) * 16 + xx)
+            dy = xy[g, 1] - ((tile // gx) * 16 + yy)
+            power = -0.5 * (co[g, 0] * dx * dx + co[g, 2] * dy * dy) - co[g, 1] * dx * dy
+            alpha = np.where(power > 0, 0.0, co[g, 3] * np.exp(np.minimum(power, 0)))
+            assert alpha.max() < 1.0 / 255.0, "tile %d: reachable pair %d was culled" % (tile, g)
+    assert dropped_total == ost.num_rendered - st.num_rendered
