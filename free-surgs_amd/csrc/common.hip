@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 
+#include "fsgs_device.h"
 #include "fsgs_host.h"
 
 namespace fsgs {
@@ -70,7 +71,23 @@ static void prof_drain() {
 }
 }  // namespace fsgs
 
+namespace {
+__global__ void selftest_transpose_reduce_kernel(const float *in, float *out) {
+  const int lane = threadIdx.x & 63;
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) v[i] = in[lane * 64 + i];
+  out[lane] = fsgs::wave_transpose_reduce64(v, lane);
+}
+}  // namespace
+
 extern "C" {
+int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stream_t stream) {
+  if (!in64x64 || !out64) return FSGS_ERR_INVALID;
+  hipLaunchKernelGGL(selftest_transpose_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
 int fsgs_profile_enable(uint64_t mask) {
   std::lock_guard<std::mutex> lk(fsgs::g_prof_mu);
   fsgs::prof_drain();

@@ -39,6 +39,43 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return readlane(wave_sum_lane63(v), 63); }
 
+// ---- transposing wave reduction ----------------------------------------------------------------------------
+// in: every lane holds 64 partial values v[0..63].  out: lane l holds sum over all 64 lanes of v[l].
+// Six halving steps (lane bit k <-> value-index bit k): at each step a lane keeps the half of the values
+// whose index bit equals its own lane bit and receives the partner lane's partials for that half.
+//   bit 5: v_permlane32_swap, bit 4: v_permlane16_swap (one swap + one add fold TWO values),
+//   bit 3: DPP row_ror:8, bit 2: DPP row_half_mirror (partner l^7: still a bit-2 flip), bits 1,0: quad_perm.
+// 141 VALU instructions for 64 values (2.2 per value) against 8 per value for 64 separate DPP reductions.
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float fold_dpp(float x, float y, bool upper) {
+  float keep = upper ? y : x, send = upper ? x : y;
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true);
+  return keep + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_transpose_reduce64(const float (&v)[64], int lane) {
+  float w[32], x[16], y[8], z[4], u[2];
+#pragma unroll
+  for (int i = 0; i < 32; i++) w[i] = swap32_add(v[i], v[i + 32]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) x[i] = swap16_add(w[i], w[i + 16]);
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 8], b3);  // row_ror:8
+#pragma unroll
+  for (int i = 0; i < 4; i++) z[i] = fold_dpp<0x141>(y[i], y[i + 4], b2);  // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 2; i++) u[i] = fold_dpp<0x4E>(z[i], z[i + 2], b1);   // quad_perm [2,3,0,1]
+  return fold_dpp<0xB1>(u[0], u[1], b0);                                  // quad_perm [1,0,3,2]
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_max_i(int v) {
   int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);

@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
+  // gradient component slots of one Gaussian (16 per Gaussian, 4 Gaussians per transposing reduction):
+  //   0,1 mean2D x,y | 2,3,4 conic A,B,C | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
+  const int my_u = lane >> 4, my_c = lane & 15;  // after the reduction lane l owns (Gaussian u, component c)
+  const bool c_used = my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C);
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -383,106 +387,84 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
-    // lane j will hold the tile's total for Gaussian j
-    float o_mx = 0.f, o_my = 0.f, o_A = 0.f, o_B = 0.f, o_C = 0.f, o_op = 0.f, o_mxr = 0.f, o_myr = 0.f;
-    float o_col[C];
+    for (int jj = n - 1; jj >= 0; jj -= 4) {
+      float v[64];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) o_col[ch] = 0.f;
-    for (int j = n - 1; j >= 0; j--) {
-      const int pos = lo + j;  // 0-based index in the tile list
-      uint32_t bm = readlane(gmask, j);  // scalar: quadrants this Gaussian can reach ...
+      for (int i = 0; i < 64; i++) v[i] = 0.f;
+      bool any_group = false;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
-      if (bm == 0) continue;
-      const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
-      const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
-      const float bo = readlane(gco.w, j);
-      float bcol[C];
+      for (int u = 0; u < 4; u++) {
+        const int j = jj - u;
+        if (j < 0) continue;       // wave-uniform
+        const int pos = lo + j;    // 0-based index in the tile list
+        uint32_t bm = readlane(gmask, j);  // scalar: quadrants this Gaussian can reach ...
 #pragma unroll
-      for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
-      float s_mx = 0.f, s_my = 0.f, s_A = 0.f, s_B = 0.f, s_C = 0.f, s_op = 0.f, s_mxr = 0.f, s_myr = 0.f;
-      float s_col[C];
+        for (int k = 0; k < 4; k++)
+          if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
+        if (bm == 0) continue;
+        const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
+        const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
+        const float bo = readlane(gco.w, j);
+        float bcol[C];
 #pragma unroll
-      for (int ch = 0; ch < C; ch++) s_col[ch] = 0.f;
-      bool any = false;
+        for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
+        float *s = &v[16 * u];
+        bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (!((bm >> k) & 1u)) continue;  // wave-uniform
-        if (pos >= last[k]) continue;
-        SplatEval e;
-        if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
-        any = true;
-        float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
-        T[k] = T[k] * inv1ma;
-        float wgt = e.alpha * T[k];
-        float dL_dalpha = 0.0f, dL_dalpha_rgb = 0.0f;
+        for (int k = 0; k < 4; k++) {
+          if (!((bm >> k) & 1u)) continue;  // wave-uniform
+          if (pos >= last[k]) continue;
+          SplatEval e;
+          if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
+          any = true;
+          float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
+          T[k] = T[k] * inv1ma;
+          float wgt = e.alpha * T[k];
+          float dL_dalpha = 0.0f, dL_dalpha_rgb = 0.0f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-          acc[k][ch] = fmaf(aprev[k], cprev[k][ch], (1.0f - aprev[k]) * acc[k][ch]);
-          cprev[k][ch] = bcol[ch];
-          dL_dalpha = fmaf(bcol[ch] - acc[k][ch], g[k][ch], dL_dalpha);
-          if (SPLIT && ch == 2) dL_dalpha_rgb = dL_dalpha;
-          s_col[ch] = fmaf(wgt, g[k][ch], s_col[ch]);
+          for (int ch = 0; ch < C; ch++) {
+            acc[k][ch] = fmaf(aprev[k], cprev[k][ch], (1.0f - aprev[k]) * acc[k][ch]);
+            cprev[k][ch] = bcol[ch];
+            dL_dalpha = fmaf(bcol[ch] - acc[k][ch], g[k][ch], dL_dalpha);
+            if (SPLIT && ch == 2) dL_dalpha_rgb = dL_dalpha;
+            s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
+          }
+          dL_dalpha *= T[k];
+          aprev[k] = e.alpha;
+          const float bgw = -Tfin[k] * inv1ma;
+          dL_dalpha = fmaf(bgw, bgdot[k], dL_dalpha);
+          float dL_dG = bo * dL_dalpha;
+          float gdx = e.G * e.dx, gdy = e.G * e.dy;
+          float dG_ddx = -gdx * bA - gdy * bB;
+          float dG_ddy = -gdy * bC - gdx * bB;
+          s[0] = fmaf(dL_dG, dG_ddx, s[0]);
+          s[1] = fmaf(dL_dG, dG_ddy, s[1]);
+          if (SPLIT) {
+            float dG_rgb = bo * fmaf(bgw, bgdot_rgb[k], dL_dalpha_rgb * T[k]);
+            s[6] = fmaf(dG_rgb, dG_ddx, s[6]);
+            s[7] = fmaf(dG_rgb, dG_ddy, s[7]);
+          }
+          s[2] = fmaf(-0.5f * gdx * e.dx, dL_dG, s[2]);
+          s[3] = fmaf(-gdx * e.dy, dL_dG, s[3]);
+          s[4] = fmaf(-0.5f * gdy * e.dy, dL_dG, s[4]);
+          s[5] = fmaf(e.G, dL_dalpha, s[5]);
         }
-        dL_dalpha *= T[k];
-        aprev[k] = e.alpha;
-        const float bgw = -Tfin[k] * inv1ma;
-        dL_dalpha = fmaf(bgw, bgdot[k], dL_dalpha);
-        float dL_dG = bo * dL_dalpha;
-        float gdx = e.G * e.dx, gdy = e.G * e.dy;
-        float dG_ddx = -gdx * bA - gdy * bB;
-        float dG_ddy = -gdy * bC - gdx * bB;
-        s_mx = fmaf(dL_dG, dG_ddx, s_mx);
-        s_my = fmaf(dL_dG, dG_ddy, s_my);
-        if (SPLIT) {
-          float dG_rgb = bo * fmaf(bgw, bgdot_rgb[k], dL_dalpha_rgb * T[k]);
-          s_mxr = fmaf(dG_rgb, dG_ddx, s_mxr);
-          s_myr = fmaf(dG_rgb, dG_ddy, s_myr);
-        }
-        s_A = fmaf(-0.5f * gdx * e.dx, dL_dG, s_A);
-        s_B = fmaf(-gdx * e.dy, dL_dG, s_B);
-        s_C = fmaf(-0.5f * gdy * e.dy, dL_dG, s_C);
-        s_op = fmaf(e.G, dL_dalpha, s_op);
+        any_group = any_group || (__ballot(any) != 0ull);
       }
-      if (__ballot(any) == 0ull) continue;  // wave-uniform: nobody in the tile is touched
-      // NB: the reductions must run with the whole wave active -- evaluate them BEFORE the select
-      // (a C++ `mine ? wave_sum(x) : o` would execute the DPP ops in lane j only).
-      const float t_mx = wave_sum(s_mx), t_my = wave_sum(s_my), t_A = wave_sum(s_A), t_B = wave_sum(s_B);
-      const float t_C = wave_sum(s_C), t_op = wave_sum(s_op);
-      const float t_mxr = SPLIT ? wave_sum(s_mxr) : 0.f, t_myr = SPLIT ? wave_sum(s_myr) : 0.f;
-      float t_col[C];
+      if (!any_group) continue;  // wave-uniform: none of the four touched any pixel of the tile
+      // 64 x 64 transposing reduction: lane (u, c) receives the tile total of component c of Gaussian jj-u
+      const float tot = wave_transpose_reduce64(v, lane);
+      const int j_mine = jj - my_u;
+      uint32_t gsel = readlane(gid, jj);
 #pragma unroll
-      for (int ch = 0; ch < C; ch++) t_col[ch] = wave_sum(s_col[ch]);
-      const bool mine = lane == j;  // lane j keeps the tile total of Gaussian j
-      o_mx = mine ? t_mx : o_mx;
-      o_my = mine ? t_my : o_my;
-      o_A = mine ? t_A : o_A;
-      o_B = mine ? t_B : o_B;
-      o_C = mine ? t_C : o_C;
-      o_op = mine ? t_op : o_op;
-      if (SPLIT) {
-        o_mxr = mine ? t_mxr : o_mxr;
-        o_myr = mine ? t_myr : o_myr;
+      for (int u = 1; u < 4; u++) {
+        uint32_t gu = readlane(gid, max(jj - u, 0));
+        gsel = (my_u == u) ? gu : gsel;
       }
-#pragma unroll
-      for (int ch = 0; ch < C; ch++) o_col[ch] = mine ? t_col[ch] : o_col[ch];
-    }
-    if (lane < n) {
-      float *ga = grad_acc + (size_t)gid * kAccStride;
-      if (o_mx != 0.f) atomicAdd(ga + 0, o_mx);
-      if (o_my != 0.f) atomicAdd(ga + 1, o_my);
-      if (o_A != 0.f) atomicAdd(ga + 2, o_A);
-      if (o_B != 0.f) atomicAdd(ga + 3, o_B);
-      if (o_C != 0.f) atomicAdd(ga + 4, o_C);
-      if (o_op != 0.f) atomicAdd(ga + 5, o_op);
-      if (SPLIT) {
-        if (o_mxr != 0.f) atomicAdd(ga + 6, o_mxr);
-        if (o_myr != 0.f) atomicAdd(ga + 7, o_myr);
+      if (j_mine >= 0 && c_used && tot != 0.f) {
+        float *dst = my_c < 8 ? grad_acc + (size_t)gsel * kAccStride + my_c : dcolors + (size_t)gsel * C + (my_c - 8);
+        atomicAdd(dst, tot);
       }
-#pragma unroll
-      for (int ch = 0; ch < C; ch++)
-        if (o_col[ch] != 0.f) atomicAdd(dcolors + (size_t)gid * C + ch, o_col[ch]);
     }
     hi = lo;
   }

@@ -97,11 +97,48 @@ __device__ __forceinline__ Activated activate(const RenderDev &a, int i) {
   return o;
 }
 
+// The SH block [P, K-1, 3] is 180 B per Gaussian at degree 3; a thread-per-Gaussian access pattern would touch
+// 64 x 180 B per load instruction.  Each workgroup therefore copies its 256 Gaussians' coefficients
+// (one contiguous 46 KB run) through LDS with coalesced accesses; the per-thread stride of 45 floats
+// is odd, so the LDS side is bank-conflict free.
+constexpr int SH_REST_MAX = 45;  // (16 - 1) * 3
+__device__ __forceinline__ void stage_in(float *lds, const float *src, size_t first, size_t count) {
+  // count floats starting at src[first]; first*4 is 16-byte aligned for 256-Gaussian blocks when the row
+  // length is a multiple of 4 bytes x 4 -- fall back to scalar copies otherwise
+  if (((first & 3) == 0) && ((((uintptr_t)src) & 15) == 0)) {
+    const float4 *s4 = (const float4 *)(src + first);
+    size_t n4 = count >> 2;
+    for (size_t i = threadIdx.x; i < n4; i += 256) ((float4 *)lds)[i] = s4[i];
+    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) lds[i] = src[first + i];
+  } else {
+    for (size_t i = threadIdx.x; i < count; i += 256) lds[i] = src[first + i];
+  }
+}
+__device__ __forceinline__ void stage_out(float *dst, const float *lds, size_t first, size_t count) {
+  if (((first & 3) == 0) && ((((uintptr_t)dst) & 15) == 0)) {
+    float4 *d4 = (float4 *)(dst + first);
+    size_t n4 = count >> 2;
+    for (size_t i = threadIdx.x; i < n4; i += 256) d4[i] = ((const float4 *)lds)[i];
+    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) dst[first + i] = lds[i];
+  } else {
+    for (size_t i = threadIdx.x; i < count; i += 256) dst[first + i] = lds[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
                                                              float *__restrict__ colors6,
                                                              uint32_t *__restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];
+  const int b0 = blockIdx.x * blockDim.x;
+  int i = b0 + threadIdx.x;
+  const int row = (a.K - 1) * 3;  // floats of f_rest per Gaussian
+  if (a.deg > 0) {
+    size_t cnt = (size_t)min(256, P - b0) * row;
+    stage_in(s_rest, a.f_rest, (size_t)b0 * row, cnt);
+    __syncthreads();
+  }
   if (i >= P) return;
+  const float *my_rest = s_rest + (size_t)threadIdx.x * row;
   Activated act = activate(a, i);
   // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
   float dx = a.xyz[3 * i] - a.cam_center[0], dy = a.xyz[3 * i + 1] - a.cam_center[1],
@@ -116,7 +153,7 @@ __global__ __launch_bounds__(256) void render_pre_fwd_kernel(int P, CamParams ca
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     float v = b[0] * a.f_dc[3 * i + c];
-    for (int k = 1; k < nk; k++) v = fmaf(b[k], a.f_rest[((size_t)i * (a.K - 1) + (k - 1)) * 3 + c], v);
+    for (int k = 1; k < nk; k++) v = fmaf(b[k], my_rest[(k - 1) * 3 + c], v);
     v += 0.5f;
     if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
     rgb[c] = v;
@@ -149,7 +186,17 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
                                                              const uint32_t *__restrict__ flags, int mode,
                                                              RenderGradsDev out) {
   __shared__ float red[12][4];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];  // coefficients in, their gradients out
+  const int b0 = blockIdx.x * blockDim.x;
+  int i = b0 + threadIdx.x;
+  const int row = (a.K - 1) * 3;
+  const bool stage = (mode & MODE_PARAM_GRAD) && row > 0;
+  const size_t stage_cnt = (size_t)min(256, P - b0) * row;
+  if (stage) {
+    if (a.deg > 0) stage_in(s_rest, a.f_rest, (size_t)b0 * row, stage_cnt);
+    __syncthreads();
+  }
+  float *my_rest = s_rest + (size_t)threadIdx.x * row;
   float gxc[3] = {0.f, 0.f, 0.f};  // dL/dx_cam
   float xw[3] = {0.f, 0.f, 0.f};
   float dxyz[3] = {0.f, 0.f, 0.f};
@@ -204,15 +251,15 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
         float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
         out.f_dc[3 * i + c] = b[0] * gcol;
         for (int k = 1; k < a.K; k++) {
-          size_t at = ((size_t)i * (a.K - 1) + (k - 1)) * 3 + c;
+          const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
           if (k < nk) {
-            float coef = a.f_rest[at];
-            out.f_rest[at] = b[k] * gcol;
+            float coef = my_rest[at];
+            my_rest[at] = b[k] * gcol;
             ddx = fmaf(gcol * coef, bx[k], ddx);
             ddy = fmaf(gcol * coef, by[k], ddy);
             ddz = fmaf(gcol * coef, bz[k], ddz);
           } else {
-            out.f_rest[at] = 0.f;
+            my_rest[at] = 0.f;
           }
         }
       }
@@ -228,7 +275,11 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
     out.opacity[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) out.f_dc[3 * i + c] = 0.f;
-    for (int k = 0; k < (a.K - 1) * 3; k++) out.f_rest[(size_t)i * (a.K - 1) * 3 + k] = 0.f;
+    for (int k = 0; k < row; k++) my_rest[k] = 0.f;
+  }
+  if (stage) {  // coalesced store of the workgroup's SH-rest gradients
+    __syncthreads();
+    stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
   }
   if (i < P) {
     out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f;

@@ -202,3 +202,19 @@ def test_binning_is_upstream_order_minus_unreachable_pairs(oracle32):
             alpha = np.where(power > 0, 0.0, co[g, 3] * np.exp(np.minimum(power, 0)))
             assert alpha.max() < 1.0 / 255.0, "tile %d: reachable pair %d was culled" % (tile, g)
     assert dropped_total == ost.num_rendered - st.num_rendered
+
+
+def test_wave_transposing_reduction_selftest():
+    """the permlane-swap / DPP transposing reduction of blend_bwd, isolated: out[l] = sum_lanes in[lane][l]."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    m = rng.standard_normal((64, 64)).astype(np.float32)
+    m[:, 5] = np.arange(64)  # asymmetric columns catch lane/value mix-ups
+    a = torch.tensor(m, device=DEV)
+    out = torch.zeros(64, device=DEV)
+    _lib.check(lib.fsgs_selftest_transpose_reduce(_lib.ptr(a), _lib.ptr(out), _lib.current_stream()), "selftest")
+    np.testing.assert_allclose(out.cpu().numpy(), m.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
