@@ -184,6 +184,16 @@ def main():
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": ms_total / launches,
                     "launches": launches, "algorithmic_bytes": b_alg, "num_rendered": R, "channels": C}
+        # HBM bytes per launch measured offline with rocprofv3 --pmc (scripts/gpu_pmc.sh, separate passes,
+        # gfx950 FETCH_SIZE x2 correction calibrated on the Adam kernel) for exactly this workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "blend_bwd_kernel<%d; %s>" % (C, "true" if fused else "false")
+            if pmc.get("config") == args.config and key in pmc["kernels"] and world == 1:
+                roofline["traffic"] = pmc["kernels"][key]["traffic_bytes"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+        except Exception:
+            pass
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
 
     cpu = None
