@@ -1,0 +1,190 @@
+// flow.hip -- optical-flow reprojection loss of the tracking step for gfx950 (MI355X).
+//
+// Reference: projection_flow_loss (scene/pose_optimizer.py:164-218).  Its pose-INDEPENDENT half
+// (back-projection of the previous depth, duplicate/origin rejection, scene/pose_optimizer.py:42-73) is
+// constant over the 50 tracking iterations of a frame and is prepared once per frame on the host side
+// (fsgs_amd/flow.py: FlowTargets).  These kernels are the per-iteration half: transform the M world
+// points by the current pose, project with K, keep the border-safe points in front of the camera, L1
+// against the forward flow -- one streaming pass forward, one backward that reduces dL/dw2c (12 floats)
+// with DPP wave sums and one atomic per workgroup.  28 B/point read, HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsgs.h"
+#include "fsgs_device.h"
+#include "fsgs_host.h"
+
+using namespace fsgs;
+
+namespace {
+
+struct FlowCam {
+  float K[9];
+  int W, H;
+  float edge;
+};
+
+struct FlowPoint {
+  bool valid;
+  float eu, ev;        // residuals (projection flow - gt flow)
+  float cx, cy, cz;    // camera-frame point
+  float pz, u, v;      // K-projected depth (+1e-5) and pixel
+};
+
+__device__ __forceinline__ FlowPoint flow_point(const FlowCam &c, const float *__restrict__ w,
+                                                const float *__restrict__ pts, const int64_t *__restrict__ pix_vu,
+                                                const float *__restrict__ flow, size_t i) {
+  FlowPoint o;
+  float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  o.cx = w[0] * x + w[1] * y + w[2] * z + w[3];
+  o.cy = w[4] * x + w[5] * y + w[6] * z + w[7];
+  o.cz = w[8] * x + w[9] * y + w[10] * z + w[11];
+  float p0 = c.K[0] * o.cx + c.K[1] * o.cy + c.K[2] * o.cz;
+  float p1 = c.K[3] * o.cx + c.K[4] * o.cy + c.K[5] * o.cz;
+  float p2 = c.K[6] * o.cx + c.K[7] * o.cy + c.K[8] * o.cz;
+  o.pz = p2 + 1e-5f;
+  o.u = p0 / o.pz;
+  o.v = p1 / o.pz;
+  o.valid = (o.u < (float)c.W - c.edge) && (o.u > c.edge) && (o.v < (float)c.H - c.edge) && (o.v > c.edge) &&
+            (o.pz > 0.f);
+  int64_t sv = pix_vu[2 * i], su = pix_vu[2 * i + 1];
+  size_t at = (size_t)sv * c.W + (size_t)su;
+  size_t plane = (size_t)c.H * c.W;
+  o.eu = (o.u - (float)su) - flow[at];
+  o.ev = (o.v - (float)sv) - flow[plane + at];
+  return o;
+}
+
+// acc[0] += sum(|eu| + |ev|) over valid points, acc[1] += #valid, acc[2] += #NaN   (doubles)
+__global__ __launch_bounds__(256) void flow_fwd_kernel(size_t M, FlowCam c, const float *__restrict__ w2c,
+                                                       const float *__restrict__ pts,
+                                                       const int64_t *__restrict__ pix_vu,
+                                                       const float *__restrict__ flow, double *__restrict__ acc) {
+  __shared__ float red[3][4];
+  float s = 0.f, n = 0.f, bad = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (size_t)gridDim.x * 256) {
+    FlowPoint p = flow_point(c, w2c, pts, pix_vu, flow, i);
+    if (p.valid) {
+      float e = fabsf(p.eu) + fabsf(p.ev);
+      if (e != e) bad += 1.f; else s += e;
+      n += 1.f;
+    }
+  }
+  float ts = wave_sum(s), tn = wave_sum(n), tb = wave_sum(bad);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = ts; red[1][wid] = tn; red[2][wid] = tb; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (t != 0.f) atomicAdd(acc + threadIdx.x, (double)t);
+  }
+}
+
+// loss = sum / (2 * count);  0 when nothing survives or a NaN was seen (scene/pose_optimizer.py:196-214)
+__global__ void flow_finish_kernel(const double *acc, float *out) {
+  double n = acc[1];
+  out[0] = (n > 0 && acc[2] == 0) ? (float)(acc[0] / (2.0 * n)) : 0.f;
+  out[1] = (float)n;
+}
+
+// dL/dw2c[r][c] += upstream/(2 n) * sum_i [sign(eu) du/dcam_r + sign(ev) dv/dcam_r] * [x;1]_c
+__global__ __launch_bounds__(256) void flow_bwd_kernel(size_t M, FlowCam c, const float *__restrict__ w2c,
+                                                       const float *__restrict__ pts,
+                                                       const int64_t *__restrict__ pix_vu,
+                                                       const float *__restrict__ flow,
+                                                       const double *__restrict__ acc,
+                                                       const float *__restrict__ upstream,
+                                                       float *__restrict__ dw2c) {
+  __shared__ float red[12][4];
+  const double n = acc[1];
+  const bool live = n > 0 && acc[2] == 0;
+  const float scale = live ? (upstream ? upstream[0] : 1.f) / (2.f * (float)n) : 0.f;
+  float g[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) g[k] = 0.f;
+  if (live) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (size_t)gridDim.x * 256) {
+      FlowPoint p = flow_point(c, w2c, pts, pix_vu, flow, i);
+      if (!p.valid) continue;
+      float su = p.eu > 0.f ? 1.f : (p.eu < 0.f ? -1.f : 0.f);
+      float sv = p.ev > 0.f ? 1.f : (p.ev < 0.f ? -1.f : 0.f);
+      float ipz = 1.0f / p.pz;
+      // dL/dp (p = K cam): u = p0/pz, v = p1/pz
+      float dp0 = su * ipz, dp1 = sv * ipz, dp2 = -(su * p.u + sv * p.v) * ipz;
+      // dL/dcam = K^T dp
+      float dc0 = c.K[0] * dp0 + c.K[3] * dp1 + c.K[6] * dp2;
+      float dc1 = c.K[1] * dp0 + c.K[4] * dp1 + c.K[7] * dp2;
+      float dc2 = c.K[2] * dp0 + c.K[5] * dp1 + c.K[8] * dp2;
+      float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+      g[0] = fmaf(dc0, x, g[0]); g[1] = fmaf(dc0, y, g[1]); g[2] = fmaf(dc0, z, g[2]); g[3] += dc0;
+      g[4] = fmaf(dc1, x, g[4]); g[5] = fmaf(dc1, y, g[5]); g[6] = fmaf(dc1, z, g[6]); g[7] += dc1;
+      g[8] = fmaf(dc2, x, g[8]); g[9] = fmaf(dc2, y, g[9]); g[10] = fmaf(dc2, z, g[10]); g[11] += dc2;
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    float t = wave_sum(g[k]);
+    if (lane == 0) red[k][wid] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float t = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) * scale;
+    if (t != 0.f) atomicAdd(dw2c + threadIdx.x, t);
+  }
+}
+
+int flow_blocks(size_t M) {
+  size_t b = (M + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b ? b : 1));
+}
+
+FlowCam make_flow_cam(const float *K9, int W, int H, float edge) {
+  FlowCam c;
+  for (int i = 0; i < 9; i++) c.K[i] = K9[i];
+  c.W = W; c.H = H; c.edge = edge;
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsgs_flow_pose_loss_forward(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                                const float *K9_host, const float *flow_fw, int W, int H, float edge, double *acc3,
+                                float *out2, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M < 0 || !w2c || !K9_host || !flow_fw || !acc3 || !out2 || W <= 0 || H <= 0) return FSGS_ERR_INVALID;
+  if (M > 0 && (!pts_world || !pix_vu)) return FSGS_ERR_INVALID;
+  FSGS_HIP(hipMemsetAsync(acc3, 0, 3 * sizeof(double), stream));
+  FlowCam c = make_flow_cam(K9_host, W, H, edge);
+  {
+    ProfScope ps(PROF_FLOW, stream);
+    if (M > 0)
+      hipLaunchKernelGGL(flow_fwd_kernel, dim3(flow_blocks((size_t)M)), dim3(256), 0, stream, (size_t)M, c, w2c,
+                         pts_world, pix_vu, flow_fw, acc3);
+    hipLaunchKernelGGL(flow_finish_kernel, dim3(1), dim3(1), 0, stream, acc3, out2);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_flow_pose_loss_backward(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                                 const float *K9_host, const float *flow_fw, int W, int H, float edge,
+                                 const double *acc3, const float *upstream, float *dw2c, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M < 0 || !w2c || !K9_host || !flow_fw || !acc3 || !dw2c || W <= 0 || H <= 0) return FSGS_ERR_INVALID;
+  FSGS_HIP(hipMemsetAsync(dw2c, 0, 16 * sizeof(float), stream));
+  if (M == 0) return FSGS_OK;
+  if (!pts_world || !pix_vu) return FSGS_ERR_INVALID;
+  FlowCam c = make_flow_cam(K9_host, W, H, edge);
+  {
+    ProfScope ps(PROF_FLOW, stream);
+    hipLaunchKernelGGL(flow_bwd_kernel, dim3(flow_blocks((size_t)M)), dim3(256), 0, stream, (size_t)M, c, w2c,
+                       pts_world, pix_vu, flow_fw, acc3, upstream, dw2c);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+}  // extern "C"

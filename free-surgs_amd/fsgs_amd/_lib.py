@@ -106,6 +106,10 @@ _PROTOTYPES = {
     "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "fsgs_photometric_loss_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "fsgs_pearson_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsgs_flow_pose_loss_forward": (_i, [_i64, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, _vp, _vp,
+                                         _vp]),
+    "fsgs_flow_pose_loss_backward": (_i, [_i64, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, _vp, _vp,
+                                          _vp, _vp]),
     "fsgs_adam_step": (_i, [_i, C.POINTER(FsgsAdamGroup), C.c_float, C.c_float, C.c_float, _vp]),
     "fsgs_densify_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pearson_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -65,3 +65,71 @@ def projection_flow_loss_torch(depth_prev, w2c_prev, w2c_cur, K, flow_fw, rigid_
     H, W = depth_prev.shape[1], depth_prev.shape[2]
     pts, vu = backproject_previous(depth_prev, K, w2c_prev, rigid_mask)
     return flow_pose_loss_torch(pts, vu, w2c_cur, K, flow_fw.float(), W, H)
+
+
+# ---- product path: per-frame cache + HIP kernels (csrc/flow.hip) ------------------------------------------
+class FlowTargets:
+    """The pose-independent half of projection_flow_loss, prepared ONCE per tracked frame (the reference
+    redoes it in each of the 50 iterations, incl. a 1.3M-row unique): world points of the previous frame's
+    valid pixels and their pixel indices, plus the forward flow, all resident on the device."""
+
+    def __init__(self, depth_prev, w2c_prev, K, flow_fw, rigid_mask=None):
+        self.H, self.W = int(depth_prev.shape[1]), int(depth_prev.shape[2])
+        pts, vu = backproject_previous(depth_prev, K, w2c_prev, rigid_mask)
+        self.pts = pts.detach().contiguous().float()
+        self.vu = vu.detach().contiguous().to(torch.int64)
+        self.flow = flow_fw.detach().contiguous().float()
+        Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32).reshape(9)
+        import ctypes as C
+
+        self.K9 = (C.c_float * 9)(*[float(v) for v in Kn])
+
+
+class _FlowPoseLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w2c, targets, edge):
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        if not w2c.is_cuda:
+            raise RuntimeError("fsgs flow loss needs CUDA/HIP tensors; there is no CPU fallback")
+        w = w2c.detach().contiguous().float()
+        acc = torch.empty((3,), dtype=torch.float64, device=w.device)
+        out = torch.empty((2,), dtype=torch.float32, device=w.device)
+        M = int(targets.pts.shape[0])
+        with torch.cuda.device(w.device):
+            rc = lib.fsgs_flow_pose_loss_forward(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(w), targets.K9,
+                                                 _lib.ptr(targets.flow), targets.W, targets.H, float(edge),
+                                                 _lib.ptr(acc), _lib.ptr(out), _lib.current_stream())
+        _lib.check(rc, "fsgs_flow_pose_loss_forward")
+        ctx.save_for_backward(w, acc)
+        ctx.targets, ctx.edge = targets, float(edge)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _lib
+
+        lib = _lib.load()
+        w, acc = ctx.saved_tensors
+        t = ctx.targets
+        up = grad_out.detach().contiguous().float().reshape(1)
+        dw = torch.empty((4, 4), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = lib.fsgs_flow_pose_loss_backward(int(t.pts.shape[0]), _lib.ptr(t.pts), _lib.ptr(t.vu), _lib.ptr(w), t.K9,
+                                                  _lib.ptr(t.flow), t.W, t.H, ctx.edge, _lib.ptr(acc), _lib.ptr(up),
+                                                  _lib.ptr(dw), _lib.current_stream())
+        _lib.check(rc, "fsgs_flow_pose_loss_backward")
+        return dw, None, None
+
+
+def flow_pose_loss(w2c_cur, targets, edge=20):
+    """projection_flow_loss given the cached per-frame targets (scene/pose_optimizer.py:183-216)."""
+    return _FlowPoseLoss.apply(w2c_cur, targets, edge)
+
+
+def projection_flow_loss(depth_prev, w2c_prev, w2c_cur, K, flow_fw, rigid_mask=None):
+    """Same signature role as the reference function (one-shot: builds the targets, then the HIP loss)."""
+    return flow_pose_loss(w2c_cur, FlowTargets(depth_prev, w2c_prev, K, flow_fw, rigid_mask))

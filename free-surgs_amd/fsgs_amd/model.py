@@ -109,3 +109,110 @@ class GaussianCloud:
         self.variables["xyz_gradient_accum"][update_filter] += torch.norm(
             viewspace_grad[update_filter], dim=-1, keepdim=True)
         self.variables["denom"][update_filter] += 1
+
+
+    # ---- densification / pruning / opacity reset (scene/gaussian_model.py:452-456,501-676; Appendix D) ----
+    def _swap_params(self, new_tensors, moment_fn):
+        """Install new leaf tensors for every group and transform the Adam moments with
+        moment_fn(name, old_moment) -> new_moment (the reference's state surgery, :501-580)."""
+        for group in self.optimizer.param_groups:
+            name = group["name"]
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            new = new_tensors[name].detach().contiguous().requires_grad_(True)
+            if state is not None and "exp_avg" in state:
+                state["exp_avg"] = moment_fn(name, state["exp_avg"])
+                state["exp_avg_sq"] = moment_fn(name, state["exp_avg_sq"])
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            self.params[name] = new
+
+    def prune_points(self, mask):
+        keep = ~mask
+        self._swap_params({k: self.params[k].detach()[keep] for k in PARAM_NAMES}, lambda n, m: m[keep])
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            self.variables[k] = self.variables[k][keep]
+
+    def densification_postfix(self, new):
+        dev = self.params["_xyz"].device
+        cat = {k: torch.cat((self.params[k].detach(), new[k]), dim=0) for k in PARAM_NAMES}
+        self._swap_params(cat, lambda n, m: torch.cat((m, torch.zeros_like(new[n])), dim=0))
+        P = self.num_points
+        self.variables["xyz_gradient_accum"] = torch.zeros((P, 1), device=dev)
+        self.variables["denom"] = torch.zeros((P, 1), device=dev)
+        self.variables["max_radii2D"] = torch.zeros((P,), device=dev)
+
+    def densify_and_clone(self, grads, grad_threshold):
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (
+            torch.max(self.get_scaling, dim=1).values <= self.variables["scene_radius"] * 0.01)
+        self.densification_postfix({k: self.params[k].detach()[sel] for k in PARAM_NAMES})
+
+    def densify_and_split(self, grads, grad_threshold, N=2):
+        from .synth import quat_to_rot  # noqa: F401  (same polynomial as build_rotation)
+
+        P0 = self.num_points
+        padded = torch.zeros((P0,), device=self.params["_xyz"].device)
+        padded[: grads.shape[0]] = grads.squeeze()
+        sel = (padded >= grad_threshold) & (
+            torch.max(self.get_scaling, dim=1).values > self.variables["scene_radius"] * 0.01)
+        scale_sel = self.get_scaling.detach()[sel]
+        stds = scale_sel.repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
+        q = self.params["_rotation"].detach()[sel]
+        q = q / torch.sqrt((q * q).sum(dim=1, keepdim=True))
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        R = R.repeat(N, 1, 1)
+        new = {
+            "_xyz": torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self.params["_xyz"].detach()[sel].repeat(N, 1),
+            "_scaling": torch.log(scale_sel.repeat(N, 1) / (0.8 * N)),
+            "_rotation": self.params["_rotation"].detach()[sel].repeat(N, 1),
+            "_features_dc": self.params["_features_dc"].detach()[sel].repeat(N, 1, 1),
+            "_features_rest": self.params["_features_rest"].detach()[sel].repeat(N, 1, 1),
+            "_opacity": self.params["_opacity"].detach()[sel].repeat(N, 1),
+        }
+        self.densification_postfix(new)
+        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=sel.device, dtype=torch.bool)))
+        self.prune_points(prune)
+
+    def densify_and_prune(self, max_grad, min_opacity, max_screen_size):
+        grads = self.variables["xyz_gradient_accum"].reshape(-1, 1) / self.variables["denom"].reshape(-1, 1)
+        self.densify_and_clone(grads, max_grad)
+        self.densify_and_split(grads, max_grad)
+        prune = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            big_vs = self.variables["max_radii2D"] > max_screen_size
+            big_ws = self.get_scaling.max(dim=1).values > 0.1 * self.variables["scene_radius"]
+            prune = prune | big_vs | big_ws
+        self.prune_points(prune)
+
+    def reset_opacity(self):
+        op = self.get_opacity.detach()
+        new = inverse_sigmoid(torch.min(op, torch.ones_like(op) * 0.01))
+        for group in self.optimizer.param_groups:
+            if group["name"] != "_opacity":
+                continue
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            t = new.detach().contiguous().requires_grad_(True)
+            if state is not None and "exp_avg" in state:
+                state["exp_avg"] = torch.zeros_like(new)
+                state["exp_avg_sq"] = torch.zeros_like(new)
+                self.optimizer.state[t] = state
+            group["params"][0] = t
+            self.params["_opacity"] = t
+
+    def initialize_optimizer(self, fused=True):
+        """global_run's fresh Adam with default eps and the mapping learning rates (scene/gaussian_model.py:372-378)."""
+        lr = {"_xyz": self.opt.position_lr_init * self.spatial_lr_scale, "_features_dc": self.opt.feature_lr,
+              "_features_rest": self.opt.feature_lr / 20.0, "_opacity": self.opt.opacity_lr,
+              "_scaling": self.opt.scaling_lr, "_rotation": self.opt.rotation_lr}
+        groups = [{"params": [self.params[k]], "lr": lr[k], "name": k} for k in PARAM_NAMES]
+        if fused:
+            from .optim import FusedAdam
+
+            self.optimizer = FusedAdam(groups)
+        else:
+            self.optimizer = torch.optim.Adam(groups)

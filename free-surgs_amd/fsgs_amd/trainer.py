@@ -77,11 +77,22 @@ class PoseTrack:
 
 
 class FrameData:
-    """Per-frame inputs kept resident in HBM: colour [3,H,W], mono-depth [H,W]."""
+    """Per-frame inputs kept resident in HBM (PoseModel.record_data, scene/pose_optimizer.py:441-460):
+    colours [3,H,W], mono-depth [H,W] (already normalised to [0.5,1.5], :406-407), forward flows
+    flows_fw[i] [2,H,W] (frame i -> i+1), intrinsics K [3,3], predicted depths [H,W] per frame,
+    optional ground-truth w2c poses for evaluation."""
 
-    def __init__(self, colors, monodeps):
+    def __init__(self, colors, monodeps, flows_fw=None, K=None, gt_w2c=None):
         self.colors = colors
         self.monodeps = monodeps
+        self.flows_fw = flows_fw
+        self.K = K
+        self.gt_w2c = gt_w2c
+        self.pred_depths = [None] * len(colors)
+        n = len(colors)
+        idx = np.arange(n)
+        self.i_test = idx[4::8]  # scene/pose_optimizer.py:416-419
+        self.i_train = np.array([i for i in idx if i not in self.i_test])
 
 
 def mapping_loss(pkg, gt_image, mono_dep, corners=None, hip_losses=True):
@@ -120,3 +131,154 @@ def mapping_step(pc, poses, frames, timesteps, fused=True, step_optimizer=True, 
             pc.optimizer.step()
             pc.optimizer.zero_grad(set_to_none=True)
     return loss.detach(), first
+
+
+def tracking_step(pc, poses, frames, t, targets, rigid_mask, fused=True):
+    """One pose-only iteration of FreeSurGS.tracking (train.py:166-200): masked photometric loss +
+    0.1 * flow reprojection loss, backward to the pose, scheduler.step() BEFORE optimizer.step()."""
+    from .flow import flow_pose_loss
+
+    rend = render if fused else render_two_pass
+    pkg = rend(poses, t, pc, gs_grad=False, cam_grad=True)
+    mask = ((pkg["render_dep"] > 0) * rigid_mask).unsqueeze(0)
+    rgb = LOSS_W_TRACKING["rgb"] * losses.rgb_loss_func(pkg["render"], frames.colors[t], mask=mask)
+    flow = LOSS_W_TRACKING["flow"] * flow_pose_loss(pkg["render_w2c"], targets)
+    loss = flow + rgb
+    loss.backward()
+    poses.scheduler.step()
+    with torch.no_grad():
+        poses.optimizer.step()
+        poses.optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), rgb.detach(), flow.detach(), pkg
+
+
+class Runner:
+    """Counterpart of the FreeSurGS driver class (train.py:33-443) for the hot path: progressive_run
+    (track each new frame, map the training frames), global_run (random-frame mapping iterations with
+    densification), validation (PSNR on the test frames) and eval_pose (RPE / ATE)."""
+
+    def __init__(self, pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, fused=True,
+                 seed=0, densify=True, row0_depth_quirk=True):
+        import random
+
+        self.pc, self.poses, self.frames = pc, poses, frames
+        self.tracking_iter, self.mapping_iter, self.first_mapping_iter = tracking_iter, mapping_iter, first_mapping_iter
+        self.fused = fused
+        self.iteration = 0
+        self.keyframes = []
+        self.rng = random.Random(seed)
+        self.densify = densify
+        # train.py:343 stores render_dep[0] -- ROW 0 of the [H,W] depth, broadcast over all rows -- as the
+        # previous-frame depth of the flow loss.  True reproduces the reference; False stores the full map.
+        self.row0_depth_quirk = row0_depth_quirk
+        self.log = []
+        H, W = frames.colors[0].shape[-2:]
+        self.h, self.w = int(H), int(W)
+
+    # ---- train.py:297-316 -------------------------------------------------------------------------------
+    def densification(self):
+        from . import dist as fdist
+
+        it = self.iteration
+        if not self.densify:
+            return
+        if it % 300 == 0 and it < 15000:
+            fdist.sync_densification_stats(self.pc)
+            size_threshold = 20 if it > 4000 else None
+            self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
+        if it % 3000 == 0:
+            self.pc.reset_opacity()
+
+    def mapping(self, cur_t, mapping_iter, progressive):
+        views = 2 if (progressive and cur_t != 0) else 1
+        self.pc.optimizer.zero_grad(set_to_none=True)
+        pkg = None
+        for _ in range(mapping_iter):
+            self.iteration += 1
+            ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
+            loss, _first = mapping_step(self.pc, self.poses, self.frames, ts, fused=self.fused, step_optimizer=False)
+            with torch.no_grad():
+                self.densification()
+                self.pc.optimizer.step()
+                self.pc.optimizer.zero_grad(set_to_none=True)
+            pkg = _first if views == 1 else None
+        if pkg is None:  # the reference returns the LAST rendered view (cur_t)
+            with torch.no_grad():
+                pkg = (render if self.fused else render_two_pass)(self.poses, cur_t, self.pc, gs_grad=False, cam_grad=False)
+        return pkg
+
+    def tracking(self, t):
+        from .flow import FlowTargets
+
+        # Sampson-distance rigid mask (train.py:158-165) is once-per-frame kornia work outside the hot path
+        # (SURVEY.md s8f #3): all-ones here, as the reference uses for t <= 1
+        rigid = torch.ones((self.h, self.w), dtype=torch.bool, device=self.frames.colors[0].device)
+        depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
+        targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
+        out = None
+        for _ in range(self.tracking_iter):
+            out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=self.fused)
+        return out
+
+    def progressive_run(self):
+        n = len(self.frames.colors)
+        self.poses.initialize_tracking_optimizer(self.tracking_iter)
+        with torch.no_grad():
+            self.poses.get_pose(0)
+        for t in range(n):
+            self.pc.update_learning_rate(self.iteration)
+            if t > 0:
+                if t > 1:
+                    self.poses.initialize_pose(t)
+                else:
+                    with torch.no_grad():
+                        self.poses.r[..., t] = self.poses.r[..., t - 1]
+                        self.poses.t[..., t] = self.poses.t[..., t - 1]
+                self.poses.initialize_tracking_optimizer(self.tracking_iter)
+                loss, rgb, flow, _ = self.tracking(t)
+                self.log.append(("track", t, float(loss), float(rgb), float(flow)))
+            if t in self.frames.i_train:
+                if self.iteration % 1000 == 0:
+                    self.pc.oneupSHdegree()
+                it = self.first_mapping_iter if t == 0 else self.mapping_iter
+                pkg = self.mapping(t, it, progressive=True)
+                self.frames.pred_depths[t] = self._stored_depth(pkg)
+                self.keyframes.append(t)
+            elif self.frames.pred_depths[t] is None:
+                with torch.no_grad():
+                    pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
+                self.frames.pred_depths[t] = self._stored_depth(pkg)
+
+    def _stored_depth(self, pkg):
+        d = pkg["render_dep"].detach().float()
+        if self.row0_depth_quirk:
+            return d[0].expand(self.h, self.w).contiguous()
+        return d.contiguous()
+
+    def global_run(self, iterations):
+        self.pc.initialize_optimizer()
+        for it in range(1, iterations + 1):
+            ts = int(self.rng.choice(list(self.frames.i_train)))
+            if it % 1000 == 0:
+                self.pc.oneupSHdegree()
+            self.pc.update_learning_rate(it)
+            self.mapping(ts, 1, progressive=False)
+
+    def validation(self):
+        from . import metrics
+
+        preds, gts = [], []
+        with torch.no_grad():
+            for i in self.frames.i_test:
+                pkg = (render if self.fused else render_two_pass)(self.poses, int(i), self.pc, False, False)
+                preds.append(pkg["render"].detach().cpu().numpy())
+                gts.append(self.frames.colors[int(i)].detach().cpu().numpy())
+        return metrics.psnr(np.stack(gts), np.stack(preds)) if preds else float("nan")
+
+    def eval_pose(self):
+        from . import metrics
+
+        with torch.no_grad():
+            pred = np.stack([self.poses.get_pose(i).detach().cpu().numpy() for i in range(len(self.frames.colors))])
+        gt = np.stack([np.asarray(g, np.float32) for g in self.frames.gt_w2c])
+        return metrics.pose_metrics(pred, gt)[1]

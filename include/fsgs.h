@@ -200,6 +200,20 @@ int fsgs_pearson_backward(int H, int W, int n_patches, int box, const int64_t *p
                           const float *src, const float *tgt, const float *coef, const float *region_weight,
                           int wrt_src, float *grad, fsgs_stream_t stream);
 
+/* ---- optical-flow reprojection loss of the tracking step (scene/pose_optimizer.py:164-218) ----------- */
+
+/* pts_world [M,3] and pix_vu int64 [M,2] = (v, u): the back-projected valid pixels of the previous frame
+ * (pose independent, prepared once per frame).  w2c [4,4] DEVICE row-major current pose; K9_host = row-major
+ * 3x3 intrinsics on the HOST; flow_fw [2,H,W] (channel 0 = du, 1 = dv).  edge = 20 in the reference.
+ * acc3 double[3] scratch kept for backward; out2 float[2] = {loss, #valid} on the device. */
+int fsgs_flow_pose_loss_forward(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                                const float *K9_host, const float *flow_fw, int W, int H, float edge,
+                                double *acc3, float *out2, fsgs_stream_t stream);
+/* dw2c [4,4] (rows 0..2 = upstream * dloss/dw2c, row 3 = 0); upstream DEVICE scalar or NULL. */
+int fsgs_flow_pose_loss_backward(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                                 const float *K9_host, const float *flow_fw, int W, int H, float edge,
+                                 const double *acc3, const float *upstream, float *dw2c, fsgs_stream_t stream);
+
 /* ---- optimiser step and densification statistics -------------------------------------------------- */
 
 /* One parameter group of torch.optim.Adam (no weight decay, no amsgrad): all DEVICE pointers of n

@@ -248,6 +248,76 @@ def main():
         ds2 = GM.get_depth_and_silhouette(gm, pts, Vt.unsqueeze(0))
         np.savez_compressed(os.path.join(OUT, "depth_sil.npz"), pts=npy(pts), ds_identity=npy(ds),
                             viewmatrix_stored=npy(Vt), ds_stored=npy(ds2))
+        # ---------------- pose metrics (utils/geometry_utils.py:18-29, utils/utils_poses/*) ----------------
+        from utils import geometry_utils  # noqa: E402
+
+        seed_all(6)
+        out = {}
+        for case in range(3):
+            n = 12 + 5 * case
+            ang = np.cumsum(np.random.randn(n, 3) * 0.03, axis=0)
+            pos = np.cumsum(np.random.randn(n, 3) * 0.05, axis=0)
+            gt = np.tile(np.eye(4), (n, 1, 1))
+            from scipy.spatial.transform import Rotation as Rot
+
+            gt[:, :3, :3] = Rot.from_rotvec(ang).as_matrix()
+            gt[:, :3, 3] = pos
+            sim_R = Rot.from_rotvec([0.3, -0.2, 0.5]).as_matrix()
+            pred = gt.copy()
+            pred[:, :3, :3] = sim_R @ gt[:, :3, :3] @ Rot.from_rotvec(np.random.randn(n, 3) * 0.01).as_matrix()
+            pred[:, :3, 3] = (gt[:, :3, 3] @ sim_R.T) * 1.7 + np.array([0.3, -1.0, 2.0]) + np.random.randn(n, 3) * 0.01
+            import contextlib, io
+
+            with contextlib.redirect_stdout(io.StringIO()):
+                aligned, metrics = geometry_utils.align_pose(torch.tensor(pred).float(), torch.tensor(gt).float())
+            out[f"gt_{case}"] = gt.astype(np.float32)
+            out[f"pred_{case}"] = pred.astype(np.float32)
+            out[f"aligned_{case}"] = npy(aligned)
+            out[f"metrics_{case}"] = np.array(metrics, dtype=np.float64)  # rpe_trans, rpe_rot(deg), ate
+        np.savez_compressed(os.path.join(OUT, "pose_metrics.npz"), **out)
+
+        # ---------------- densify / prune / opacity reset (scene/gaussian_model.py:501-681) ----------------
+        from scene import gaussian_model as gmod  # noqa: E402
+
+        seed_all(7)
+        GM = gmod.GaussianModel
+        P = 400
+        gm = GM.__new__(GM)
+        gm.setup_functions()
+        gm.max_sh_degree, gm.active_sh_degree = 3, 0
+        raw = {"_xyz": torch.randn(P, 3), "_features_dc": torch.randn(P, 1, 3), "_features_rest": torch.randn(P, 15, 3),
+               "_opacity": torch.randn(P, 1) * 2.0, "_scaling": torch.randn(P, 3) * 0.8 - 4.0,
+               "_rotation": torch.randn(P, 4)}
+        gm.params = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
+        gm.variables = {"max_radii2D": torch.rand(P) * 40, "xyz_gradient_accum": torch.rand(P, 1) * 1e-3,
+                        "denom": torch.randint(0, 3, (P, 1)).float(), "scene_radius": torch.tensor(0.75)}
+        groups = [{"params": [gm.params[k]], "lr": 1e-3, "name": k} for k in raw]
+        gm.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        for k in raw:  # one Adam step so the moments are non-trivial
+            gm.params[k].grad = torch.randn_like(gm.params[k]) * 1e-2
+        gm.optimizer.step()
+        before = {k: npy(gm.params[k]) for k in raw}
+        mom = {k: npy(gm.optimizer.state[gm.params[k]]["exp_avg"]) for k in raw}
+        mom2 = {k: npy(gm.optimizer.state[gm.params[k]]["exp_avg_sq"]) for k in raw}
+        var = {k: npy(v) for k, v in gm.variables.items()}
+        out = {"P": P}
+        out.update({"p_" + k: v for k, v in before.items()})
+        out.update({"m_" + k: v for k, v in mom.items()})
+        out.update({"v_" + k: v for k, v in mom2.items()})
+        out.update({"var_" + k: v for k, v in var.items()})
+        import contextlib, io
+
+        torch.manual_seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gm.densify_and_prune(2e-4, 0.05, 20)
+        out.update({"d_" + k: npy(gm.params[k]) for k in raw})
+        out.update({"dm_" + k: npy(gm.optimizer.state[gm.params[k]]["exp_avg"]) for k in raw})
+        out.update({"dvar_" + k: npy(v) for k, v in gm.variables.items()})
+        with contextlib.redirect_stdout(io.StringIO()):
+            gm.reset_opacity()
+        out["r_opacity"] = npy(gm.params["_opacity"])
+        out["r_m_opacity"] = npy(gm.optimizer.state[gm.params["_opacity"]]["exp_avg"])
+        np.savez_compressed(os.path.join(OUT, "densify.npz"), **out)
     print("golden fixtures written to", OUT)
 
 

@@ -1,0 +1,76 @@
+"""GPU parity of the flow reprojection loss kernels (csrc/flow.hip) against the golden vectors captured
+from the reference's projection_flow_loss and against the torch statement at C1 size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd import flow, pose
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+T = lambda a: torch.tensor(np.asarray(a), device=DEV)
+
+
+def test_flow_loss_matches_reference_golden():
+    g = np.load(os.path.join(G, "flow_loss.npz"))
+    for tag, rm in (("rigid", T(g["rigid"])), ("norigid", None)):
+        r = T(g["q"]).reshape(1, 4, 1).clone().requires_grad_(True)
+        t = T(g["t"]).reshape(3, 1).clone().requires_grad_(True)
+        w2c = pose.pose_to_w2c(r, t, 0)
+        w2c.retain_grad()
+        l = flow.projection_flow_loss(T(g["depth_prev"]), g["w2c_prev"], w2c, g["K"], T(g["flow"])[0], rm)
+        l.backward()
+        np.testing.assert_allclose(l.item(), g[f"loss_{tag}"], rtol=2e-5)
+        np.testing.assert_allclose(w2c.grad.cpu().numpy()[:3], g[f"dw2c_{tag}"][:3], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(r.grad.cpu().numpy(), g[f"dr_{tag}"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g[f"dt_{tag}"], rtol=2e-3, atol=2e-4)
+
+
+def test_flow_loss_matches_torch_statement_at_c1_and_caches_targets():
+    torch.manual_seed(0)
+    H, W = 512, 640
+    from fsgs_amd import synth
+
+    K = synth.intrinsics(W, H)
+    u = torch.arange(W, device=DEV).float()[None] / W
+    v = torch.arange(H, device=DEV).float()[:, None] / H
+    depth = (1.0 + 0.3 * torch.sin(6.28 * u) * torch.cos(6.28 * v)).reshape(1, H, W).contiguous()
+    depth[0, :9, :11] = 0.0
+    fl = torch.randn(2, H, W, device=DEV)
+    rigid = torch.rand(H, W, device=DEV) > 0.1
+    w_prev = synth.pose_matrix((1, 0.001, 0.002, -0.001), (0.01, 0.0, -0.01)).astype(np.float32)
+    targets = flow.FlowTargets(depth, w_prev, K, fl, rigid)
+    for it in range(3):  # the per-frame targets are reused over the tracking iterations
+        q = torch.tensor([1.0, 0.01 * it, -0.02, 0.015], device=DEV).reshape(1, 4, 1).requires_grad_(True)
+        t = torch.tensor([0.02, -0.01, 0.03 * it], device=DEV).reshape(3, 1).requires_grad_(True)
+        a = pose.pose_to_w2c(q, t, 0)
+        a.retain_grad()
+        la = flow.flow_pose_loss(a, targets)
+        (2.0 * la).backward()
+        ga = a.grad.clone()
+        b = a.detach().clone().requires_grad_(True)
+        lb = flow.projection_flow_loss_torch(depth, w_prev, b, K, fl, rigid)
+        (2.0 * lb).backward()
+        assert abs(la.item() - lb.item()) <= 2e-5 * abs(lb.item())
+        scale = b.grad[:3].abs().max().item()
+        assert (ga[:3] - b.grad[:3]).abs().max().item() <= 1e-3 * scale
+
+
+def test_flow_loss_empty_and_behind_camera_are_zero():
+    H, W = 64, 80
+    from fsgs_amd import synth
+
+    K = synth.intrinsics(W, H)
+    depth = torch.zeros(1, H, W, device=DEV)
+    fl = torch.zeros(2, H, W, device=DEV)
+    w = torch.eye(4, device=DEV).requires_grad_(True)
+    l = flow.projection_flow_loss(depth, np.eye(4, dtype=np.float32), w, K, fl, None)
+    l.backward()
+    assert l.item() == 0.0 and not bool(w.grad.abs().sum())
+    depth = torch.ones(1, H, W, device=DEV)
+    flip = torch.diag(torch.tensor([1.0, 1.0, -1.0, 1.0], device=DEV)).requires_grad_(True)  # everything behind
+    l = flow.projection_flow_loss(depth, np.eye(4, dtype=np.float32), flip, K, fl, None)
+    assert l.item() == 0.0

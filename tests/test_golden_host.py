@@ -133,3 +133,42 @@ def test_depth_silhouette_pseudo_colours_use_the_stored_matrix_rows():
     np.testing.assert_allclose((z * z).numpy(), g["ds_stored"][:, 2], rtol=1e-5, atol=1e-6)
     assert (g["ds_stored"][:, 1] == 1).all()
     np.testing.assert_allclose(pts[:, 2].numpy(), g["ds_identity"][:, 0], rtol=1e-6)
+
+
+def test_pose_metrics_match_reference_align_pose():
+    from fsgs_amd import metrics
+
+    g = _load("pose_metrics.npz")
+    for case in range(3):
+        aligned, m = metrics.pose_metrics(g[f"pred_{case}"], g[f"gt_{case}"])
+        np.testing.assert_allclose(aligned, g[f"aligned_{case}"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(m, g[f"metrics_{case}"], rtol=2e-3, atol=1e-5)
+
+
+def test_densify_prune_and_opacity_reset_match_reference():
+    """same inputs, same torch RNG seed -> identical clone / split / prune result and Adam-state surgery
+    (scene/gaussian_model.py:501-676)."""
+    from fsgs_amd.model import PARAM_NAMES, GaussianCloud
+
+    g = _load("densify.npz")
+    pc = GaussianCloud({k: g["p_" + k] for k in PARAM_NAMES}, device="cpu", scene_radius=float(g["var_scene_radius"]))
+    pc.training_setup(fused=False)
+    for grp in pc.optimizer.param_groups:  # install the recorded Adam moments
+        p = grp["params"][0]
+        pc.optimizer.state[p] = {"step": torch.tensor(1.0), "exp_avg": T(g["m_" + grp["name"]]).clone(),
+                                 "exp_avg_sq": T(g["v_" + grp["name"]]).clone()}
+    pc.variables["max_radii2D"] = T(g["var_max_radii2D"]).clone()
+    pc.variables["xyz_gradient_accum"] = T(g["var_xyz_gradient_accum"]).clone()
+    pc.variables["denom"] = T(g["var_denom"]).clone()
+    torch.manual_seed(11)
+    pc.densify_and_prune(2e-4, 0.05, 20)
+    assert pc.num_points == g["d__xyz"].shape[0] and pc.num_points != int(g["P"])
+    for k in PARAM_NAMES:
+        np.testing.assert_allclose(pc.params[k].detach().numpy(), g["d_" + k], rtol=1e-6, atol=1e-7)
+        st = pc.optimizer.state[pc.params[k]]
+        np.testing.assert_allclose(st["exp_avg"].numpy(), g["dm_" + k], rtol=1e-6, atol=1e-12)
+    for k in ("max_radii2D", "xyz_gradient_accum", "denom"):
+        np.testing.assert_array_equal(pc.variables[k].numpy(), g["dvar_" + k])
+    pc.reset_opacity()
+    np.testing.assert_allclose(pc.params["_opacity"].detach().numpy(), g["r_opacity"], rtol=1e-6)
+    assert not np.any(pc.optimizer.state[pc.params["_opacity"]]["exp_avg"].numpy())
