@@ -228,14 +228,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, 
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
 template <int C, bool WITH_DEPTH>
-__global__ __launch_bounds__(256) void blend_fwd_kernel(
+__global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
     const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ depth,
     const float *__restrict__ colors, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
     float *__restrict__ out_color, float *__restrict__ out_color2, float *__restrict__ out_depth) {
-  const int lane = threadIdx.x & 63;
-  const int vb = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tile = vb * 4 + (threadIdx.x >> 6);
+  // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
+  const int lane = threadIdx.x;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
@@ -330,20 +330,23 @@ constexpr int kAccStride = 8;
 // reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
 // `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
 template <int C, bool SPLIT>
-__global__ __launch_bounds__(256) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
     CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
     const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ colors,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
     float *__restrict__ dcolors) {
-  const int lane = threadIdx.x & 63;
-  const int vb = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tile = vb * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
   const size_t HW = (size_t)H * W;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
-  float px[4], py[4], T[4], Tfin[4], bgdot[4], bgdot_rgb[4], aprev[4], g[4][C], acc[4][C], cprev[4][C];
+  // acc[k][ch]: colour accumulated BEHIND the Gaussian being processed, normalised by the transmittance in
+  // front of it (UPSTREAM's accum_rec; updated right after each Gaussian instead of lazily before the next,
+  // the same fma in the same order, so last_alpha / last_color need no registers).
+  // tb[k] = T_final * (bg . dL/dpixel), tbr[k] the same over the RGB channels only.
+  float px[4], py[4], T[4], tb[4], tbr[4], g[4][C], acc[4][C];
   int last[4], qlast[4];
   int mylast = 0;
 #pragma unroll
@@ -352,24 +355,23 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
     py[k] = (float)tp.y[k];
     bool inside = tp.x[k] < W && tp.y[k] < H;
     size_t pix = inside ? (size_t)tp.y[k] * W + tp.x[k] : 0;
-    Tfin[k] = inside ? final_T[pix] : 0.0f;
-    T[k] = Tfin[k];
+    const float Tfin = inside ? final_T[pix] : 0.0f;
+    T[k] = Tfin;
     last[k] = inside ? (int)n_contrib[pix] : 0;
     qlast[k] = wave_max(last[k]);  // deepest contributor of quadrant k (scalar)
     mylast = max(mylast, last[k]);
-    aprev[k] = 0.0f;
-    bgdot[k] = 0.0f;
-    bgdot_rgb[k] = 0.0f;
+    float bgdot = 0.0f, bgdot_rgb = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < C; ch++) {
       // channels >= 3 of the fused pass come from their own tensor; a missing tensor is a zero gradient
       const float *gp = ch < 3 ? dL_dcolor : dL_dcolor2;
       g[k][ch] = (inside && gp) ? gp[(ch < 3 ? ch : ch - 3) * HW + pix] : 0.0f;
-      bgdot[k] = fmaf(cam.bg[ch], g[k][ch], bgdot[k]);
-      if (SPLIT && ch < 3) bgdot_rgb[k] = fmaf(cam.bg[ch], g[k][ch], bgdot_rgb[k]);
+      bgdot = fmaf(cam.bg[ch], g[k][ch], bgdot);
+      if (SPLIT && ch < 3) bgdot_rgb = fmaf(cam.bg[ch], g[k][ch], bgdot_rgb);
       acc[k][ch] = 0.0f;
-      cprev[k][ch] = 0.0f;
     }
+    tb[k] = Tfin * bgdot;
+    tbr[k] = Tfin * bgdot_rgb;
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
@@ -421,18 +423,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
           T[k] = T[k] * inv1ma;
           float wgt = e.alpha * T[k];
           float dL_dalpha = 0.0f, dL_dalpha_rgb = 0.0f;
+          const float one_m_a = 1.0f - e.alpha;
 #pragma unroll
           for (int ch = 0; ch < C; ch++) {
-            acc[k][ch] = fmaf(aprev[k], cprev[k][ch], (1.0f - aprev[k]) * acc[k][ch]);
-            cprev[k][ch] = bcol[ch];
             dL_dalpha = fmaf(bcol[ch] - acc[k][ch], g[k][ch], dL_dalpha);
             if (SPLIT && ch == 2) dL_dalpha_rgb = dL_dalpha;
             s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
+            acc[k][ch] = fmaf(e.alpha, bcol[ch], one_m_a * acc[k][ch]);  // now "behind" the next one in front
           }
           dL_dalpha *= T[k];
-          aprev[k] = e.alpha;
-          const float bgw = -Tfin[k] * inv1ma;
-          dL_dalpha = fmaf(bgw, bgdot[k], dL_dalpha);
+          dL_dalpha = fmaf(-inv1ma, tb[k], dL_dalpha);
           float dL_dG = bo * dL_dalpha;
           float gdx = e.G * e.dx, gdy = e.G * e.dy;
           float dG_ddx = -gdx * bA - gdy * bB;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(
           s[0] = fmaf(dL_dG, dG_ddx, s[0]);
           s[1] = fmaf(dL_dG, dG_ddy, s[1]);
           if (SPLIT) {
-            float dG_rgb = bo * fmaf(bgw, bgdot_rgb[k], dL_dalpha_rgb * T[k]);
+            float dG_rgb = bo * fmaf(-inv1ma, tbr[k], dL_dalpha_rgb * T[k]);
             s[6] = fmaf(dG_rgb, dG_ddx, s[6]);
             s[7] = fmaf(dG_rgb, dG_ddy, s[7]);
           }
@@ -759,8 +759,7 @@ template <int C, bool WITH_DEPTH = true>
 int launch_blend_fwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *depth, const float *colors, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
-  int blocks = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(blocks), dim3(256), 0, s, cam, ntiles, ranges, plist, xy,
+  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, ranges, plist, xy,
                      co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
@@ -768,8 +767,7 @@ template <int C, bool SPLIT = false>
 int launch_blend_bwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
-  int blocks = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(blocks), dim3(256), 0, s, cam, ntiles, ranges, plist, xy, co,
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, ranges, plist, xy, co,
                      colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
   return 0;
 }
