@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--two-pass", action="store_true", help="unfused render (two rasteriser calls)")
     ap.add_argument("--torch-losses", action="store_true", help="plain-PyTorch losses instead of the HIP kernels")
+    ap.add_argument("--autograd", action="store_true",
+                    help="drive the step through torch.autograd (trainer.mapping_step) instead of the autograd-free "
+                         "stepper (fast_step.FastStepper); same arithmetic, more host overhead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     args = ap.parse_args()
@@ -138,12 +141,19 @@ def main():
 
     bucket = fdist.GradBucket(pc) if world > 1 else None
     n_frames = len(frames.colors)
+    use_fast = fused and hip_losses and not args.autograd
+    if use_fast:
+        from fsgs_amd.fast_step import FastStepper
+
+        stepper = FastStepper(pc, poses, frames)
 
     def one_step(it):
         ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
         if bucket is not None:
             bucket.attach(pc)
         sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None
+        if use_fast:
+            return stepper.mapping_step([ts], grad_sync=sync), None
         return mapping_step(pc, poses, frames, [ts], fused=fused, hip_losses=hip_losses, grad_sync=sync)
 
     def barrier():
@@ -210,6 +220,7 @@ def main():
             "config": {"workload": "%s: mapping iteration, %dx%d, %d Gaussians (%s scene), 1 camera/rank" % (
                 args.config, W, H, P, CONFIGS[args.config][3]),
                 "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
+                "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "parallelism": "dp%d" % world, "loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
         }

@@ -32,14 +32,15 @@ struct AdamTable {
   float inv_bc2_sqrt[ADAM_MAX_GROUPS];  // 1 / sqrt(1 - beta2^t)
   int block_start[ADAM_MAX_GROUPS + 1];
   int ngroups;
-  float beta1, beta2, eps;
+  float beta1, beta2, one_minus_beta1, one_minus_beta2, eps;
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float b1, float b2, float eps,
-                                         float step_size, float inv_bc2_sqrt) {
-  // torch.optim.Adam (single-tensor path): lerp, mul+addcmul, sqrt/bc2 + eps, addcdiv
-  m = fmaf(1.0f - b1, g - m, m);
-  v = fmaf(1.0f - b2, g * g, b2 * v);
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1, float b2, float omb2,
+                                         float eps, float step_size, float inv_bc2_sqrt) {
+  // torch.optim.Adam: lerp_(grad, 1-beta1); mul_(beta2).addcmul_(grad, grad, value=1-beta2); sqrt/bc2 + eps; addcdiv_
+  // (1-beta) is formed in DOUBLE on the host like torch does: 1 - 0.999f would be off by 4.7e-5 relative)
+  m = fmaf(omb1, g - m, m);
+  v = fmaf(omb2, g * g, b2 * v);
   float denom = sqrtf(v) * inv_bc2_sqrt + eps;
   p = p - step_size * (m / denom);
 }
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t) {
   const int64_t base = (int64_t)(blockIdx.x - t.block_start[gi]) * ADAM_ELEMS_PER_BLOCK;
   float *p = t.p[gi], *m = t.m[gi], *v = t.v[gi];
   const float *g = t.g[gi];
-  const float b1 = t.beta1, b2 = t.beta2, eps = t.eps, ss = t.step_size[gi], ib = t.inv_bc2_sqrt[gi];
+  const float b1 = t.one_minus_beta1, b2 = t.beta2, ob2 = t.one_minus_beta2, eps = t.eps, ss = t.step_size[gi],
+              ib = t.inv_bc2_sqrt[gi];
   const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
 #pragma unroll
   for (int it = 0; it < 4; it++) {
@@ -61,15 +63,15 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t) {
     if (i >= n) break;
     if (aligned && i + 4 <= n) {
       float4 pp = *(float4 *)(p + i), gg = *(const float4 *)(g + i), mm = *(float4 *)(m + i), vv = *(float4 *)(v + i);
-      adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, eps, ss, ib);
-      adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, eps, ss, ib);
-      adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, eps, ss, ib);
-      adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, eps, ss, ib);
+      adam_one(pp.x, gg.x, mm.x, vv.x, b1, b2, ob2, eps, ss, ib);
+      adam_one(pp.y, gg.y, mm.y, vv.y, b1, b2, ob2, eps, ss, ib);
+      adam_one(pp.z, gg.z, mm.z, vv.z, b1, b2, ob2, eps, ss, ib);
+      adam_one(pp.w, gg.w, mm.w, vv.w, b1, b2, ob2, eps, ss, ib);
       *(float4 *)(p + i) = pp; *(float4 *)(m + i) = mm; *(float4 *)(v + i) = vv;
     } else {
       for (int64_t j = i; j < n && j < i + 4; j++) {
         float pp = p[j], mm = m[j], vv = v[j];
-        adam_one(pp, g[j], mm, vv, b1, b2, eps, ss, ib);
+        adam_one(pp, g[j], mm, vv, b1, b2, ob2, eps, ss, ib);
         p[j] = pp; m[j] = mm; v[j] = vv;
       }
     }
@@ -97,13 +99,14 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int32_t
 
 extern "C" {
 
-int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, float beta1, float beta2, float eps,
+int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, double beta1, double beta2, double eps,
                    fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (ngroups < 0 || ngroups > ADAM_MAX_GROUPS || (ngroups > 0 && !groups)) return FSGS_ERR_INVALID;
   AdamTable t;
   std::memset(&t, 0, sizeof(t));
-  t.beta1 = beta1; t.beta2 = beta2; t.eps = eps;
+  t.beta1 = (float)beta1; t.beta2 = (float)beta2; t.eps = (float)eps;
+  t.one_minus_beta1 = (float)(1.0 - beta1); t.one_minus_beta2 = (float)(1.0 - beta2);
   int blocks = 0, k = 0;
   for (int i = 0; i < ngroups; i++) {
     const FsgsAdamGroup &g = groups[i];
@@ -111,7 +114,7 @@ int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, float beta1, float 
     if (g.n == 0) continue;
     if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq) return FSGS_ERR_INVALID;
     t.p[k] = g.param; t.g[k] = g.grad; t.m[k] = g.exp_avg; t.v[k] = g.exp_avg_sq; t.n[k] = g.n;
-    double bc1 = 1.0 - pow((double)beta1, (double)g.step), bc2 = 1.0 - pow((double)beta2, (double)g.step);
+    double bc1 = 1.0 - pow(beta1, (double)g.step), bc2 = 1.0 - pow(beta2, (double)g.step);
     t.step_size[k] = (float)((double)g.lr / bc1);
     t.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(bc2));
     t.block_start[k] = blocks;

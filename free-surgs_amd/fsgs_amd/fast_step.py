@@ -1,0 +1,234 @@
+"""Autograd-free mapping / tracking iterations: the same arithmetic as trainer.mapping_step /
+tracking_step (train.py:166-200,236-272), but every stage is ONE C-ABI call into libfsgs_hip.so and the
+chain rule between stages is written out by hand, so a step costs ~15 kernel launches and no autograd
+graph (the torch-autograd path spends ~0.5 ms/step of pure host time in ~100 tiny kernels).
+
+    mapping :  render fwd -> rgb loss fwd -> pearson(global + patches) fwd
+               -> rgb bwd (x5) -> pearson bwd (x0.05, x0.15/n) -> render bwd -> densify stats -> Adam
+    tracking:  render fwd -> masked rgb loss fwd -> flow loss fwd -> their bwd -> render bwd (pose only)
+               -> quaternion/translation chain (12 floats, torch) -> Adam
+
+Equivalence with the autograd path is asserted in tests/test_fast_step_gpu.py.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, losses, rasterizer
+from .model import PARAM_NAMES
+from .render_ops import _args_struct
+
+LOSS_W_MAPPING = {"rgb": 5.0, "pearson": 0.05, "local_pearson": 0.15}  # train.py:254-258
+LOSS_W_TRACKING = {"rgb": 1.0, "flow": 0.1}  # train.py:180-184
+BOX, P_CORR = 128, 0.5  # train.py:257
+
+
+class _Buffers:
+    """Per-shape device buffers reused across steps (nothing here survives a change of P, H or W)."""
+
+    def __init__(self, P, H, W, n_patches, dev):
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        self.key = (P, H, W, n_patches, str(dev))
+        self.image, self.depth_sil = f(3, H, W), f(3, H, W)
+        self.radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        self.maps = f(3, 3, H, W)
+        self.sums = torch.empty((2,), dtype=torch.float64, device=dev)
+        self.rgb_out = f(3)
+        self.stats = torch.empty((5 * (n_patches + 1),), dtype=torch.float64, device=dev)
+        self.coef = f(8 * (n_patches + 1))
+        self.pe_out = f(2)
+        self.d_image = f(3, H, W)
+        self.d_depth_sil = torch.zeros((3, H, W), dtype=torch.float32, device=dev)  # planes 1,2 stay zero
+        self.up_rgb = torch.tensor([LOSS_W_MAPPING["rgb"]], dtype=torch.float32, device=dev)
+        w = np.full((n_patches + 1,), LOSS_W_MAPPING["local_pearson"] / max(n_patches, 1), np.float32)
+        w[0] = LOSS_W_MAPPING["pearson"]
+        self.pe_w = torch.tensor(w, device=dev)
+        self.means2D_grad = f(P, 3)
+        self.bwd_scratch = torch.empty((P * 56 + 512,), dtype=torch.uint8, device=dev)
+        self.sizes = {}
+
+
+class FastStepper:
+    def __init__(self, pc, poses, frames):
+        self.pc, self.poses, self.frames = pc, poses, frames
+        self.buf = None
+        self.cfg = None
+        self.cfg_key = None
+        self.lib = _lib.load()
+        self.last = {}
+
+    # ---- helpers -----------------------------------------------------------------------------------------
+    def _buffers(self, P, H, W, n_patches, dev):
+        key = (P, H, W, n_patches, str(dev))
+        if self.buf is None or self.buf.key != key:
+            self.buf = _Buffers(P, H, W, n_patches, dev)
+        return self.buf
+
+    def _cfg(self):
+        cam = self.pc.cam
+        key = (id(cam), cam.viewmatrix._version, cam.projmatrix._version, cam.bg._version)
+        if self.cfg_key != key:
+            self.cfg = rasterizer.make_cfg(cam, 6)
+            self.cfg_key = key
+        return self.cfg
+
+    def _render_forward(self, w2c, b):
+        pc, lib = self.pc, self.lib
+        p = pc.params
+        cfg = self._cfg()
+        P, H, W = pc.num_points, cfg.image_height, cfg.image_width
+        dev = p["_xyz"].device
+        args = _args_struct(p["_xyz"], p["_features_dc"], p["_features_rest"], p["_opacity"], p["_scaling"],
+                            p["_rotation"], w2c, self.poses.cam_center, pc.active_sh_degree, pc.max_sh_degree)
+        cap = rasterizer._capacity_for(P, W, H)
+        nr = C.c_int64(0)
+        stream = _lib.current_stream()
+        for _attempt in range(3):
+            sz = b.sizes.get(cap)
+            if sz is None:
+                sb, xb = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(lib.fsgs_render_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_render_sizes")
+                sz = b.sizes[cap] = (sb.value, xb.value)
+            state = torch.empty((sz[0],), dtype=torch.uint8, device=dev)
+            scratch = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
+            rc = lib.fsgs_render_forward(C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil),
+                                         _lib.ptr(b.radii), _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap,
+                                         C.byref(nr), stream)
+            if rc == _lib.FSGS_ERR_CAPACITY and nr.value > cap:
+                cap = int(nr.value * 1.25) + 1024
+                rasterizer._capacity[(P, W, H)] = cap
+                continue
+            _lib.check(rc, "fsgs_render_forward")
+            break
+        else:
+            raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
+        rasterizer.last_num_rendered = int(nr.value)
+        return args, state, sz[0], cap, int(nr.value)
+
+    def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
+                         param_grads):
+        cfg = self._cfg()
+        rc = self.lib.fsgs_render_backward(C.byref(cfg), self.pc.num_points, C.byref(args), _lib.ptr(b.radii),
+                                           _lib.ptr(state), sbytes, cap, nr, _lib.ptr(d_image), _lib.ptr(d_depth_sil),
+                                           int(gs_grad), int(cam_grad), int(param_grads), C.byref(grads),
+                                           _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(), _lib.current_stream())
+        _lib.check(rc, "fsgs_render_backward")
+
+    @staticmethod
+    def _grad_struct(tensors, means2D, w2c):
+        g = _lib.FsgsRenderGrads()
+        (g.xyz, g.features_dc, g.features_rest, g.opacity, g.scaling, g.rotation) = [
+            None if t is None else t.data_ptr() for t in tensors]
+        g.means2D = means2D.data_ptr()
+        g.w2c = None if w2c is None else w2c.data_ptr()
+        return g
+
+    # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
+    def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None):
+        pc, lib = self.pc, self.lib
+        dev = pc.params["_xyz"].device
+        H, W = int(pc.cam.image_height), int(pc.cam.image_width)
+        n_patches = int(P_CORR * (H // BOX) * (W // BOX))
+        total = None
+        with torch.no_grad(), torch.cuda.device(dev):
+            b = self._buffers(pc.num_points, H, W, n_patches, dev)
+            stream = _lib.current_stream()
+            for k, ts in enumerate(timesteps):
+                w2c = self.poses.get_pose(ts).detach().contiguous()
+                args, state, sbytes, cap, nr = self._render_forward(w2c, b)
+                gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
+                # losses forward
+                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, 0.2,
+                                                             _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
+                                                             stream), "fsgs_photometric_loss_forward")
+                cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+                dep = b.depth_sil[0]
+                _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                    _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
+                                                    _lib.ptr(b.pe_out), stream), "fsgs_pearson_forward")
+                # losses backward (upstream factors are device constants)
+                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None,
+                                                              _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
+                                                              _lib.ptr(b.d_image), stream),
+                           "fsgs_photometric_loss_backward")
+                _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                     _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w), 0,
+                                                     _lib.ptr(b.d_depth_sil[0]), stream), "fsgs_pearson_backward")
+                # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
+                first = k == 0
+                tgt = []
+                for name in PARAM_NAMES:
+                    p = pc.params[name]
+                    if first:
+                        if p.grad is None:
+                            p.grad = torch.empty_like(p)
+                        tgt.append(p.grad)
+                    else:
+                        tgt.append(torch.empty_like(p))
+                m2 = b.means2D_grad if first else torch.empty_like(b.means2D_grad)
+                grads = self._grad_struct(tgt, m2, None)
+                self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, b.d_depth_sil, grads, True, False, True)
+                if not first:
+                    for name, t in zip(PARAM_NAMES, tgt):
+                        pc.params[name].grad.add_(t)
+                    # render() itself raises max_radii2D for EVERY rendered view (gaussian_renderer/__init__.py:79)
+                    pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
+                loss_k = (LOSS_W_MAPPING["rgb"] * b.rgb_out[0] + LOSS_W_MAPPING["pearson"] * b.pe_out[0]
+                          + LOSS_W_MAPPING["local_pearson"] * b.pe_out[1])
+                total = loss_k if total is None else total + loss_k
+                if first:  # densification statistics come from view 0 only (train.py:260-263)
+                    radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
+            if grad_sync is not None:
+                grad_sync(pc)
+            from . import optim
+
+            optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
+                                pc.variables["xyz_gradient_accum"], pc.variables["denom"])
+            self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil}
+            if step_optimizer:
+                pc.optimizer.step()
+                # gradients are overwritten by the next step's backward; nothing to zero
+        return total
+
+    # ---- tracking (train.py:166-200) -----------------------------------------------------------------------
+    def tracking_step(self, t, targets, rigid_mask):
+        pc, lib, poses = self.pc, self.lib, self.poses
+        dev = pc.params["_xyz"].device
+        H, W = int(pc.cam.image_height), int(pc.cam.image_width)
+        with torch.cuda.device(dev):
+            w2c = poses.get_pose(t)  # keeps the tiny quaternion -> matrix graph for the 12-float chain rule
+            with torch.no_grad():
+                b = self._buffers(pc.num_points, H, W, int(P_CORR * (H // BOX) * (W // BOX)), dev)
+                stream = _lib.current_stream()
+                wd = w2c.detach().contiguous()
+                args, state, sbytes, cap, nr = self._render_forward(wd, b)
+                mask = ((b.depth_sil[0] > 0) * rigid_mask).to(torch.float32).contiguous()
+                gt = self.frames.colors[t]
+                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
+                                                             0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
+                                                             _lib.ptr(b.rgb_out), stream), "fsgs_photometric_loss_forward")
+                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
+                                                              _lib.ptr(b.maps), None, 0.2, _lib.ptr(b.d_image), stream),
+                           "fsgs_photometric_loss_backward")
+                acc = torch.empty((3,), dtype=torch.float64, device=dev)
+                fl_out = torch.empty((2,), dtype=torch.float32, device=dev)
+                M = int(targets.pts.shape[0])
+                _lib.check(lib.fsgs_flow_pose_loss_forward(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
+                                                           targets.K9, _lib.ptr(targets.flow), W, H, 20.0, _lib.ptr(acc),
+                                                           _lib.ptr(fl_out), stream), "fsgs_flow_pose_loss_forward")
+                d_flow = torch.empty((4, 4), dtype=torch.float32, device=dev)
+                _lib.check(lib.fsgs_flow_pose_loss_backward(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
+                                                            targets.K9, _lib.ptr(targets.flow), W, H, 20.0, _lib.ptr(acc),
+                                                            None, _lib.ptr(d_flow), stream), "fsgs_flow_pose_loss_backward")
+                d_w2c = torch.empty((4, 4), dtype=torch.float32, device=dev)
+                grads = self._grad_struct([None] * 6, b.means2D_grad, d_w2c)
+                self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False)
+                d_total = LOSS_W_TRACKING["rgb"] * d_w2c + LOSS_W_TRACKING["flow"] * d_flow
+                rgb, flow = LOSS_W_TRACKING["rgb"] * b.rgb_out[0], LOSS_W_TRACKING["flow"] * fl_out[0]
+            w2c.backward(d_total)  # LearnPose.forward's backward: normalize + q2rot, 12 floats
+            poses.scheduler.step()
+            with torch.no_grad():
+                poses.optimizer.step()
+                poses.optimizer.zero_grad(set_to_none=True)
+        return (flow + rgb).detach(), rgb.detach(), flow.detach()

@@ -102,8 +102,13 @@ def mapping_loss(pkg, gt_image, mono_dep, corners=None, hip_losses=True):
     else:  # the plain-PyTorch statement of the same maths (numerics reference of the fused kernels)
         rgb_f, pe_f, lp_f = losses.rgb_loss_torch, losses.pearson_torch, losses.local_pearson_torch
     rgb = rgb_f(pkg["render"], gt_image) * LOSS_W_MAPPING["rgb"]
-    pear = pe_f(mono_dep, pkg["render_dep"])
-    lp = lp_f(mono_dep, pkg["render_dep"], 128, 0.5, corners)
+    if hip_losses:  # global + patch Pearson from ONE pair of launches
+        from . import loss_ops
+
+        pear, lp = loss_ops.pearson_pair(mono_dep, pkg["render_dep"], 128, 0.5, corners)
+    else:
+        pear = pe_f(mono_dep, pkg["render_dep"])
+        lp = lp_f(mono_dep, pkg["render_dep"], 128, 0.5, corners)
     return rgb + pear * LOSS_W_MAPPING["pearson"] + lp * LOSS_W_MAPPING["local_pearson"]
 
 
@@ -171,6 +176,11 @@ class Runner:
         # train.py:343 stores render_dep[0] -- ROW 0 of the [H,W] depth, broadcast over all rows -- as the
         # previous-frame depth of the flow loss.  True reproduces the reference; False stores the full map.
         self.row0_depth_quirk = row0_depth_quirk
+        self.fast = None
+        if fused:
+            from .fast_step import FastStepper
+
+            self.fast = FastStepper(pc, poses, frames)
         self.log = []
         H, W = frames.colors[0].shape[-2:]
         self.h, self.w = int(H), int(W)
@@ -196,7 +206,12 @@ class Runner:
         for _ in range(mapping_iter):
             self.iteration += 1
             ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
-            loss, _first = mapping_step(self.pc, self.poses, self.frames, ts, fused=self.fused, step_optimizer=False)
+            if self.fast is not None:
+                self.fast.pc = self.pc
+                self.fast.mapping_step(ts, step_optimizer=False)
+                _first = None
+            else:
+                loss, _first = mapping_step(self.pc, self.poses, self.frames, ts, fused=False, step_optimizer=False)
             with torch.no_grad():
                 self.densification()
                 self.pc.optimizer.step()
@@ -217,7 +232,10 @@ class Runner:
         targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
         out = None
         for _ in range(self.tracking_iter):
-            out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=self.fused)
+            if self.fast is not None:
+                out = self.fast.tracking_step(t, targets, rigid) + (None,)
+            else:
+                out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
         return out
 
     def progressive_run(self):

@@ -229,7 +229,7 @@ typedef struct FsgsAdamGroup {
 } FsgsAdamGroup;
 
 /* groups: HOST array of <= 8 groups, updated by ONE kernel launch (train.py:194,272). */
-int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, float beta1, float beta2, float eps,
+int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, double beta1, double beta2, double eps,
                    fsgs_stream_t stream);
 
 /* For every Gaussian with radii > 0: max_radii2D = max(., radii); xyz_gradient_accum += ||viewspace_grad||;

@@ -1,0 +1,30 @@
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rm -rf /tmp/tr && mkdir -p /tmp/tr
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o tr -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/trace.log 2>&1
+f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
+python - "$f" <<'PY'
+import csv, sys, re
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# last 2 steps: find the last two adam_kernel launches
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
+seg = rows[a + 1:b + 1]
+t0 = int(seg[0]["Start_Timestamp"]); t1 = int(seg[-1]["End_Timestamp"])
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
+out = open("gpurun_out/trace_step.txt", "w")
+def P(*a):
+    s = " ".join(str(x) for x in a); print(s); out.write(s + "\n")
+P("one step: wall %.1f us, kernels %d, busy %.1f us, idle %.1f us" % ((t1 - t0) / 1e3, len(seg), busy / 1e3, (t1 - t0 - busy) / 1e3))
+prev_end = t0
+for r in seg:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([A-Za-z_0-9:]+(<[0-9a-z, ]+>)?)", name); name = (m.group(1) if m else name)[-48:]
+    P("%8.1f gap %6.1f dur %7.1f  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, name))
+    prev_end = max(prev_end, e)
+PY

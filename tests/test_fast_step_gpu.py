@@ -1,0 +1,93 @@
+"""The autograd-free step (fsgs_amd/fast_step.py: every stage one C-ABI call, chain rule by hand) must be
+the same computation as the autograd path (fsgs_amd/trainer.py), which in turn is pinned against the
+reference's call sequence by tests/test_render_gpu.py / test_loss_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd import losses, synth
+from fsgs_amd.fast_step import FastStepper
+from fsgs_amd.model import PARAM_NAMES, GaussianCloud
+from fsgs_amd.trainer import FrameData, PoseTrack, mapping_step, settings_from_cam, tracking_step
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _world(seed=0, W=320, H=256, P=6000, n=3):
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=seed)
+    pc = GaussianCloud(sc, sh_degree=3, device=DEV)
+    pc.cam = settings_from_cam(cam, DEV)
+    pc.active_sh_degree = 2
+    pc.training_setup()
+    poses = PoseTrack(n, DEV)
+    poses.set_pose(1, q=synth.PERTURBED_POSE["q"], t=synth.PERTURBED_POSE["t"])
+    poses.set_pose(2, q=(1, -0.01, 0.005, 0.0), t=(-0.01, 0.02, 0.01))
+    g = torch.Generator().manual_seed(seed)
+    colors = [torch.rand(3, H, W, generator=g).to(DEV) for _ in range(n)]
+    monos = [(torch.rand(H, W, generator=g) + 0.5).to(DEV) for _ in range(n)]
+    flows = [torch.randn(2, H, W, generator=g).to(DEV) for _ in range(n - 1)]
+    frames = FrameData(colors, monos, flows_fw=flows, K=cam["K"])
+    return pc, poses, frames, cam
+
+
+@pytest.mark.parametrize("views", [[1], [2, 1]])
+def test_fast_mapping_step_equals_autograd_step(views):
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    a = _world()
+    b = _world()
+    from fsgs_amd import optim, trainer
+
+    fs = FastStepper(b[0], b[1], b[2])
+    la = lb = None
+    for _ in range(2):  # two consecutive steps: gradient buffers are reused, Adam state advances
+        loss, first = 0, None
+        for ts in views:  # autograd path, same patch corners for every view
+            pkg = trainer.render(a[1], ts, a[0], gs_grad=True, cam_grad=False)
+            loss = loss + trainer.mapping_loss(pkg, a[2].colors[ts], a[2].monodeps[ts], corners)
+            first = first or pkg
+        loss.backward()
+        optim.densify_stats(first["radii"], first["viewspace_points"].grad, a[0].variables["max_radii2D"],
+                            a[0].variables["xyz_gradient_accum"], a[0].variables["denom"])
+        a[0].optimizer.step()
+        a[0].optimizer.zero_grad(set_to_none=True)
+        la = loss.detach()
+        lb = fs.mapping_step(views, corners=corners)
+    assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())
+    for k in PARAM_NAMES:
+        pa, pb = a[0].params[k].detach(), b[0].params[k].detach()
+        # Adam normalises the step: a few flipped alpha decisions move single Gaussians by O(lr)
+        diff = (pa - pb).abs()
+        assert (diff > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
+    for k in ("max_radii2D", "denom"):
+        assert torch.equal(a[0].variables[k], b[0].variables[k]), k
+    assert torch.allclose(a[0].variables["xyz_gradient_accum"], b[0].variables["xyz_gradient_accum"], rtol=1e-3,
+                          atol=1e-9)
+
+
+def test_fast_tracking_step_equals_autograd_step():
+    from fsgs_amd.flow import FlowTargets
+
+    H, W = 256, 320
+    a = _world(seed=1)
+    b = _world(seed=1)
+    rigid = torch.rand(H, W, device=DEV) > 0.1
+    depth_prev = (torch.rand(1, H, W, device=DEV) + 0.5)
+    out = []
+    for w, fast in ((a, False), (b, True)):
+        pc, poses, frames, cam = w
+        poses.initialize_tracking_optimizer(50)
+        targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), frames.K, frames.flows_fw[0], rigid)
+        if fast:
+            fs = FastStepper(pc, poses, frames)
+            for _ in range(3):
+                l = fs.tracking_step(1, targets, rigid)
+        else:
+            for _ in range(3):
+                l = tracking_step(pc, poses, frames, 1, targets, rigid)
+        out.append((l[0].item(), poses.r.detach().clone(), poses.t.detach().clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-4 * abs(out[0][0])
+    assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=2e-4)  # Adam steps are +-lr sized: compare poses
+    assert torch.allclose(out[0][2], out[1][2], rtol=0, atol=2e-4)
