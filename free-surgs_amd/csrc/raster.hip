@@ -27,10 +27,10 @@ int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
   if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !state_bytes || !scratch_bytes) return FSGS_ERR_INVALID;
   *state_bytes = state_layout(P, width, height, max_pairs).total;
   ScratchLayout sl;
-  if (scratch_layout(P, width, height, max_pairs, sl) != 0) return fsgs_fail("rocprim size query");
+  scratch_layout(P, width, height, max_pairs, sl);
   // backward needs P * 8 floats of accumulators; make one scratch size serve both directions
   size_t bwd = (size_t)(P > 0 ? P : 1) * kAccStride * sizeof(float) + 256;
-  *scratch_bytes = sl.total > bwd ? sl.total : bwd;
+  *scratch_bytes = sl.total_bytes > bwd ? sl.total_bytes : bwd;
   return FSGS_OK;
 }
 
@@ -57,10 +57,10 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   FwdBuffers B;
   int rc = bind_forward_buffers(P, W, H, max_pairs, 0, state, state_bytes, scratch, scratch_bytes, B);
   if (rc != FSGS_OK) return rc;
-  FSGS_HIP(hipMemsetAsync(B.ranges, 0, sizeof(int2) * (size_t)ntiles, stream));
+  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles, stream));
   if (P > 0) {
     ProfScope ps(PROF_PREPROCESS_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.key_a, B.idx_a};
+    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, opacities,
                        scales, rotations, g);
   }

@@ -7,7 +7,6 @@
 #include <string.h>
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/fsgs.h"
 #include "fsgs_device.h"
@@ -82,22 +81,13 @@ __device__ __forceinline__ Projected project_gaussian(const CamParams &cam, floa
   int maxy = min(cam.gy, max(0, (int)((py + r_ + FSGS_TILE - 1) / FSGS_TILE)));
   int area = (maxx - minx) * (maxy - miny);
   if (area <= 0) return o;
-  // exact footprint culling: keep only the tiles of the 3-sigma rect that some pixel can actually reach
   const float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
-  const float tau = footprint_tau(opacity);
-  int touched = 0;
-  for (int ty = miny; ty < maxy; ty++)
-    for (int tx = minx; tx < maxx; tx++)
-      touched += rect_touched(px, py, cA, cB, cC, tau, (float)(tx * FSGS_TILE), (float)(ty * FSGS_TILE),
-                              (float)FSGS_TILE, (float)FSGS_TILE)
-                     ? 1
-                     : 0;
-  o.radius = r_;  // radii / visibility keep UPSTREAM's meaning even when no tile survives
+  o.radius = r_;  // radii / visibility keep UPSTREAM's meaning even when no tile survives the footprint test
   o.xy = make_float2(px, py);
   o.conic_op = make_float4(cA, cB, cC, opacity);
   o.tz = t.z;
-  if (touched == 0) return o;
-  o.ntile = (uint32_t)touched;
+  if (footprint_tau(opacity) < 0.f) return o;  // alpha can never reach 1/255
+  o.ntile = (uint32_t)area;                    // upper bound; the binning kernels apply the exact test per tile
   o.rect = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
   o.key = __float_as_uint(t.z);  // positive float: the bit pattern is order preserving
   return o;
@@ -110,9 +100,11 @@ struct GeomOut {  // per-Gaussian arrays written by every preprocess kernel
   int32_t *radii;
   uint32_t *tiles;
   ushort4 *rect;
-  uint32_t *depthkey;
-  uint32_t *index;
+  uint32_t *tile_count;  // [tiles] histogram of the binning count pass (zeroed by the host)
+  int gx;
 };
+// also the COUNT pass of the binning: the values are in registers here, so the per-tile histogram is
+// built without a second sweep over the Gaussians
 __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const Projected &o) {
   g.radii[i] = o.radius;
   g.tiles[i] = o.ntile;
@@ -120,8 +112,13 @@ __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const P
   g.xy[i] = o.xy;
   g.conic_op[i] = o.conic_op;
   g.depth[i] = o.tz;
-  g.depthkey[i] = o.key;
-  g.index[i] = (uint32_t)i;
+  if (o.ntile == 0) return;
+  const float tau = footprint_tau(o.conic_op.w);
+  for (int y = o.rect.y; y < o.rect.w; y++)
+    for (int x = o.rect.x; x < o.rect.z; x++)
+      if (rect_touched(o.xy.x, o.xy.y, o.conic_op.x, o.conic_op.y, o.conic_op.z, tau, (float)(x * FSGS_TILE),
+                       (float)(y * FSGS_TILE), (float)FSGS_TILE, (float)FSGS_TILE))
+        atomicAdd(&g.tile_count[y * g.gx + x], 1u);
 }
 
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams cam, const float *__restrict__ means3D,
@@ -137,64 +134,127 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams ca
   store_projected(g, i, o);
 }
 
-// tiles touched, read through the depth order (input of the prefix sum)
-struct TilesInDepthOrder {
-  const uint32_t *tiles;
-  __device__ __forceinline__ uint32_t operator()(uint32_t g) const { return tiles[g]; }
-};
-
-// R3  emit (tile id, Gaussian) pairs, walking the Gaussians in depth order
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int P, int gx, const uint32_t *__restrict__ order,
-                                                         const uint32_t *__restrict__ incl,
-                                                         const uint32_t *__restrict__ tiles,
-                                                         const ushort4 *__restrict__ rect,
-                                                         const float2 *__restrict__ xy,
-                                                         const float4 *__restrict__ conic_op,
-                                                         uint32_t sentinel_tile, uint32_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals) {
+// ------------------------------------------------------------------------------------------------
+// R2-R5  binning: per-tile lists built directly, no global sort
+//   count   : one thread per Gaussian walks its 3-sigma tile rect, keeps the tiles its alpha >= 1/255
+//             footprint can reach (rect_touched, exact) and bumps tile_count[tile]
+//   scan    : ONE workgroup turns the counts into [start,end) ranges (tiles <= 8 K) and the total R
+//   scatter : same walk, claims slot = start + atomic cursor and writes the 64-bit key
+//             (depth bits << 32 | Gaussian index)
+//   sort    : one workgroup per tile sorts its keys in LDS (normalised bitonic network, virtual +inf
+//             padding) and leaves the Gaussian indices in `plist`
+// The resulting order inside a tile is (depth, index) ascending = UPSTREAM's order including ties,
+// independent of the order in which the atomics landed.
+// ------------------------------------------------------------------------------------------------
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uint32_t *__restrict__ tiles,
+                                                        const ushort4 *__restrict__ rect,
+                                                        const float2 *__restrict__ xy,
+                                                        const float4 *__restrict__ conic_op,
+                                                        const float *__restrict__ depth,
+                                                        uint32_t *__restrict__ tile_count,
+                                                        const int2 *__restrict__ ranges,
+                                                        unsigned long long *__restrict__ keys) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
-  uint32_t g = order[i];
-  uint32_t n = tiles[g];
-  if (n == 0) return;
-  uint32_t off = incl[i] - n;
-  ushort4 rc = rect[g];
-  const float2 p = xy[g];
-  const float4 co = conic_op[g];
+  if (tiles[i] == 0) return;
+  const ushort4 rc = rect[i];
+  const float2 p = xy[i];
+  const float4 co = conic_op[i];
   const float tau = footprint_tau(co.w);
-  const uint32_t end = off + n;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(SCATTER ? depth[i] : 0.f) << 32) | (uint32_t)i;
   for (int y = rc.y; y < rc.w; y++)
     for (int x = rc.x; x < rc.z; x++) {
-      // the same (deterministic) test as the count in project_gaussian
-      if (off < end && rect_touched(p.x, p.y, co.x, co.y, co.z, tau, (float)(x * FSGS_TILE), (float)(y * FSGS_TILE),
-                                    (float)FSGS_TILE, (float)FSGS_TILE)) {
-        keys[off] = (uint32_t)(y * gx + x);
-        vals[off] = g;
-        off++;
+      if (!rect_touched(p.x, p.y, co.x, co.y, co.z, tau, (float)(x * FSGS_TILE), (float)(y * FSGS_TILE),
+                        (float)FSGS_TILE, (float)FSGS_TILE))
+        continue;
+      const int t = y * gx + x;
+      const uint32_t slot = atomicAdd(&tile_count[t], 1u);  // count pass: histogram; scatter pass: cursor
+      if (SCATTER) keys[(size_t)ranges[t].x + slot] = key;
+    }
+}
+
+// single workgroup: exclusive scan of tile_count -> ranges, total -> *total_out, cursors reset to zero
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *__restrict__ tile_count,
+                                                          int2 *__restrict__ ranges, uint32_t *__restrict__ total_out) {
+  __shared__ uint32_t part[1024];
+  const int per = (ntiles + 1023) / 1024;
+  const int t0 = threadIdx.x * per;
+  uint32_t s = 0;
+  for (int k = 0; k < per; k++) s += (t0 + k < ntiles) ? tile_count[t0 + k] : 0u;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (int k = 0; k < per; k++) {
+    if (t0 + k < ntiles) {
+      uint32_t c = tile_count[t0 + k];
+      ranges[t0 + k] = make_int2((int)run, (int)(run + c));
+      tile_count[t0 + k] = 0;  // becomes the scatter cursor
+      run += c;
+    }
+  }
+  if (threadIdx.x == 1023) *total_out = part[1023];
+}
+
+constexpr int SORT_LDS_KEYS = 2048;  // 16 KB of LDS per workgroup; longer lists sort in global memory
+
+// compare-exchange network over m (power of two) virtual elements, n real ones; every exchange puts the
+// smaller key at the lower index, so the +inf padding (indices >= n) never moves and is never touched
+template <typename Mem>
+__device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
+  for (int k = 2; k <= m; k <<= 1) {
+    const int hk = k >> 1;
+    for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {  // first step of the merge: mirror partner
+      int blk = t / hk, off = t - blk * hk;
+      int i = blk * k + off, l = blk * k + k - 1 - off;
+      if (l < n) {
+        unsigned long long a = keys[i], b = keys[l];
+        if (a > b) { keys[i] = b; keys[l] = a; }
       }
     }
-  // belt and braces: should count and emission ever disagree, park the unused slots behind the last tile
-  for (; off < end; off++) {
-    keys[off] = sentinel_tile;
-    vals[off] = g;
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+        int i = 2 * j * (t / j) + (t % j), l = i + j;
+        if (l < n) {
+          unsigned long long a = keys[i], b = keys[l];
+          if (a > b) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
-// R5  [start,end) of every tile's run in the sorted pair list
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, uint32_t ntiles,
-                                                          const uint32_t *__restrict__ keys,
-                                                          int2 *__restrict__ ranges) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= R) return;
-  uint32_t t = keys[k];
-  if (t >= ntiles) return;  // sentinel slots
-  if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
-  if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
+__global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 *__restrict__ ranges,
+                                                         unsigned long long *__restrict__ keys,
+                                                         uint32_t *__restrict__ plist) {
+  __shared__ unsigned long long lds[SORT_LDS_KEYS];
+  const int tile = blockIdx.x;
+  const int2 rg = ranges[tile];
+  const int n = rg.y - rg.x;
+  if (n <= 0) return;
+  int m = 1;
+  while (m < n) m <<= 1;
+  unsigned long long *gk = keys + rg.x;
+  if (n <= SORT_LDS_KEYS) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = gk[i];
+    __syncthreads();
+    bitonic_sort_ascending(lds, n, m);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)lds[i];
+  } else {  // rare: a tile with more than 2048 Gaussians sorts in place in global memory (L2 resident)
+    __syncthreads();
+    bitonic_sort_ascending(gk, n, m);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)gk[i];
+  }
 }
 
-// ------------------------------------------------------------------------------------------------
-// R6  forward blend: one wave per 16x16 tile, 4 pixels per lane
-// ------------------------------------------------------------------------------------------------
 // Pixel ownership inside a 16x16 tile: four 8x8 quadrants, lane l owns pixel (l & 7, l >> 3) of each
 // quadrant k = 0..3 at offset (8*(k&1), 8*(k>>1)).  Whether a Gaussian can reach a quadrant at all is a
 // wave-uniform question answered once per pair by its owning lane (rect_touched, exact), carried as a
@@ -652,49 +712,32 @@ StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0
 }
 
 struct ScratchLayout {
-  size_t tiles, rect, key_a, key_b, idx_a, idx_b, incl, pk_a, pk_b, pv_a, temp, temp_bytes, total;
+  size_t tiles, rect, tile_count, total, keys, total_bytes;
 };
 int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
   Carver c;
   size_t Pn = (size_t)(P > 0 ? P : 1), Rn = (size_t)(cap > 0 ? cap : 1);
+  size_t ntiles = (size_t)((W + FSGS_TILE - 1) / FSGS_TILE) * ((H + FSGS_TILE - 1) / FSGS_TILE);
   L.tiles = c.take(4 * Pn);
   L.rect = c.take(8 * Pn);
-  L.key_a = c.take(4 * Pn);
-  L.key_b = c.take(4 * Pn);
-  L.idx_a = c.take(4 * Pn);
-  L.idx_b = c.take(4 * Pn);
-  L.incl = c.take(4 * Pn);
-  L.pk_a = c.take(4 * Rn);
-  L.pk_b = c.take(4 * Rn);
-  L.pv_a = c.take(4 * Rn);
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  uint32_t *nu = nullptr;
-  if (rocprim::radix_sort_pairs(nullptr, t1, nu, nu, nu, nu, Pn, 0, 32, (hipStream_t)0) != hipSuccess) return -1;
-  if (rocprim::radix_sort_pairs(nullptr, t2, nu, nu, nu, nu, Rn, 0, 20, (hipStream_t)0) != hipSuccess) return -1;
-  TilesInDepthOrder f{nullptr};
-  auto it = rocprim::make_transform_iterator(nu, f);
-  if (rocprim::inclusive_scan(nullptr, t3, it, nu, Pn, rocprim::plus<uint32_t>(), (hipStream_t)0) != hipSuccess)
-    return -1;
-  L.temp_bytes = t1 > t2 ? t1 : t2;
-  if (t3 > L.temp_bytes) L.temp_bytes = t3;
-  L.temp_bytes += 256;
-  L.temp = c.take(L.temp_bytes);
-  L.total = c.total();
+  L.tile_count = c.take(4 * ntiles);
+  L.total = c.take(16);
+  L.keys = c.take(8 * Rn);
+  L.total_bytes = c.total();
   return 0;
 }
 
 struct FwdBuffers {
   float2 *xy; float4 *co; float *depth; int2 *ranges; float *final_T; uint32_t *n_contrib; uint32_t *plist;
   float *colors; uint32_t *flags;
-  uint32_t *tiles; ushort4 *rect; uint32_t *key_a, *key_b, *idx_a, *idx_b, *incl, *pk_a, *pk_b, *pv_a;
-  void *temp; size_t temp_bytes;
+  uint32_t *tiles; ushort4 *rect; uint32_t *tile_count; uint32_t *total; unsigned long long *keys;
 };
 int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channels, void *state, size_t state_bytes,
                          void *scratch, size_t scratch_bytes, FwdBuffers &B) {
   StateLayout SL = state_layout(P, W, H, max_pairs, keep_channels);
   ScratchLayout XL;
-  if (scratch_layout(P, W, H, max_pairs, XL) != 0) return fsgs_fail("rocprim size query");
-  if (state_bytes < SL.total || scratch_bytes < XL.total) return FSGS_ERR_CAPACITY;
+  scratch_layout(P, W, H, max_pairs, XL);
+  if (state_bytes < SL.total || scratch_bytes < XL.total_bytes) return FSGS_ERR_CAPACITY;
   char *sb = (char *)state, *xb = (char *)scratch;
   B.xy = (float2 *)(sb + SL.xy); B.co = (float4 *)(sb + SL.conic_op); B.depth = (float *)(sb + SL.depth);
   B.ranges = (int2 *)(sb + SL.ranges); B.final_T = (float *)(sb + SL.final_T);
@@ -702,53 +745,36 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   B.colors = keep_channels ? (float *)(sb + SL.colors) : nullptr;
   B.flags = keep_channels ? (uint32_t *)(sb + SL.flags) : nullptr;
   B.tiles = (uint32_t *)(xb + XL.tiles); B.rect = (ushort4 *)(xb + XL.rect);
-  B.key_a = (uint32_t *)(xb + XL.key_a); B.key_b = (uint32_t *)(xb + XL.key_b);
-  B.idx_a = (uint32_t *)(xb + XL.idx_a); B.idx_b = (uint32_t *)(xb + XL.idx_b);
-  B.incl = (uint32_t *)(xb + XL.incl);
-  B.pk_a = (uint32_t *)(xb + XL.pk_a); B.pk_b = (uint32_t *)(xb + XL.pk_b); B.pv_a = (uint32_t *)(xb + XL.pv_a);
-  B.temp = xb + XL.temp; B.temp_bytes = XL.temp_bytes;
+  B.tile_count = (uint32_t *)(xb + XL.tile_count); B.total = (uint32_t *)(xb + XL.total);
+  B.keys = (unsigned long long *)(xb + XL.keys);
   return FSGS_OK;
 }
-// everything between the preprocess kernel and the blend: depth sort, tile-count scan, the one host sync
-// that reads R, pair emission, stable sort by tile, tile ranges.  ranges must be zeroed by the caller.
+// everything between the preprocess kernel (which also builds the per-tile histogram; the caller zeroes
+// B.tile_count before launching it) and the blend: scan (+ the one host sync that reads R), scatter,
+// per-tile sort.  Three launches.
 int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, int64_t *num_rendered,
                 hipStream_t stream) {
   const int ntiles = cam.gx * cam.gy;
+  if (ntiles > 1024 * 64) return FSGS_ERR_INVALID;
   uint32_t R = 0;
-  if (P > 0) {
-    {
-      ProfScope ps(PROF_SORT_DEPTH, stream);
-      FSGS_HIP(rocprim::radix_sort_pairs(B.temp, B.temp_bytes, B.key_a, B.key_b, B.idx_a, B.idx_b, (size_t)P, 0, 32,
-                                         stream));
-    }
-    TilesInDepthOrder f{B.tiles};
-    auto it = rocprim::make_transform_iterator(B.idx_b, f);
-    {
-      ProfScope ps(PROF_SCAN, stream);
-      FSGS_HIP(rocprim::inclusive_scan(B.temp, B.temp_bytes, it, B.incl, (size_t)P, rocprim::plus<uint32_t>(),
-                                       stream));
-    }
-    FSGS_HIP(hipMemcpyAsync(&R, B.incl + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    FSGS_HIP(hipStreamSynchronize(stream));  // the one host sync (UPSTREAM R2 does the same)
+  {
+    ProfScope ps(PROF_SCAN, stream);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
   }
+  FSGS_HIP(hipGetLastError());
+  FSGS_HIP(hipMemcpyAsync(&R, B.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  FSGS_HIP(hipStreamSynchronize(stream));  // the one host sync (UPSTREAM R2 does the same)
   *num_rendered = (int64_t)R;
   if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
   if (R > 0) {
     {
-      ProfScope ps(PROF_EMIT, stream);
-      hipLaunchKernelGGL(emit_pairs_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.idx_b, B.incl,
-                         B.tiles, B.rect, B.xy, B.co, (uint32_t)ntiles, B.pk_a, B.pv_a);
+      ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
+      hipLaunchKernelGGL((bin_pairs_kernel<true>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
+                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.ranges, B.keys);
     }
-    FSGS_HIP(hipGetLastError());
     {
       ProfScope ps(PROF_SORT_TILE, stream);
-      FSGS_HIP(rocprim::radix_sort_pairs(B.temp, B.temp_bytes, B.pk_a, B.pk_b, B.pv_a, B.plist, (size_t)R, 0,
-                                         tile_bits(ntiles + 1), stream));
-    }
-    {
-      ProfScope ps(PROF_RANGES, stream);
-      hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, (uint32_t)ntiles, B.pk_b,
-                         B.ranges);
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist);
     }
     FSGS_HIP(hipGetLastError());
   }

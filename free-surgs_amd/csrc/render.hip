@@ -331,9 +331,9 @@ int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
   if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !state_bytes || !scratch_bytes) return FSGS_ERR_INVALID;
   *state_bytes = state_layout(P, width, height, max_pairs, 6).total;
   ScratchLayout sl;
-  if (scratch_layout(P, width, height, max_pairs, sl) != 0) return fsgs_fail("rocprim size query");
+  scratch_layout(P, width, height, max_pairs, sl);
   size_t bwd = (size_t)(P > 0 ? P : 1) * (kAccStride + 6) * sizeof(float) + 512;
-  *scratch_bytes = sl.total > bwd ? sl.total : bwd;
+  *scratch_bytes = sl.total_bytes > bwd ? sl.total_bytes : bwd;
   return FSGS_OK;
 }
 
@@ -352,10 +352,10 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   FwdBuffers B;
   int rc = bind_forward_buffers(P, W, H, max_pairs, 6, state, state_bytes, scratch, scratch_bytes, B);
   if (rc != FSGS_OK) return rc;
-  FSGS_HIP(hipMemsetAsync(B.ranges, 0, sizeof(int2) * (size_t)ntiles, stream));
+  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles, stream));
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.key_a, B.idx_a};
+    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};
     hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), g,
                        B.colors, B.flags);
   }

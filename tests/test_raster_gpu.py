@@ -218,3 +218,21 @@ def test_wave_transposing_reduction_selftest():
     out = torch.zeros(64, device=DEV)
     _lib.check(lib.fsgs_selftest_transpose_reduce(_lib.ptr(a), _lib.ptr(out), _lib.current_stream()), "selftest")
     np.testing.assert_allclose(out.cpu().numpy(), m.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_heavy_tile_takes_the_global_memory_sort_path(oracle32):
+    """> 2048 Gaussians in one tile (LDS sort capacity) -> in-place global-memory bitonic fallback; duplicate
+    depths included so the (depth, index) tie order is exercised."""
+    cam = synth.make_camera(64, 48)
+    K = cam["K"]
+    n = 3000
+    rng = np.random.default_rng(3)
+    z = np.round(rng.uniform(0.5, 1.5, n), 3)  # many exact depth ties
+    u = rng.uniform(18, 30, n)
+    v = rng.uniform(18, 30, n)
+    xyz = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1).astype(np.float32)
+    s = (np.full((n, 3), 1.2) * z[:, None] / K[0, 0]).astype(np.float32)
+    rot = np.tile(np.array([[1, 0, 0, 0]], np.float32), (n, 1))
+    op = rng.uniform(0.01, 0.05, n).astype(np.float32)
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    _compare(oracle32, cam, xyz, col, op, s, rot)
