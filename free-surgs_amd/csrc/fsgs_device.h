@@ -76,6 +76,23 @@ __device__ __forceinline__ float wave_transpose_reduce64(const float (&v)[64], i
   return fold_dpp<0xB1>(u[0], u[1], b0);                                  // quad_perm [1,0,3,2]
 }
 
+// 32-value variant: lane l ends with the total of v[l >> 1] (lanes l and l^1 hold the same value).
+// 70 VALU instructions for 32 values; needs only 32 live registers instead of 64.
+__device__ __forceinline__ float wave_transpose_reduce32(const float (&v)[32], int lane) {
+  float w[16], x[8], y[4], z[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = swap32_add(v[i], v[i + 16]);   // lane bit 5 <-> index bit 4
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = swap16_add(w[i], w[i + 8]);     // lane bit 4 <-> index bit 3
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int i = 0; i < 4; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 4], b3);  // lane bit 3 <-> index bit 2
+#pragma unroll
+  for (int i = 0; i < 2; i++) z[i] = fold_dpp<0x141>(y[i], y[i + 2], b2);  // lane bit 2 <-> index bit 1
+  float u = fold_dpp<0x4E>(z[0], z[1], b1);                                 // lane bit 1 <-> index bit 0
+  return dpp_add<0xB1>(u);                                                  // lanes l, l^1: plain sum
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_max_i(int v) {
   int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);

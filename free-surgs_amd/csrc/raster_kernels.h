@@ -390,7 +390,7 @@ constexpr int kAccStride = 8;
 // reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
 // `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
 template <int C, bool SPLIT>
-__global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
     const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ colors,
     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
@@ -402,13 +402,14 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
   const int W = cam.W, H = cam.H;
   const size_t HW = (size_t)H * W;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
-  // acc[k][ch]: colour accumulated BEHIND the Gaussian being processed, normalised by the transmittance in
-  // front of it (UPSTREAM's accum_rec; updated right after each Gaussian instead of lazily before the next,
-  // the same fma in the same order, so last_alpha / last_color need no registers).
-  // tb[k] = T_final * (bg . dL/dpixel), tbr[k] the same over the RGB channels only.
-  float px[4], py[4], T[4], tb[4], tbr[4], g[4][C], acc[4][C];
+  // Colour terms of dL/dalpha, per pixel and Gaussian i (T_i = transmittance in front of i):
+  //   sum_ch g_ch (c_ch T_i - B_ch / (1 - alpha_i)),   B_ch = sum_{k behind i} c_k alpha_k T_k
+  // which is UPSTREAM's T (c - accum_rec) written with the absolute colour behind.  Only the scalar
+  // gB = sum_ch g_ch B_ch is needed, so one register per pixel replaces accum_rec / last_color / last_alpha:
+  //   gc = sum_ch g_ch c_ch;  dL/dalpha = T gc - (gB + T_final bg.g) / (1 - alpha);  gB += alpha T gc.
+  // tb[k] = T_final * (bg . dL/dpixel); gBr / tbr: the same restricted to the RGB channels (SPLIT).
+  float px[4], py[4], T[4], tb[4], tbr[4], gB[4], gBr[4], g[4][C];
   int last[4], qlast[4];
-  int mylast = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     px[k] = (float)tp.x[k];
@@ -419,7 +420,6 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
     T[k] = Tfin;
     last[k] = inside ? (int)n_contrib[pix] : 0;
     qlast[k] = wave_max(last[k]);  // deepest contributor of quadrant k (scalar)
-    mylast = max(mylast, last[k]);
     float bgdot = 0.0f, bgdot_rgb = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < C; ch++) {
@@ -428,17 +428,19 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
       g[k][ch] = (inside && gp) ? gp[(ch < 3 ? ch : ch - 3) * HW + pix] : 0.0f;
       bgdot = fmaf(cam.bg[ch], g[k][ch], bgdot);
       if (SPLIT && ch < 3) bgdot_rgb = fmaf(cam.bg[ch], g[k][ch], bgdot_rgb);
-      acc[k][ch] = 0.0f;
     }
     tb[k] = Tfin * bgdot;
     tbr[k] = Tfin * bgdot_rgb;
+    gB[k] = 0.0f;
+    gBr[k] = 0.0f;
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
-  // gradient component slots of one Gaussian (16 per Gaussian, 4 Gaussians per transposing reduction):
+  // gradient component slots of one Gaussian (16 per Gaussian, 2 Gaussians per transposing reduction):
   //   0,1 mean2D x,y | 2,3,4 conic A,B,C | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
-  const int my_u = lane >> 4, my_c = lane & 15;  // after the reduction lane l owns (Gaussian u, component c)
-  const bool c_used = my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C);
+  // after the reduction lanes l and l^1 both own (Gaussian u = l >> 5, component c = (l >> 1) & 15)
+  const int my_u = lane >> 5, my_c = (lane >> 1) & 15;
+  const bool c_used = !(lane & 1) && (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C));
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -449,13 +451,13 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
-    for (int jj = n - 1; jj >= 0; jj -= 4) {
-      float v[64];
+    for (int jj = n - 1; jj >= 0; jj -= 2) {
+      float v[32];
 #pragma unroll
-      for (int i = 0; i < 64; i++) v[i] = 0.f;
+      for (int i = 0; i < 32; i++) v[i] = 0.f;
       bool any_group = false;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 2; u++) {
         const int j = jj - u;
         if (j < 0) continue;       // wave-uniform
         const int pos = lo + j;    // 0-based index in the tile list
@@ -479,28 +481,27 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
           SplatEval e;
           if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
           any = true;
-          float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
+          const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
           T[k] = T[k] * inv1ma;
-          float wgt = e.alpha * T[k];
-          float dL_dalpha = 0.0f, dL_dalpha_rgb = 0.0f;
-          const float one_m_a = 1.0f - e.alpha;
+          const float wgt = e.alpha * T[k];
+          float gc = 0.0f, gc_rgb = 0.0f;
 #pragma unroll
           for (int ch = 0; ch < C; ch++) {
-            dL_dalpha = fmaf(bcol[ch] - acc[k][ch], g[k][ch], dL_dalpha);
-            if (SPLIT && ch == 2) dL_dalpha_rgb = dL_dalpha;
+            gc = fmaf(g[k][ch], bcol[ch], gc);
+            if (SPLIT && ch == 2) gc_rgb = gc;
             s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
-            acc[k][ch] = fmaf(e.alpha, bcol[ch], one_m_a * acc[k][ch]);  // now "behind" the next one in front
           }
-          dL_dalpha *= T[k];
-          dL_dalpha = fmaf(-inv1ma, tb[k], dL_dalpha);
-          float dL_dG = bo * dL_dalpha;
-          float gdx = e.G * e.dx, gdy = e.G * e.dy;
-          float dG_ddx = -gdx * bA - gdy * bB;
-          float dG_ddy = -gdy * bC - gdx * bB;
+          const float dL_dalpha = fmaf(T[k], gc, -inv1ma * (gB[k] + tb[k]));
+          gB[k] = fmaf(wgt, gc, gB[k]);
+          const float dL_dG = bo * dL_dalpha;
+          const float gdx = e.G * e.dx, gdy = e.G * e.dy;
+          const float dG_ddx = -gdx * bA - gdy * bB;
+          const float dG_ddy = -gdy * bC - gdx * bB;
           s[0] = fmaf(dL_dG, dG_ddx, s[0]);
           s[1] = fmaf(dL_dG, dG_ddy, s[1]);
           if (SPLIT) {
-            float dG_rgb = bo * fmaf(-inv1ma, tbr[k], dL_dalpha_rgb * T[k]);
+            const float dG_rgb = bo * fmaf(T[k], gc_rgb, -inv1ma * (gBr[k] + tbr[k]));
+            gBr[k] = fmaf(wgt, gc_rgb, gBr[k]);
             s[6] = fmaf(dG_rgb, dG_ddx, s[6]);
             s[7] = fmaf(dG_rgb, dG_ddy, s[7]);
           }
@@ -511,16 +512,12 @@ __global__ __launch_bounds__(64, 3) void blend_bwd_kernel(
         }
         any_group = any_group || (__ballot(any) != 0ull);
       }
-      if (!any_group) continue;  // wave-uniform: none of the four touched any pixel of the tile
-      // 64 x 64 transposing reduction: lane (u, c) receives the tile total of component c of Gaussian jj-u
-      const float tot = wave_transpose_reduce64(v, lane);
+      if (!any_group) continue;  // wave-uniform: neither of the two touched any pixel of the tile
+      // 64 x 32 transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
+      const float tot = wave_transpose_reduce32(v, lane);
       const int j_mine = jj - my_u;
-      uint32_t gsel = readlane(gid, jj);
-#pragma unroll
-      for (int u = 1; u < 4; u++) {
-        uint32_t gu = readlane(gid, max(jj - u, 0));
-        gsel = (my_u == u) ? gu : gsel;
-      }
+      const uint32_t g0 = readlane(gid, jj), g1 = readlane(gid, max(jj - 1, 0));
+      const uint32_t gsel = my_u ? g1 : g0;
       if (j_mine >= 0 && c_used && tot != 0.f) {
         float *dst = my_c < 8 ? grad_acc + (size_t)gsel * kAccStride + my_c : dcolors + (size_t)gsel * C + (my_c - 8);
         atomicAdd(dst, tot);
