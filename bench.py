@@ -111,6 +111,7 @@ def main():
                     help="drive the step through torch.autograd (trainer.mapping_step) instead of the autograd-free "
                          "stepper (fast_step.FastStepper); same arithmetic, more host overhead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true", help="skip the extra tracking-iteration timing")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     args = ap.parse_args()
 
@@ -206,6 +207,27 @@ def main():
             pass
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
 
+    # ---- extra: the pose-only tracking iteration (train.py:166-200) on the same scene, rank 0 / N = 1 ----
+    tracking = None
+    if use_fast and world == 1 and not args.no_tracking:
+        from fsgs_amd.flow import FlowTargets
+
+        poses.initialize_tracking_optimizer(50)
+        rigid = torch.ones((H, W), dtype=torch.bool, device=device)
+        depth_prev = frames.monodeps[0].reshape(1, H, W)
+        flow_fw = torch.zeros((2, H, W), device=device)
+        targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), cam["K"], flow_fw, rigid)
+        for _ in range(3):
+            stepper.tracking_step(1, targets, rigid)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nt = 20
+        for _ in range(nt):
+            stepper.tracking_step(1, targets, rigid)
+        torch.cuda.synchronize()
+        tracking = {"iters_per_sec": nt / (time.perf_counter() - t1), "ms_per_iter": (time.perf_counter() - t1) / nt * 1e3,
+                    "what": "render(gs_grad=False, cam_grad=True) + masked rgb loss + flow loss + pose Adam"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sc, cam, pc.active_sh_degree)
@@ -222,7 +244,7 @@ def main():
                 "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "parallelism": "dp%d" % world, "loss": float(loss)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking,
         }
         print(json.dumps(out))
     if world > 1:

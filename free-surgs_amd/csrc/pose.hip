@@ -1,0 +1,88 @@
+// pose.hip -- LearnPose.forward and its adjoint as single launches (scene/pose_optimizer.py:822-877).
+//
+// w2c = [[R(q2), t], [0 0 0 1]] with q1 = r / max(|r|, 1e-12) (F.normalize) and q2 = q1 / |q1| (q2rot
+// normalises again).  In PyTorch this is ~15 tiny kernels forward and ~30 backward per tracking iteration;
+// 7 floats in, 16 out.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsgs.h"
+#include "fsgs_host.h"
+
+namespace {
+
+struct PoseQ {
+  float q1[4], q2[4], n0, n1;
+};
+__device__ __forceinline__ PoseQ pose_quat(const float *r, int N, int id) {
+  PoseQ o;
+  float a[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) a[k] = r[k * N + id];  // r is [1,4,N]
+  o.n0 = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3]), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; k++) o.q1[k] = a[k] / o.n0;
+  o.n1 = sqrtf(o.q1[0] * o.q1[0] + o.q1[1] * o.q1[1] + o.q1[2] * o.q1[2] + o.q1[3] * o.q1[3]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) o.q2[k] = o.q1[k] / o.n1;
+  return o;
+}
+
+__global__ void pose_fwd_kernel(const float *r, const float *t, int N, int id, float *w2c) {
+  if (threadIdx.x != 0) return;
+  PoseQ p = pose_quat(r, N, id);
+  const float qr = p.q2[0], x = p.q2[1], y = p.q2[2], z = p.q2[3];
+  w2c[0] = 1.f - 2.f * (y * y + z * z); w2c[1] = 2.f * (x * y - qr * z);       w2c[2] = 2.f * (x * z + qr * y);
+  w2c[4] = 2.f * (x * y + qr * z);       w2c[5] = 1.f - 2.f * (x * x + z * z); w2c[6] = 2.f * (y * z - qr * x);
+  w2c[8] = 2.f * (x * z - qr * y);       w2c[9] = 2.f * (y * z + qr * x);       w2c[10] = 1.f - 2.f * (x * x + y * y);
+  w2c[3] = t[0 * N + id]; w2c[7] = t[1 * N + id]; w2c[11] = t[2 * N + id];  // t is [3,N]
+  w2c[12] = 0.f; w2c[13] = 0.f; w2c[14] = 0.f; w2c[15] = 1.f;
+}
+
+// dr [1,4,N], dt [3,N]: overwritten (zero except column id)
+__global__ void pose_bwd_kernel(const float *r, int N, int id, const float *dW, float *dr, float *dt) {
+  for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) dr[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) dt[i] = 0.f;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  PoseQ p = pose_quat(r, N, id);
+  const float qr = p.q2[0], x = p.q2[1], y = p.q2[2], z = p.q2[3];
+  const float d0 = dW[0], d1 = dW[1], d2 = dW[2], d3 = dW[4], d4 = dW[5], d5 = dW[6], d6 = dW[8], d7 = dW[9],
+              d8 = dW[10];
+  float g[4];
+  g[0] = 2.f * (-z * d1 + y * d2 + z * d3 - x * d5 - y * d6 + x * d7);
+  g[1] = 2.f * (y * d1 + z * d2 + y * d3 - 2.f * x * d4 - qr * d5 + z * d6 + qr * d7 - 2.f * x * d8);
+  g[2] = 2.f * (-2.f * y * d0 + x * d1 + qr * d2 + x * d3 + z * d5 - qr * d6 + z * d7 - 2.f * y * d8);
+  g[3] = 2.f * (-2.f * z * d0 - qr * d1 + x * d2 + qr * d3 - 2.f * z * d4 + y * d5 + x * d6 + y * d7);
+  // q2 = q1 / |q1|
+  float dot = p.q2[0] * g[0] + p.q2[1] * g[1] + p.q2[2] * g[2] + p.q2[3] * g[3];
+  float h[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) h[k] = (g[k] - p.q2[k] * dot) / p.n1;
+  // q1 = r / max(|r|, eps)
+  dot = p.q1[0] * h[0] + p.q1[1] * h[1] + p.q1[2] * h[2] + p.q1[3] * h[3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) dr[k * N + id] = (h[k] - p.q1[k] * dot) / p.n0;
+  dt[0 * N + id] = dW[3]; dt[1 * N + id] = dW[7]; dt[2 * N + id] = dW[11];
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsgs_pose_forward(const float *r, const float *t, int num_cams, int cam_id, float *w2c, fsgs_stream_t stream) {
+  if (!r || !t || !w2c || num_cams <= 0 || cam_id < 0 || cam_id >= num_cams) return FSGS_ERR_INVALID;
+  hipLaunchKernelGGL(pose_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r, t, num_cams, cam_id, w2c);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_pose_backward(const float *r, int num_cams, int cam_id, const float *dw2c, float *dr, float *dt,
+                       fsgs_stream_t stream) {
+  if (!r || !dw2c || !dr || !dt || num_cams <= 0 || cam_id < 0 || cam_id >= num_cams) return FSGS_ERR_INVALID;
+  hipLaunchKernelGGL(pose_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, r, num_cams, cam_id, dw2c, dr, dt);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+}  // extern "C"

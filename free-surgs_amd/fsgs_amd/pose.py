@@ -30,3 +30,44 @@ def transform_to_frame(means3D, w2c, gaussians_grad=True, camera_grad=True):
     m = w2c if camera_grad else w2c.detach()
     p = means3D if gaussians_grad else means3D.detach()
     return p @ m[:3, :3].T + m[:3, 3]
+
+
+class _PoseToW2C(torch.autograd.Function):
+    """LearnPose.forward as ONE launch forward and ONE backward (csrc/pose.hip)."""
+
+    @staticmethod
+    def forward(ctx, r_param, t_param, cam_id):
+        from . import _lib
+
+        lib = _lib.load()
+        if not r_param.is_cuda:
+            raise RuntimeError("fsgs pose op needs CUDA/HIP tensors; there is no CPU fallback")
+        r = r_param.detach().contiguous().float()
+        t = t_param.detach().contiguous().float()
+        N = int(r.shape[-1])
+        w2c = torch.empty((4, 4), dtype=torch.float32, device=r.device)
+        with torch.cuda.device(r.device):
+            _lib.check(lib.fsgs_pose_forward(_lib.ptr(r), _lib.ptr(t), N, int(cam_id), _lib.ptr(w2c),
+                                             _lib.current_stream()), "fsgs_pose_forward")
+        ctx.save_for_backward(r)
+        ctx.meta = (N, int(cam_id), tuple(r_param.shape), tuple(t_param.shape))
+        return w2c
+
+    @staticmethod
+    def backward(ctx, dw):
+        from . import _lib
+
+        lib = _lib.load()
+        (r,) = ctx.saved_tensors
+        N, cam_id, rs, ts = ctx.meta
+        g = dw.detach().contiguous().float()
+        dr = torch.empty(rs, dtype=torch.float32, device=r.device)
+        dt = torch.empty(ts, dtype=torch.float32, device=r.device)
+        with torch.cuda.device(r.device):
+            _lib.check(lib.fsgs_pose_backward(_lib.ptr(r), N, cam_id, _lib.ptr(g), _lib.ptr(dr), _lib.ptr(dt),
+                                              _lib.current_stream()), "fsgs_pose_backward")
+        return dr, dt, None
+
+
+def pose_to_w2c_hip(r_param, t_param, cam_id):
+    return _PoseToW2C.apply(r_param, t_param, cam_id)

@@ -48,7 +48,12 @@ class PoseTrack:
             self.t[:, i] = torch.as_tensor(t, dtype=torch.float32, device=self.t.device)
 
     def get_pose(self, i):
-        w2c = pose_to_w2c(self.r, self.t, int(i))
+        if self.r.is_cuda:
+            from .pose import pose_to_w2c_hip
+
+            w2c = pose_to_w2c_hip(self.r, self.t, int(i))  # one launch each way (csrc/pose.hip)
+        else:
+            w2c = pose_to_w2c(self.r, self.t, int(i))  # CPU: the torch statement (gloo tests)
         self.pred_w2c[int(i)] = w2c.detach()
         return w2c
 

@@ -214,6 +214,14 @@ int fsgs_flow_pose_loss_backward(int64_t M, const float *pts_world, const int64_
                                  const float *K9_host, const float *flow_fw, int W, int H, float edge,
                                  const double *acc3, const float *upstream, float *dw2c, fsgs_stream_t stream);
 
+/* ---- LearnPose.forward and its adjoint (scene/pose_optimizer.py:822-877) --------------------------------- */
+
+/* r [1,4,N] quaternions (r,x,y,z), t [3,N] translations, cam_id -> w2c [4,4] row-major (all DEVICE). */
+int fsgs_pose_forward(const float *r, const float *t, int num_cams, int cam_id, float *w2c, fsgs_stream_t stream);
+/* dw2c [4,4] -> dr [1,4,N], dt [3,N] (overwritten; zero except column cam_id). */
+int fsgs_pose_backward(const float *r, int num_cams, int cam_id, const float *dw2c, float *dr, float *dt,
+                       fsgs_stream_t stream);
+
 /* ---- optimiser step and densification statistics -------------------------------------------------- */
 
 /* One parameter group of torch.optim.Adam (no weight decay, no amsgrad): all DEVICE pointers of n

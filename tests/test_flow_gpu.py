@@ -74,3 +74,18 @@ def test_flow_loss_empty_and_behind_camera_are_zero():
     flip = torch.diag(torch.tensor([1.0, 1.0, -1.0, 1.0], device=DEV)).requires_grad_(True)  # everything behind
     l = flow.projection_flow_loss(depth, np.eye(4, dtype=np.float32), flip, K, fl, None)
     assert l.item() == 0.0
+
+
+def test_pose_kernels_match_reference_golden():
+    """LearnPose.forward + gradients (csrc/pose.hip) against the vectors captured from the reference."""
+    from fsgs_amd.pose import pose_to_w2c_hip
+
+    g = np.load(os.path.join(G, "pose_glue.npz"))
+    for cam in range(g["r"].shape[2]):
+        r = T(g["r"]).requires_grad_(True)
+        t = T(g["t"]).requires_grad_(True)
+        w2c = pose_to_w2c_hip(r, t, cam)
+        (w2c * T(g["wsum"])).sum().backward()
+        np.testing.assert_allclose(w2c.detach().cpu().numpy(), g[f"w2c_{cam}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r.grad.cpu().numpy(), g[f"dr_{cam}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g[f"dt_{cam}"], rtol=1e-5, atol=1e-7)
