@@ -68,6 +68,7 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   rc = run_binning(cam, P, B, max_pairs, num_rendered, stream);
   if (rc != FSGS_OK) return rc;
   const int2 *ranges = B.ranges;
+  const uint32_t *order = (ntiles <= ORDER_MAX_TILES && *num_rendered > 0) ? B.order : nullptr;
   const uint32_t *plist = B.plist;
   const float2 *xy = B.xy;
   const float4 *co = B.co;
@@ -76,9 +77,9 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   uint32_t *n_contrib = B.n_contrib;
   ProfScope ps_blend(PROF_BLEND_FWD, stream);
   switch (C) {
-    case 1: launch_blend_fwd<1>(cam, ntiles, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
-    case 3: launch_blend_fwd<3>(cam, ntiles, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
-    case 6: launch_blend_fwd<6>(cam, ntiles, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 1: launch_blend_fwd<1>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 3: launch_blend_fwd<3>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 6: launch_blend_fwd<6>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
@@ -108,6 +109,7 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   const float2 *xy = (const float2 *)(sb + SL.xy);
   const float4 *co = (const float4 *)(sb + SL.conic_op);
   const int2 *ranges = (const int2 *)(sb + SL.ranges);
+  const uint32_t *order = (ntiles <= ORDER_MAX_TILES && num_rendered > 0) ? (const uint32_t *)(sb + SL.order) : nullptr;
   const float *final_T = (const float *)(sb + SL.final_T);
   const uint32_t *n_contrib = (const uint32_t *)(sb + SL.n_contrib);
   const uint32_t *plist = (const uint32_t *)(sb + SL.plist);
@@ -117,9 +119,9 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   if (num_rendered > 0) {
     ProfScope ps(PROF_BLEND_BWD, stream);
     switch (C) {
-      case 1: launch_blend_bwd<1>(cam, ntiles, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 3: launch_blend_bwd<3>(cam, ntiles, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 6: launch_blend_bwd<6>(cam, ntiles, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 1: launch_blend_bwd<1>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 3: launch_blend_bwd<3>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 6: launch_blend_bwd<6>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
     }
     FSGS_HIP(hipGetLastError());
   }

@@ -255,6 +255,46 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 
   }
 }
 
+// Longest-processing-time-first dispatch order: workgroup b of the blend kernels takes tile order[b], tiles
+// sorted by descending list length, so the long lists start first and the tail of the launch is made of
+// short ones (5120 tiles on ~4096 wave slots is ~1.25 "rounds"; the second round must be cheap).
+constexpr int ORDER_MAX_TILES = 1 << 20;
+constexpr int ORDER_BINS = 2048;
+// counting sort by (clipped) list length, one workgroup: histogram -> exclusive scan -> scatter (LDS atomics)
+__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const int2 *__restrict__ ranges,
+                                                          uint32_t *__restrict__ order) {
+  __shared__ uint32_t hist[ORDER_BINS];
+  __shared__ uint32_t part[1024];
+  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+    int2 rg = ranges[i];
+    int n = min(rg.y - rg.x, ORDER_BINS - 1);
+    atomicAdd(&hist[ORDER_BINS - 1 - n], 1u);  // bin 0 = longest lists
+  }
+  __syncthreads();
+  // exclusive scan of 2048 bins: 2 per thread + Hillis-Steele over the 1024 partial sums
+  const uint32_t a0 = hist[2 * threadIdx.x], a1 = hist[2 * threadIdx.x + 1];
+  part[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const uint32_t base = part[threadIdx.x] - (a0 + a1);
+  hist[2 * threadIdx.x] = base;
+  hist[2 * threadIdx.x + 1] = base + a0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
+    int2 rg = ranges[i];
+    int n = min(rg.y - rg.x, ORDER_BINS - 1);
+    uint32_t pos = atomicAdd(&hist[ORDER_BINS - 1 - n], 1u);
+    order[pos] = (uint32_t)i;
+  }
+}
+
 // Pixel ownership inside a 16x16 tile: four 8x8 quadrants, lane l owns pixel (l & 7, l >> 3) of each
 // quadrant k = 0..3 at offset (8*(k&1), 8*(k>>1)).  Whether a Gaussian can reach a quadrant at all is a
 // wave-uniform question answered once per pair by its owning lane (rect_touched, exact), carried as a
@@ -289,13 +329,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, 
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
 template <int C, bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
-    CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
-    const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ depth,
-    const float *__restrict__ colors, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-    float *__restrict__ out_color, float *__restrict__ out_color2, float *__restrict__ out_depth) {
+    CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
+    const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
+    const float *__restrict__ depth, const float *__restrict__ colors, float *__restrict__ final_T,
+    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
+    float *__restrict__ out_depth) {
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
   const int lane = threadIdx.x;
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
@@ -391,13 +432,13 @@ constexpr int kAccStride = 8;
 // `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
 template <int C, bool SPLIT>
 __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
-    CamParams cam, int ntiles, const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
-    const float2 *__restrict__ xy, const float4 *__restrict__ conic_op, const float *__restrict__ colors,
-    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+    CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
+    const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
+    const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
     float *__restrict__ dcolors) {
   const int lane = threadIdx.x;
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
   const int W = cam.W, H = cam.H;
   const size_t HW = (size_t)H * W;
@@ -685,7 +726,7 @@ int tile_bits(int ntiles) {
 }
 
 struct StateLayout {
-  size_t xy, conic_op, depth, ranges, final_T, n_contrib, plist, colors, flags, total;
+  size_t xy, conic_op, depth, ranges, order, final_T, n_contrib, plist, colors, flags, total;
 };
 // keep_channels > 0: the fused render also keeps colours[P, keep_channels] and a flag byte per Gaussian
 StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0) {
@@ -696,6 +737,7 @@ StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0
   L.conic_op = c.take(sizeof(float4) * (size_t)P);
   L.depth = c.take(sizeof(float) * (size_t)P);
   L.ranges = c.take(sizeof(int2) * (size_t)ntiles);
+  L.order = c.take(sizeof(uint32_t) * (size_t)ntiles);
   L.final_T = c.take(sizeof(float) * (size_t)W * H);
   L.n_contrib = c.take(sizeof(uint32_t) * (size_t)W * H);
   L.plist = c.take(sizeof(uint32_t) * (size_t)cap);
@@ -725,7 +767,7 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
 }
 
 struct FwdBuffers {
-  float2 *xy; float4 *co; float *depth; int2 *ranges; float *final_T; uint32_t *n_contrib; uint32_t *plist;
+  float2 *xy; float4 *co; float *depth; int2 *ranges; uint32_t *order; float *final_T; uint32_t *n_contrib; uint32_t *plist;
   float *colors; uint32_t *flags;
   uint32_t *tiles; ushort4 *rect; uint32_t *tile_count; uint32_t *total; unsigned long long *keys;
 };
@@ -737,7 +779,7 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   if (state_bytes < SL.total || scratch_bytes < XL.total_bytes) return FSGS_ERR_CAPACITY;
   char *sb = (char *)state, *xb = (char *)scratch;
   B.xy = (float2 *)(sb + SL.xy); B.co = (float4 *)(sb + SL.conic_op); B.depth = (float *)(sb + SL.depth);
-  B.ranges = (int2 *)(sb + SL.ranges); B.final_T = (float *)(sb + SL.final_T);
+  B.ranges = (int2 *)(sb + SL.ranges); B.order = (uint32_t *)(sb + SL.order); B.final_T = (float *)(sb + SL.final_T);
   B.n_contrib = (uint32_t *)(sb + SL.n_contrib); B.plist = (uint32_t *)(sb + SL.plist);
   B.colors = keep_channels ? (float *)(sb + SL.colors) : nullptr;
   B.flags = keep_channels ? (uint32_t *)(sb + SL.flags) : nullptr;
@@ -772,6 +814,8 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
     {
       ProfScope ps(PROF_SORT_TILE, stream);
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist);
+      if (ntiles <= ORDER_MAX_TILES)
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.ranges, B.order);
     }
     FSGS_HIP(hipGetLastError());
   }
@@ -779,18 +823,18 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
 }
 
 template <int C, bool WITH_DEPTH = true>
-int launch_blend_fwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
+int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *depth, const float *colors, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
-  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, ranges, plist, xy,
+  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy,
                      co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
 template <int C, bool SPLIT = false>
-int launch_blend_bwd(const CamParams &cam, int ntiles, const int2 *ranges, const uint32_t *plist, const float2 *xy,
+int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, ranges, plist, xy, co,
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
                      colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
   return 0;
 }

@@ -364,7 +364,7 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (rc != FSGS_OK) return rc;
   {
     ProfScope ps(PROF_BLEND_FWD, stream);
-    launch_blend_fwd<6, false>(cam, ntiles, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T, B.n_contrib,
+    launch_blend_fwd<6, false>(cam, ntiles, (ntiles <= ORDER_MAX_TILES && *num_rendered > 0) ? B.order : nullptr, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T, B.n_contrib,
                                out_image, out_depth_sil, nullptr, stream);
   }
   FSGS_HIP(hipGetLastError());
@@ -401,7 +401,8 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   if (cam_grad) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
   if (num_rendered > 0 && (dL_dimage || dL_ddepth_sil)) {
     ProfScope ps(PROF_BLEND_BWD, stream);
-    launch_blend_bwd<6, true>(cam, ntiles, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
+    launch_blend_bwd<6, true>(cam, ntiles, ntiles <= ORDER_MAX_TILES ? (const uint32_t *)(sb + SL.order) : nullptr,
+                              (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
                               (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),
                               (const float *)(sb + SL.colors), (const float *)(sb + SL.final_T),
                               (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
