@@ -51,7 +51,8 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
 __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
                                                               const float *__restrict__ gt,
                                                               const float *__restrict__ mask,
-                                                              float *__restrict__ maps, double *__restrict__ sums) {
+                                                              float *__restrict__ maps,
+                                                              float *__restrict__ partials) {
   __shared__ float sx[SS_IN][SS_IN + 1];
   __shared__ float sy[SS_IN][SS_IN + 1];
   __shared__ float hz[5][SS_IN][SS_TILE + 1];
@@ -123,17 +124,39 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   float t1 = block_sum_256(l1_acc, red);
   float t2 = block_sum_256(ss_acc, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], (double)t1);
-    atomicAdd(&sums[1], (double)t2);
+    // per-workgroup partials, reduced by the finish kernel: thousands of atomics on two addresses would
+    // serialise in one L2 channel and dominate this (otherwise streaming) kernel
+    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partials[2 * b] = t1;
+    partials[2 * b + 1] = t2;
   }
 }
 
 // loss = (1-l) * L1mean + l * (1 - SSIMmean);  out[0] = loss, out[1] = L1 mean, out[2] = SSIM mean
-__global__ void photometric_finish_kernel(const double *sums, double n, float lambda_dssim, float *out) {
-  double l1 = sums[0] / n, ss = sums[1] / n;
-  out[0] = (float)((1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss));
-  out[1] = (float)l1;
-  out[2] = (float)ss;
+__global__ __launch_bounds__(256) void photometric_finish_kernel(const float *__restrict__ partials, int nblocks,
+                                                                 double n, float lambda_dssim, float *out) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    a += (double)partials[2 * i];
+    b += (double)partials[2 * i + 1];
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double l1 = red[0][0] / n, ss = red[1][0] / n;
+    out[0] = (float)((1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss));
+    out[1] = (float)l1;
+    out[2] = (float)ss;
+  }
 }
 
 // dL/dimg = upstream * [ (1-l)/N sign(x-y) - l/N ( G*dm1 + 2x G*de11 + y G*de12 ) ] * mask
@@ -313,18 +336,25 @@ __global__ __launch_bounds__(256) void pearson_bwd_kernel(int H, int W, int box,
 
 extern "C" {
 
+size_t fsgs_photometric_scratch_bytes(int C, int H, int W) {
+  if (C <= 0 || H <= 0 || W <= 0) return 0;
+  size_t nb = (size_t)((W + SS_TILE - 1) / SS_TILE) * ((H + SS_TILE - 1) / SS_TILE) * C;
+  return nb * 2 * sizeof(float) + 64;
+}
+
 int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const float *gt, const float *mask,
-                                  float lambda_dssim, float *maps, double *sums2, float *out3,
+                                  float lambda_dssim, float *maps, void *sums2, float *out3,
                                   fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3) return FSGS_ERR_INVALID;
-  FSGS_HIP(hipMemsetAsync(sums2, 0, 2 * sizeof(double), stream));
   dim3 grid((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
+  const int nblocks = (int)(grid.x * grid.y * grid.z);
+  float *partials = (float *)sums2;  // caller-sized by fsgs_photometric_scratch_bytes
   {
     ProfScope ps(PROF_LOSS_RGB_FWD, stream);
-    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, maps, sums2);
-    hipLaunchKernelGGL(photometric_finish_kernel, dim3(1), dim3(1), 0, stream, sums2, (double)C * H * W, lambda_dssim,
-                       out3);
+    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, maps, partials);
+    hipLaunchKernelGGL(photometric_finish_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, (double)C * H * W,
+                       lambda_dssim, out3);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

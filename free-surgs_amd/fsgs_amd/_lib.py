@@ -103,6 +103,7 @@ _PROTOTYPES = {
          C.POINTER(FsgsRenderGrads), _vp, _sz, _vp],
     ),
     "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+    "fsgs_photometric_scratch_bytes": (_sz, [_i, _i, _i]),
     "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "fsgs_photometric_loss_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "fsgs_pearson_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

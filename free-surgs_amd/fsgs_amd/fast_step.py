@@ -33,7 +33,8 @@ class _Buffers:
         self.image, self.depth_sil = f(3, H, W), f(3, H, W)
         self.radii = torch.empty((P,), dtype=torch.int32, device=dev)
         self.maps = f(3, 3, H, W)
-        self.sums = torch.empty((2,), dtype=torch.float64, device=dev)
+        self.sums = torch.empty((int(_lib.load().fsgs_photometric_scratch_bytes(3, H, W)),), dtype=torch.uint8,
+                                device=dev)
         self.rgb_out = f(3)
         self.stats = torch.empty((5 * (n_patches + 1),), dtype=torch.float64, device=dev)
         self.coef = f(8 * (n_patches + 1))

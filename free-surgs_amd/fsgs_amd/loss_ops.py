@@ -29,7 +29,7 @@ class _RgbLoss(torch.autograd.Function):
                 raise ValueError("mask must broadcast as [1,H,W] (train.py:175-178)")
             m = m.reshape(H, W)
         maps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=x.device)
-        sums = torch.empty((2,), dtype=torch.float64, device=x.device)
+        sums = torch.empty((int(lib.fsgs_photometric_scratch_bytes(Cc, H, W)),), dtype=torch.uint8, device=x.device)
         out = torch.empty((3,), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = lib.fsgs_photometric_loss_forward(Cc, H, W, _lib.ptr(x), _lib.ptr(y), _lib.ptr(m),
