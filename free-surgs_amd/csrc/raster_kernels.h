@@ -335,6 +335,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
     float *__restrict__ out_depth) {
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
+  constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
+  __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
   const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
@@ -372,15 +374,30 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)g * C + ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
+    // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
+    __syncthreads();  // previous batch fully consumed (single-wave workgroup: this is just a wait)
+    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, gco.x, gco.y);
+    rec[lane * REC4 + 1] = make_float4(gco.z, gco.w, gz, 0.f);
+    {
+      float c6[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ch++) c6[ch] = ch < C ? gcol[ch < C ? ch : 0] : 0.f;
+      rec[lane * REC4 + 2] = make_float4(c6[0], c6[1], c6[2], c6[3]);
+      if (C > 4) rec[lane * REC4 + 3] = make_float4(c6[4], c6[5], c6[6], c6[7]);
+    }
+    __syncthreads();
+    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = C > 4 ? rec[3] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < n; j++) {
+      const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+      if (j + 1 < n) {  // software prefetch of the next record (wave-uniform address)
+        n0 = rec[(j + 1) * REC4 + 0]; n1 = rec[(j + 1) * REC4 + 1]; n2 = rec[(j + 1) * REC4 + 2];
+        if (C > 4) n3 = rec[(j + 1) * REC4 + 3];
+      }
       const uint32_t bm = readlane(gmask, j) & alive;  // scalar
       if (bm == 0) continue;
-      const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
-      const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
-      const float bo = readlane(gco.w, j), bz = WITH_DEPTH ? readlane(gz, j) : 0.f;
-      float bcol[C];
-#pragma unroll
-      for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
+      const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
+      const float bcol8[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         }
         float w = e.alpha * T[k];
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) acc[k][ch] = fmaf(bcol[ch], w, acc[k][ch]);
+        for (int ch = 0; ch < C; ch++) acc[k][ch] = fmaf(bcol8[ch], w, acc[k][ch]);
         if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
         T[k] = test_T;
         last[k] = pos;
@@ -437,6 +454,8 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
     float *__restrict__ dcolors) {
+  constexpr int REC4 = C > 4 ? 4 : 3;
+  __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
   const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
@@ -492,6 +511,16 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    __syncthreads();  // records of the previous batch fully consumed
+    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, gco.x, gco.y);
+    {
+      float c6[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ch++) c6[ch] = ch < C ? gcol[ch < C ? ch : 0] : 0.f;
+      rec[lane * REC4 + 1] = make_float4(gco.z, gco.w, c6[0], c6[1]);
+      rec[lane * REC4 + 2] = make_float4(c6[2], c6[3], c6[4], c6[5]);
+    }
+    __syncthreads();
     for (int jj = n - 1; jj >= 0; jj -= 2) {
       float v[32];
 #pragma unroll
@@ -507,12 +536,10 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
         for (int k = 0; k < 4; k++)
           if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
         if (bm == 0) continue;
-        const float bx = readlane(gxy.x, j), by = readlane(gxy.y, j);
-        const float bA = readlane(gco.x, j), bB = readlane(gco.y, j), bC = readlane(gco.z, j);
-        const float bo = readlane(gco.w, j);
-        float bcol[C];
-#pragma unroll
-        for (int ch = 0; ch < C; ch++) bcol[ch] = readlane(gcol[ch], j);
+        // broadcast reads of record j (same LDS address in every lane)
+        const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
+        const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y;
+        const float bcol[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         float *s = &v[16 * u];
         bool any = false;
 #pragma unroll
