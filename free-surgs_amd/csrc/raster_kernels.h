@@ -20,7 +20,7 @@ using namespace fsgs;
 // device-side parameter block (passed by value)
 // ------------------------------------------------------------------------------------------------
 struct CamParams {
-  int W, H, gx, gy;
+  int W, H, gx, gy, flags;
   float tanfovx, tanfovy, fx, fy, scale_modifier;
   float V[16];
   float PM[16];
@@ -255,42 +255,71 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 
   }
 }
 
-// Longest-processing-time-first dispatch order: workgroup b of the blend kernels takes tile order[b], tiles
-// sorted by descending list length, so the long lists start first and the tail of the launch is made of
-// short ones (5120 tiles on ~4096 wave slots is ~1.25 "rounds"; the second round must be cheap).
+// Dispatch order of the blend kernels: workgroup b takes tile order[b].
+//   * longest-processing-time first: tiles sorted by descending list length, so long lists start first and
+//     the tail of the launch is made of short ones (5120 tiles on ~4096-5120 wave slots is barely more than
+//     one "round"; the stragglers must be cheap);
+//   * XCD-aware: the dispatcher places workgroup b on XCD b % 8 (observed, speed only), and every XCD has its
+//     own L2.  The image is cut into 8 bands of consecutive tiles; band x is sorted on its own and its i-th
+//     longest tile goes to position 8*i + x, so each L2 only ever sees the Gaussians of one band
+//     (without this the longest-first order scatters every XCD over the whole image and the fabric
+//     traffic of the blend kernels triples).
 constexpr int ORDER_MAX_TILES = 1 << 20;
-constexpr int ORDER_BINS = 2048;
-// counting sort by (clipped) list length, one workgroup: histogram -> exclusive scan -> scatter (LDS atomics)
-__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, const int2 *__restrict__ ranges,
+constexpr int ORDER_BINS = 1024;
+constexpr int ORDER_XCD = 8;
+// bands of EQUAL WORK, not equal tile count: ranges[i].x is the prefix sum of the list lengths, so tile i
+// belongs to band floor(8 * start_i / R).  Bands are interleaved round-robin (position 8*rank + band while
+// every band still has tiles, dense afterwards), so the order is a permutation of [0, ntiles).
+// nbands = 1: plain longest-first over the whole image (fastest: 568 vs 624 us for both blend kernels at C2,
+// because in-order dispatch stalls whenever one XCD is momentarily fuller than the others);
+// nbands = 8: XCD-banded (1.7x instead of 3x the algorithmic fabric traffic).  FsgsRasterCfg.flags bit 0.
+__global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands, const int2 *__restrict__ ranges,
                                                           uint32_t *__restrict__ order) {
-  __shared__ uint32_t hist[ORDER_BINS];
-  __shared__ uint32_t part[1024];
-  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x) hist[i] = 0;
+  __shared__ uint32_t hist[ORDER_XCD][ORDER_BINS];
+  __shared__ uint32_t part[ORDER_XCD][128];
+  __shared__ uint32_t band_size[ORDER_XCD];
+  const unsigned long long R = (unsigned long long)max(ranges[ntiles - 1].y, 1);
+  for (int i = threadIdx.x; i < ORDER_XCD * ORDER_BINS; i += blockDim.x) (&hist[0][0])[i] = 0;
+  if (threadIdx.x < ORDER_XCD) band_size[threadIdx.x] = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
     int2 rg = ranges[i];
     int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    atomicAdd(&hist[ORDER_BINS - 1 - n], 1u);  // bin 0 = longest lists
+    int band = (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+    atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // bin 0 = longest lists
+    atomicAdd(&band_size[band], 1u);
   }
   __syncthreads();
-  // exclusive scan of 2048 bins: 2 per thread + Hillis-Steele over the 1024 partial sums
-  const uint32_t a0 = hist[2 * threadIdx.x], a1 = hist[2 * threadIdx.x + 1];
-  part[threadIdx.x] = a0 + a1;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+  {  // exclusive scan of each band's 1024 bins: 128 threads per band, 8 bins each
+    const int band = threadIdx.x >> 7, t = threadIdx.x & 127;
+    uint32_t loc[8], s = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { loc[q] = hist[band][t * 8 + q]; s += loc[q]; }
+    part[band][t] = s;
     __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+    for (int off = 1; off < 128; off <<= 1) {
+      uint32_t v = t >= off ? part[band][t - off] : 0u;
+      __syncthreads();
+      part[band][t] += v;
+      __syncthreads();
+    }
+    uint32_t run = part[band][t] - s;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { hist[band][t * 8 + q] = run; run += loc[q]; }
   }
-  const uint32_t base = part[threadIdx.x] - (a0 + a1);
-  hist[2 * threadIdx.x] = base;
-  hist[2 * threadIdx.x + 1] = base + a0;
   __syncthreads();
   for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
     int2 rg = ranges[i];
     int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    uint32_t pos = atomicAdd(&hist[ORDER_BINS - 1 - n], 1u);
+    int band = (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+    uint32_t rank = atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // rank inside the band, longest first
+    uint32_t pos = 0;
+#pragma unroll
+    for (int b2 = 0; b2 < ORDER_XCD; b2++) {
+      if (b2 >= nbands) break;
+      uint32_t sz = band_size[b2];
+      pos += min(rank, sz) + ((b2 < band && sz > rank) ? 1u : 0u);
+    }
     order[pos] = (uint32_t)i;
   }
 }
@@ -338,8 +367,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
   __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
-  const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= ntiles) return;
+  const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile_u >= (uint32_t)ntiles) return;  // also the 0xFFFFFFFF holes of the banded order
+  const int tile = (int)tile_u;
   const int W = cam.W, H = cam.H;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
   float px[4], py[4];
@@ -457,8 +487,9 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   constexpr int REC4 = C > 4 ? 4 : 3;
   __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
-  const int tile = order ? (int)order[blockIdx.x] : xcd_swizzle(blockIdx.x, gridDim.x);
-  if (tile >= ntiles) return;
+  const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile_u >= (uint32_t)ntiles) return;  // also the 0xFFFFFFFF holes of the banded order
+  const int tile = (int)tile_u;
   const int W = cam.W, H = cam.H;
   const size_t HW = (size_t)H * W;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
@@ -740,6 +771,7 @@ CamParams make_cam(const FsgsRasterCfg *cfg) {
   c.fx = c.W / (2.0f * cfg->tanfovx);
   c.fy = c.H / (2.0f * cfg->tanfovy);
   c.scale_modifier = cfg->scale_modifier;
+  c.flags = cfg->flags;
   memcpy(c.V, cfg->viewmatrix, sizeof(c.V));
   memcpy(c.PM, cfg->projmatrix, sizeof(c.PM));
   memcpy(c.bg, cfg->bg, sizeof(c.bg));
@@ -764,7 +796,7 @@ StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0
   L.conic_op = c.take(sizeof(float4) * (size_t)P);
   L.depth = c.take(sizeof(float) * (size_t)P);
   L.ranges = c.take(sizeof(int2) * (size_t)ntiles);
-  L.order = c.take(sizeof(uint32_t) * (size_t)ntiles);
+  L.order = c.take(sizeof(uint32_t) * ((size_t)ntiles + 16));
   L.final_T = c.take(sizeof(float) * (size_t)W * H);
   L.n_contrib = c.take(sizeof(uint32_t) * (size_t)W * H);
   L.plist = c.take(sizeof(uint32_t) * (size_t)cap);
@@ -842,7 +874,8 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
       ProfScope ps(PROF_SORT_TILE, stream);
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist);
       if (ntiles <= ORDER_MAX_TILES)
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.ranges, B.order);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
+                           (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order);
     }
     FSGS_HIP(hipGetLastError());
   }

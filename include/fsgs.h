@@ -46,6 +46,9 @@ enum {
 };
 
 #define FSGS_MAX_CHANNELS 8
+/* dispatch the blend workgroups XCD-banded (each XCD's L2 sees one band of the image: less fabric traffic)
+ * instead of plain longest-list-first over the whole image (default, ~10 % faster on MI355X) */
+#define FSGS_FLAG_XCD_BANDED_ORDER 1
 
 /* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
  * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
@@ -54,7 +57,7 @@ typedef struct FsgsRasterCfg {
   int32_t image_height;
   int32_t image_width;
   int32_t channels;        /* colour channels of colors_precomp: 1..FSGS_MAX_CHANNELS (reference: 3) */
-  int32_t flags;           /* reserved, 0 */
+  int32_t flags;           /* FSGS_FLAG_* bits, 0 = defaults */
   float tanfovx;
   float tanfovy;
   float scale_modifier;
