@@ -104,3 +104,70 @@ def test_render_side_effects_and_dict_keys():
     assert torch.equal(pc.variables["seen"], pkg["radii"] > 0)
     assert torch.equal(pc.variables["max_radii2D"][pkg["radii"] > 0], pkg["radii"][pkg["radii"] > 0].float())
     assert pc.variables["means2D"] is pkg["viewspace_points"]
+
+
+def test_fused_render_with_a_posed_raster_camera():
+    """pc.cam is the identity for Free-SurGS (first-frame pose), but the op is general: a posed raster camera
+    must agree with the two-pass glue too (incl. the stored-row quirk of the depth pseudo-colour)."""
+    W, H, P = 320, 256, 4000
+    pc, poses = _setup(W, H, P, 1, seed=5)
+    cam = synth.make_camera(W, H, w2c=synth.pose_matrix((1, -0.02, 0.01, 0.02), (0.03, 0.01, -0.02)))
+    pc.cam = settings_from_cam(cam, DEV)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    ref_o, ref_g = _run(render_two_pass, pc, poses, True, True, wi, wd, ws)
+    got_o, got_g = _run(render, pc, poses, True, True, wi, wd, ws)
+    for k in ("render", "render_dep", "sil"):
+        assert_close_flip_aware(got_o[k], ref_o[k], k, floor=1.0, max_frac=2e-3)
+    floor = 1e-3 * max(float(np.abs(ref_g[k]).max()) for k in PARAM_NAMES)
+    for k in PARAM_NAMES:
+        assert_close_flip_aware(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1), k, floor=floor, rows=P, max_frac=2e-3)
+    for k in ("r", "t"):
+        assert np.abs(got_g[k] - ref_g[k]).max() <= 2e-3 * np.abs(ref_g[k]).max() + 1e-9
+
+
+def test_forward_is_bitwise_deterministic_and_reentrant_across_threads():
+    """the forward has no order-dependent float arithmetic (the binning atomics only claim slots; the per-tile
+    sort fixes the order), so repeated and concurrent calls must agree bit for bit; the library keeps no state
+    between calls (trainer + viewer threads, train.py:150,166-200)."""
+    import threading
+
+    W, H, P = 320, 256, 5000
+    pc, poses = _setup(W, H, P, 2, seed=7)
+    with torch.no_grad():
+        a = render(poses, 1, pc, gs_grad=False, cam_grad=False)
+        b = render(poses, 1, pc, gs_grad=False, cam_grad=False)
+    assert torch.equal(a["render"], b["render"]) and torch.equal(a["render_dep"], b["render_dep"])
+    assert torch.equal(a["radii"], b["radii"])
+    out = {}
+
+    def work(name):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(4):
+                out[name] = render(poses, 1, pc, gs_grad=False, cam_grad=False)["render"].clone()
+        s.synchronize()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert torch.equal(out[0], a["render"]) and torch.equal(out[1], a["render"])
+
+
+def test_fused_render_empty_and_fully_culled_cloud():
+    W, H = 160, 128
+    cam = synth.make_camera(W, H)
+    sc = synth.init_scene(W, H, 500, seed=0)
+    sc = dict(sc)
+    sc["_xyz"] = sc["_xyz"].copy()
+    sc["_xyz"][:, 2] = -1.0  # everything behind the camera
+    pc = GaussianCloud(sc, sh_degree=3, device=DEV)
+    pc.cam = settings_from_cam(cam, DEV)
+    poses = PoseTrack(1, DEV)
+    pkg = render(poses, 0, pc, gs_grad=True, cam_grad=True)
+    assert bool((pkg["render"] == 1).all()) and int(pkg["radii"].sum()) == 0
+    (pkg["render"].sum() + pkg["render_dep"].sum()).backward()
+    assert all(float(pc.params[k].grad.abs().sum()) == 0.0 for k in PARAM_NAMES)
+    assert float(poses.r.grad.abs().sum()) == 0.0
