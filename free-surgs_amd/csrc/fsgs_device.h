@@ -128,6 +128,24 @@ __device__ __forceinline__ bool splat_alpha(float gx, float gy, float A, float B
   return e.alpha >= (1.0f / 255.0f);
 }
 
+// Branch-free variant for the backward replay: returns G and alpha forced to ZERO when the pair does not
+// contribute (power > 0, alpha < 1/255 or `live` false).  The skip decision is bit-identical to splat_alpha;
+// with alpha = G = 0 every gradient term of the pair vanishes and T / gB stay untouched, so no divergent
+// branch (v_cmp -> exec round trips cost ~10 cycles each on gfx950) is needed around the arithmetic.
+__device__ __forceinline__ bool splat_alpha_masked(float gx, float gy, float A, float B, float Cc, float o, float px,
+                                                   float py, bool live, SplatEval &e) {
+  e.dx = __fsub_rn(gx, px);
+  e.dy = __fsub_rn(gy, py);
+  float q = __fmaf_rn(__fmul_rn(Cc, e.dy), e.dy, __fmul_rn(__fmul_rn(A, e.dx), e.dx));
+  float power = __fmaf_rn(__fmul_rn(-B, e.dx), e.dy, __fmul_rn(-0.5f, q));
+  float G = __expf(fminf(power, 0.0f));
+  float alpha = fminf(0.99f, __fmul_rn(o, G));
+  const bool ok = live && !(power > 0.0f) && alpha >= (1.0f / 255.0f);
+  e.G = ok ? G : 0.0f;
+  e.alpha = ok ? alpha : 0.0f;
+  return ok;
+}
+
 // ---- exact footprint culling ---------------------------------------------------------------------------
 // A Gaussian contributes to a pixel only if alpha = o*exp(-q) >= 1/255, i.e. q(d) <= tau = ln(255 o)
 // with q(d) = 1/2 (A dx^2 + C dy^2) + B dx dy, d = centre - pixel (splat_alpha above).  A rectangle of

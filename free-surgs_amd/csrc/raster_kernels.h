@@ -576,10 +576,8 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (!((bm >> k) & 1u)) continue;  // wave-uniform
-          if (pos >= last[k]) continue;
-          SplatEval e;
-          if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
-          any = true;
+          SplatEval e;  // alpha = G = 0 for lanes that do not contribute: the arithmetic below is a no-op for them
+          any |= splat_alpha_masked(bx, by, bA, bB, bC, bo, px[k], py[k], pos < last[k], e);
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
           T[k] = T[k] * inv1ma;
           const float wgt = e.alpha * T[k];
