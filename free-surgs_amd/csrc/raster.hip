@@ -128,7 +128,7 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   {
     ProfScope ps(PROF_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, scales,
-                       rotations, radii, grad_acc, dmeans2D, dopacities, dmeans3D, dscales, drotations);
+                       rotations, radii, co, grad_acc, dmeans2D, dopacities, dmeans3D, dscales, drotations);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

@@ -470,9 +470,24 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // R7  backward blend
 // ------------------------------------------------------------------------------------------------
-// grad_acc layout per Gaussian (floats): [0,1] dmean2D x,y (pixel units), [2,3,4] dconic A,B,C (true
-// partials), [5] dopacity  -> 8 floats stride;  dcolors go straight to the output tensor.
+// grad_acc layout per Gaussian (floats), with w = G dL/dalpha summed over every pixel the Gaussian blended into and
+// d = mean2D - pixel:  [0,1] sum w d_x, w d_y | [2,3,4] sum w d_x^2, w d_x d_y, w d_y^2 | [5] sum w (= dL/dopacity)
+// | [6,7] as [0,1] for the RGB channels only (SPLIT).  8 floats stride; dcolors go straight to the output tensor.
 constexpr int kAccStride = 8;
+
+// Moments -> the gradients of SURVEY.md A.4: dL/dmean2D (pixel units) = -o (A m0 + B m1, C m1 + B m0),
+// dL/dconic (A,B,C) = -o (m2/2, m3, m4/2), dL/dopacity = m5; [6,7] the RGB-only dL/dmean2D.
+__device__ __forceinline__ void unpack_moments(const float *m, float4 co, float ga[8]) {
+  const float A = co.x, B = co.y, Cc = co.z, no = -co.w;
+  ga[0] = no * fmaf(A, m[0], B * m[1]);
+  ga[1] = no * fmaf(Cc, m[1], B * m[0]);
+  ga[2] = 0.5f * no * m[2];
+  ga[3] = no * m[3];
+  ga[4] = 0.5f * no * m[4];
+  ga[5] = m[5];
+  ga[6] = no * fmaf(A, m[6], B * m[7]);
+  ga[7] = no * fmaf(Cc, m[7], B * m[6]);
+}
 
 // SPLIT (fused 6-channel pass): channels 0..2 are the RGB pass, 3..5 the depth/silhouette pass of the
 // reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
@@ -590,22 +605,22 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
           }
           const float dL_dalpha = fmaf(T[k], gc, -inv1ma * (gB[k] + tb[k]));
           gB[k] = fmaf(wgt, gc, gB[k]);
-          const float dL_dG = bo * dL_dalpha;
-          const float gdx = e.G * e.dx, gdy = e.G * e.dy;
-          const float dG_ddx = -gdx * bA - gdy * bB;
-          const float dG_ddy = -gdy * bC - gdx * bB;
-          s[0] = fmaf(dL_dG, dG_ddx, s[0]);
-          s[1] = fmaf(dL_dG, dG_ddy, s[1]);
+          // moments of w = G dL/dalpha over the pixels; the conic / opacity factors are per-Gaussian constants
+          // and are applied once, after the tile and atomic sums, by unpack_moments()
+          const float w = e.G * dL_dalpha;
+          const float wdx = w * e.dx, wdy = w * e.dy;
+          s[5] += w;
+          s[0] += wdx;
+          s[1] += wdy;
+          s[2] = fmaf(wdx, e.dx, s[2]);
+          s[3] = fmaf(wdx, e.dy, s[3]);
+          s[4] = fmaf(wdy, e.dy, s[4]);
           if (SPLIT) {
-            const float dG_rgb = bo * fmaf(T[k], gc_rgb, -inv1ma * (gBr[k] + tbr[k]));
+            const float wr = e.G * fmaf(T[k], gc_rgb, -inv1ma * (gBr[k] + tbr[k]));
             gBr[k] = fmaf(wgt, gc_rgb, gBr[k]);
-            s[6] = fmaf(dG_rgb, dG_ddx, s[6]);
-            s[7] = fmaf(dG_rgb, dG_ddy, s[7]);
+            s[6] = fmaf(wr, e.dx, s[6]);
+            s[7] = fmaf(wr, e.dy, s[7]);
           }
-          s[2] = fmaf(-0.5f * gdx * e.dx, dL_dG, s[2]);
-          s[3] = fmaf(-gdx * e.dy, dL_dG, s[3]);
-          s[4] = fmaf(-0.5f * gdy * e.dy, dL_dG, s[4]);
-          s[5] = fmaf(e.G, dL_dalpha, s[5]);
         }
         any_group = any_group || (__ballot(any) != 0ull);
       }
@@ -634,8 +649,8 @@ struct GeomGrad {
   float ds[3];     // dL/d(activated scale)
   float dq[4];     // dL/d(quaternion as handed over)
 };
-// ga: the 8-float accumulator row of this Gaussian written by blend_bwd (pixel-unit mean2D, true conic
-// partials, opacity).  Only call for radii > 0.
+// ga: the unpacked accumulator row of this Gaussian (unpack_moments: pixel-unit mean2D, true conic partials,
+// opacity).  Only call for radii > 0.
 __device__ __forceinline__ GeomGrad geom_backward(const CamParams &cam, float mx, float my, float mz, float3 s_in,
                                                   float4 q, const float *ga) {
   GeomGrad out;
@@ -732,8 +747,8 @@ __device__ __forceinline__ GeomGrad geom_backward(const CamParams &cam, float mx
 
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     int P, CamParams cam, const float *__restrict__ means3D, const float *__restrict__ scales,
-    const float *__restrict__ rots, const int32_t *__restrict__ radii, const float *__restrict__ grad_acc,
-    float *__restrict__ dmeans2D, float *__restrict__ dopac, float *__restrict__ dmeans3D,
+    const float *__restrict__ rots, const int32_t *__restrict__ radii, const float4 *__restrict__ conic_op,
+    const float *__restrict__ grad_acc, float *__restrict__ dmeans2D, float *__restrict__ dopac, float *__restrict__ dmeans3D,
     float *__restrict__ dscales, float *__restrict__ drots) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
@@ -745,8 +760,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
   if (radii[i] > 0) {
     float3 s = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
     float4 q = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
-    r = geom_backward(cam, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], s, q,
-                      grad_acc + (size_t)i * kAccStride);
+    float ga[8];
+    unpack_moments(grad_acc + (size_t)i * kAccStride, conic_op[i], ga);
+    r = geom_backward(cam, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], s, q, ga);
   }
   dmeans2D[3 * i] = r.m2x; dmeans2D[3 * i + 1] = r.m2y; dmeans2D[3 * i + 2] = 0.f;
   dopac[i] = r.dop;

@@ -181,6 +181,7 @@ constexpr int MODE_PARAM_GRAD = 4;  // gradients of features / opacity / scaling
 
 __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
+                                                             const float4 *__restrict__ conic_op,
                                                              const float *__restrict__ grad_acc,
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
   float m2x = 0.f, m2y = 0.f;
   if (live) {
     Activated act = activate(a, i);
-    const float *ga = grad_acc + (size_t)i * kAccStride;
+    float ga[8];
+    unpack_moments(grad_acc + (size_t)i * kAccStride, conic_op[i], ga);
     GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
     m2x = ga[6] * (0.5f * cam.W);
     m2y = ga[7] * (0.5f * cam.H);
@@ -415,7 +417,7 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     hipLaunchKernelGGL(render_pre_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), radii,
-                       grad_acc, dcolors6, (const uint32_t *)(sb + SL.flags), mode, out);
+                       (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6, (const uint32_t *)(sb + SL.flags), mode, out);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
