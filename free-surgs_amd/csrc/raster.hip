@@ -57,7 +57,6 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   FwdBuffers B;
   int rc = bind_forward_buffers(P, W, H, max_pairs, 0, state, state_bytes, scratch, scratch_bytes, B);
   if (rc != FSGS_OK) return rc;
-  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles, stream));
   if (P > 0) {
     ProfScope ps(PROF_PREPROCESS_FWD, stream);
     GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};

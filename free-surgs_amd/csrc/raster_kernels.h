@@ -100,11 +100,16 @@ struct GeomOut {  // per-Gaussian arrays written by every preprocess kernel
   int32_t *radii;
   uint32_t *tiles;
   ushort4 *rect;
-  uint32_t *tile_count;  // [tiles] histogram of the binning count pass (zeroed by the host)
+  uint32_t *tile_count;  // [tiles * BIN_SUBS] histogram of the binning count pass (zeroed by the host)
   int gx;
 };
-// also the COUNT pass of the binning: the values are in registers here, so the per-tile histogram is
-// built without a second sweep over the Gaussians
+// Same-address atomics serialise at ~46 ns each on MI355X (profiles/r01_atomic_scope_ubench.txt): the longest tile
+// list alone would cost > 100 us per binning pass.  Every tile therefore owns BIN_SUBS counters / cursors, picked by
+// the Gaussian index, and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
+// (depth, index) order anyway).
+constexpr int BIN_SUBS = 8;
+__device__ __forceinline__ int bin_slot(int tile, int gaussian) { return tile * BIN_SUBS + (gaussian & (BIN_SUBS - 1)); }
+
 __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const Projected &o) {
   g.radii[i] = o.radius;
   g.tiles[i] = o.ntile;
@@ -112,13 +117,6 @@ __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const P
   g.xy[i] = o.xy;
   g.conic_op[i] = o.conic_op;
   g.depth[i] = o.tz;
-  if (o.ntile == 0) return;
-  const float tau = footprint_tau(o.conic_op.w);
-  for (int y = o.rect.y; y < o.rect.w; y++)
-    for (int x = o.rect.x; x < o.rect.z; x++)
-      if (rect_touched(o.xy.x, o.xy.y, o.conic_op.x, o.conic_op.y, o.conic_op.z, tau, (float)(x * FSGS_TILE),
-                       (float)(y * FSGS_TILE), (float)FSGS_TILE, (float)FSGS_TILE))
-        atomicAdd(&g.tile_count[y * g.gx + x], 1u);
 }
 
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams cam, const float *__restrict__ means3D,
@@ -146,6 +144,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams ca
 // The resulting order inside a tile is (depth, index) ascending = UPSTREAM's order including ties,
 // independent of the order in which the atomics landed.
 // ------------------------------------------------------------------------------------------------
+// Count and scatter share one walker.  A thread-per-Gaussian loop over the tile rect is bound by the LARGEST rect
+// of the launch (one lane walks it alone, and in the scatter pass every step waits for a returning atomic), so
+// the (Gaussian, tile) candidates of the 64 Gaussians of a wave are flattened instead: an inclusive scan of the
+// rect areas, then lane l of step s takes candidate 64*s + l, finds its Gaussian by binary search in LDS and
+// tests that one tile.  BIN_UNROLL candidates per lane keep several atomics in flight.
+constexpr int BIN_UNROLL = 4;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uint32_t *__restrict__ tiles,
                                                         const ushort4 *__restrict__ rect,
@@ -153,35 +157,85 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
                                                         const float4 *__restrict__ conic_op,
                                                         const float *__restrict__ depth,
                                                         uint32_t *__restrict__ tile_count,
-                                                        const int2 *__restrict__ ranges,
                                                         unsigned long long *__restrict__ keys) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  if (tiles[i] == 0) return;
-  const ushort4 rc = rect[i];
-  const float2 p = xy[i];
-  const float4 co = conic_op[i];
-  const float tau = footprint_tau(co.w);
-  const unsigned long long key = ((unsigned long long)__float_as_uint(SCATTER ? depth[i] : 0.f) << 32) | (uint32_t)i;
-  for (int y = rc.y; y < rc.w; y++)
-    for (int x = rc.x; x < rc.z; x++) {
-      if (!rect_touched(p.x, p.y, co.x, co.y, co.z, tau, (float)(x * FSGS_TILE), (float)(y * FSGS_TILE),
-                        (float)FSGS_TILE, (float)FSGS_TILE))
-        continue;
-      const int t = y * gx + x;
-      const uint32_t slot = atomicAdd(&tile_count[t], 1u);  // count pass: histogram; scatter pass: cursor
-      if (SCATTER) keys[(size_t)ranges[t].x + slot] = key;
+  __shared__ float4 rec_a[256];  // mean2D x,y | conic A,B
+  __shared__ float4 rec_b[256];  // conic C | tau | depth bits | Gaussian index
+  __shared__ uint4 rec_c[256];   // rect x0,y0 | width | ceil(2^32 / width)
+  __shared__ uint32_t pre[256];  // inclusive scan of the rect areas, per wave
+  const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t area = 0;
+  if (i < P && tiles[i] != 0) {
+    const ushort4 rc = rect[i];
+    const float2 p = xy[i];
+    const float4 co = conic_op[i];
+    const float tau = footprint_tau(co.w);
+    const uint32_t w = (uint32_t)(rc.z - rc.x), h = (uint32_t)(rc.w - rc.y);
+    if (tau >= 0.f) area = w * h;
+    rec_a[threadIdx.x] = make_float4(p.x, p.y, co.x, co.y);
+    rec_b[threadIdx.x] = make_float4(co.z, tau, SCATTER ? depth[i] : 0.f, __uint_as_float((uint32_t)i));
+    rec_c[threadIdx.x] = make_uint4(rc.x, rc.y, w, w > 1 ? 0xFFFFFFFFu / w + 1u : 0u);
+  }
+  uint32_t incl = area;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  pre[threadIdx.x] = incl;
+  const uint32_t total = (uint32_t)readlane((int)incl, 63);
+  __syncthreads();
+  for (uint32_t base = 0; base < total; base += 64 * BIN_UNROLL) {
+    uint32_t slot[BIN_UNROLL], klo[BIN_UNROLL], khi[BIN_UNROLL];
+    bool hit[BIN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) {
+      const uint32_t item = base + (uint32_t)(u * 64 + lane);
+      hit[u] = false;
+      if (item < total) {
+        int own = 0;  // number of lanes whose inclusive prefix is <= item  ==  the owning lane
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (pre[wbase + own + step - 1] <= item) own += step;
+        const uint32_t local = item - (own ? pre[wbase + own - 1] : 0u);
+        const float4 a = rec_a[wbase + own], b = rec_b[wbase + own];
+        const uint4 c = rec_c[wbase + own];
+        const uint32_t ry = c.z > 1 ? __umulhi(local, c.w) : local;  // local / width (exact: local * width < 2^32)
+        const uint32_t rx = local - ry * c.z;
+        const int tx = (int)(c.x + rx), ty = (int)(c.y + ry);
+        if (rect_touched(a.x, a.y, a.z, a.w, b.x, b.y, (float)(tx * FSGS_TILE), (float)(ty * FSGS_TILE),
+                         (float)FSGS_TILE, (float)FSGS_TILE)) {
+          hit[u] = true;
+          klo[u] = __float_as_uint(b.w);
+          khi[u] = __float_as_uint(b.z);
+          // count pass: histogram; scatter pass: the scan left each sub-list's absolute start in its cursor
+          slot[u] = atomicAdd(&tile_count[bin_slot(ty * gx + tx, (int)klo[u])], 1u);
+        }
+      }
     }
+    if (SCATTER) {
+#pragma unroll
+      for (int u = 0; u < BIN_UNROLL; u++)
+        if (hit[u]) keys[slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
+    }
+  }
 }
 
-// single workgroup: exclusive scan of tile_count -> ranges, total -> *total_out, cursors reset to zero
+// single workgroup: exclusive scan of the sub-list counts -> tile ranges, total -> *total_out; every counter is
+// replaced by the absolute start of its sub-list (the scatter cursor)
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *__restrict__ tile_count,
                                                           int2 *__restrict__ ranges, uint32_t *__restrict__ total_out) {
+  static_assert(BIN_SUBS == 8, "two uint4 per tile");
   __shared__ uint32_t part[1024];
   const int per = (ntiles + 1023) / 1024;
   const int t0 = threadIdx.x * per;
+  uint4 *tc4 = reinterpret_cast<uint4 *>(tile_count);
   uint32_t s = 0;
-  for (int k = 0; k < per; k++) s += (t0 + k < ntiles) ? tile_count[t0 + k] : 0u;
+  for (int k = 0; k < per; k++)
+    if (t0 + k < ntiles) {
+      const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
+      s += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    }
   part[threadIdx.x] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -193,10 +247,14 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *
   uint32_t run = part[threadIdx.x] - s;
   for (int k = 0; k < per; k++) {
     if (t0 + k < ntiles) {
-      uint32_t c = tile_count[t0 + k];
-      ranges[t0 + k] = make_int2((int)run, (int)(run + c));
-      tile_count[t0 + k] = 0;  // becomes the scatter cursor
-      run += c;
+      const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
+      const uint32_t start = run;
+      uint4 sa, sb;
+      sa.x = run; run += a.x; sa.y = run; run += a.y; sa.z = run; run += a.z; sa.w = run; run += a.w;
+      sb.x = run; run += b.x; sb.y = run; run += b.y; sb.z = run; run += b.z; sb.w = run; run += b.w;
+      tc4[2 * (t0 + k)] = sa;
+      tc4[2 * (t0 + k) + 1] = sb;
+      ranges[t0 + k] = make_int2((int)start, (int)run);
     }
   }
   if (threadIdx.x == 1023) *total_out = part[1023];
@@ -832,7 +890,7 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
   size_t ntiles = (size_t)((W + FSGS_TILE - 1) / FSGS_TILE) * ((H + FSGS_TILE - 1) / FSGS_TILE);
   L.tiles = c.take(4 * Pn);
   L.rect = c.take(8 * Pn);
-  L.tile_count = c.take(4 * ntiles);
+  L.tile_count = c.take(4 * (size_t)ntiles * BIN_SUBS);
   L.total = c.take(16);
   L.keys = c.take(8 * Rn);
   L.total_bytes = c.total();
@@ -869,6 +927,12 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
   const int ntiles = cam.gx * cam.gy;
   if (ntiles > 1024 * 64) return FSGS_ERR_INVALID;
   uint32_t R = 0;
+  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles * BIN_SUBS, stream));
+  if (P > 0) {
+    ProfScope ps(PROF_EMIT, stream);  // count pass
+    hipLaunchKernelGGL((bin_pairs_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
+                       B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys);
+  }
   {
     ProfScope ps(PROF_SCAN, stream);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
@@ -882,7 +946,7 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
     {
       ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
       hipLaunchKernelGGL((bin_pairs_kernel<true>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
-                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.ranges, B.keys);
+                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys);
     }
     {
       ProfScope ps(PROF_SORT_TILE, stream);
