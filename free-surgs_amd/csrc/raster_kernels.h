@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
 
 // single workgroup: exclusive scan of the sub-list counts -> tile ranges, total -> *total_out; every counter is
 // replaced by the absolute start of its sub-list (the scatter cursor)
+template <int PER>  // PER > 0: at most PER tiles per thread, counters held in registers between the two sweeps
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *__restrict__ tile_count,
                                                           int2 *__restrict__ ranges, uint32_t *__restrict__ total_out) {
   static_assert(BIN_SUBS == 8, "two uint4 per tile");
@@ -230,34 +231,64 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *
   const int per = (ntiles + 1023) / 1024;
   const int t0 = threadIdx.x * per;
   uint4 *tc4 = reinterpret_cast<uint4 *>(tile_count);
+  constexpr int NR = PER > 0 ? PER : 1;
+  uint4 ra[NR], rb[NR];
   uint32_t s = 0;
-  for (int k = 0; k < per; k++)
-    if (t0 + k < ntiles) {
-      const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
-      s += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  if (PER > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; k++) {  // unconditional, independent loads (clamped index), masked afterwards
+      const int t = min(t0 + k, ntiles - 1);
+      ra[k] = tc4[2 * t];
+      rb[k] = tc4[2 * t + 1];
     }
-  part[threadIdx.x] = s;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      if (!(k < per && t0 + k < ntiles)) ra[k] = rb[k] = make_uint4(0, 0, 0, 0);
+      s += ra[k].x + ra[k].y + ra[k].z + ra[k].w + rb[k].x + rb[k].y + rb[k].z + rb[k].w;
+    }
+  } else {
+    for (int k = 0; k < per; k++)
+      if (t0 + k < ntiles) {
+        const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
+        s += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+      }
+  }
+  // workgroup exclusive scan of the 1024 per-thread sums: wave scan, then the 16 wave totals
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) part[wv] = incl;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  uint32_t wave_base = 0, grand = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const uint32_t v = part[w];
+    if (w < wv) wave_base += v;
+    grand += v;
   }
-  uint32_t run = part[threadIdx.x] - s;
-  for (int k = 0; k < per; k++) {
-    if (t0 + k < ntiles) {
-      const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
-      const uint32_t start = run;
-      uint4 sa, sb;
-      sa.x = run; run += a.x; sa.y = run; run += a.y; sa.z = run; run += a.z; sa.w = run; run += a.w;
-      sb.x = run; run += b.x; sb.y = run; run += b.y; sb.z = run; run += b.z; sb.w = run; run += b.w;
-      tc4[2 * (t0 + k)] = sa;
-      tc4[2 * (t0 + k) + 1] = sb;
-      ranges[t0 + k] = make_int2((int)start, (int)run);
-    }
+  uint32_t run = wave_base + incl - s;
+  auto emit = [&](int tile, const uint4 a, const uint4 b) {
+    const uint32_t start = run;
+    uint4 sa, sb;
+    sa.x = run; run += a.x; sa.y = run; run += a.y; sa.z = run; run += a.z; sa.w = run; run += a.w;
+    sb.x = run; run += b.x; sb.y = run; run += b.y; sb.z = run; run += b.z; sb.w = run; run += b.w;
+    tc4[2 * tile] = sa;
+    tc4[2 * tile + 1] = sb;
+    ranges[tile] = make_int2((int)start, (int)run);
+  };
+  if (PER > 0) {
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+      if (k < per && t0 + k < ntiles) emit(t0 + k, ra[k], rb[k]);
+  } else {
+    for (int k = 0; k < per; k++)
+      if (t0 + k < ntiles) emit(t0 + k, tc4[2 * (t0 + k)], tc4[2 * (t0 + k) + 1]);
   }
-  if (threadIdx.x == 1023) *total_out = part[1023];
+  if (threadIdx.x == 0) *total_out = grand;
 }
 
 constexpr int SORT_LDS_KEYS = 2048;  // 16 KB of LDS per workgroup; longer lists sort in global memory
@@ -935,7 +966,10 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
   }
   {
     ProfScope ps(PROF_SCAN, stream);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
+    if (ntiles <= 8 * 1024)
+      hipLaunchKernelGGL(scan_tiles_kernel<8>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
+    else
+      hipLaunchKernelGGL(scan_tiles_kernel<0>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
   }
   FSGS_HIP(hipGetLastError());
   FSGS_HIP(hipMemcpyAsync(&R, B.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -236,3 +236,25 @@ def test_heavy_tile_takes_the_global_memory_sort_path(oracle32):
     op = rng.uniform(0.01, 0.05, n).astype(np.float32)
     col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
     _compare(oracle32, cam, xyz, col, op, s, rot)
+
+
+def test_large_grid_and_screen_filling_gaussians(oracle32):
+    """2304x1040 = 144x65 = 9360 tiles (> 8192: the generic tile-scan path) with a few Gaussians whose 3-sigma
+    rect spans the whole grid next to many small ones: the flattened binning walker hands one Gaussian's
+    thousands of candidate tiles to all the lanes of its wave."""
+    cam = synth.make_camera(2304, 1040)
+    K = cam["K"]
+    rng = np.random.default_rng(11)
+    n_small, n_big = 600, 3
+    z = rng.uniform(0.6, 1.4, n_small + n_big)
+    u = rng.uniform(0, 2304, n_small + n_big)
+    v = rng.uniform(0, 1040, n_small + n_big)
+    xyz = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1).astype(np.float32)
+    sig_px = np.concatenate([rng.uniform(1.0, 12.0, n_small), [500.0, 350.0, 800.0]])
+    s = (sig_px[:, None] * rng.uniform(0.5, 1.0, (n_small + n_big, 3)) * z[:, None] / K[0, 0]).astype(np.float32)
+    q = rng.normal(size=(n_small + n_big, 4))
+    rot = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    op = np.concatenate([rng.uniform(0.05, 0.9, n_small), [0.3, 0.02, 0.6]]).astype(np.float32)
+    col = rng.uniform(0, 1, (n_small + n_big, 3)).astype(np.float32)
+    R = _compare(oracle32, cam, xyz, col, op, s, rot)
+    assert R > 9360  # the big ones alone reach most tiles
