@@ -1,6 +1,7 @@
 // common.hip -- version string and error plumbing of libfsgs_hip.so
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +19,50 @@ int fsgs_fail_hip(hipError_t e, const char *expr, const char *file, int line) {
   snprintf(g_err, sizeof(g_err), "%s -> %s (%s:%d)", expr, hipGetErrorString(e), file, line);
   (void)hipGetLastError();
   return FSGS_ERR_HIP;
+}
+
+// ---- mailbox ----------------------------------------------------------------------------------
+static std::once_flag g_mail_once;
+static uint32_t *g_mail_base = nullptr;
+static std::atomic<uint32_t> g_mail_next{0};
+constexpr int kMailSlots = 256, kMailStride = 16;  // one 64-byte line per slot
+volatile uint32_t *mailbox_acquire() {
+  std::call_once(g_mail_once, [] {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, sizeof(uint32_t) * kMailSlots * kMailStride,
+                      hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
+      g_mail_base = (uint32_t *)p;
+    else
+      (void)hipGetLastError();
+  });
+  if (!g_mail_base) return nullptr;
+  volatile uint32_t *slot = g_mail_base + (size_t)(g_mail_next.fetch_add(1) % kMailSlots) * kMailStride;
+  *slot = kMailboxEmpty;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  return slot;
+}
+bool mailbox_wait(volatile uint32_t *slot, hipStream_t stream, uint32_t *value) {
+  for (unsigned spins = 0;; spins++) {
+    const uint32_t v = *slot;
+    if (v != kMailboxEmpty) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      *value = v;
+      return true;
+    }
+    if ((spins & 0x3FFF) == 0x3FFF) {  // every few tens of microseconds: is the stream still working on it?
+      const hipError_t q = hipStreamQuery(stream);
+      if (q != hipErrorNotReady) {
+        (void)hipGetLastError();
+        const uint32_t v2 = *slot;  // finished (or failed) -- the store, if any, has landed
+        if (v2 != kMailboxEmpty) {
+          *value = v2;
+          return true;
+        }
+        return false;
+      }
+    }
+    __builtin_ia32_pause();
+  }
 }
 
 // ---- profiler ---------------------------------------------------------------------------------

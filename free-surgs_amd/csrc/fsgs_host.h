@@ -24,6 +24,19 @@ struct Carver {
   size_t total() const { return off + 256; }
 };
 
+// ---- device -> host mailbox ---------------------------------------------------------------------
+// The forward needs ONE number back from the device per call (R, the number of tile pairs).  A D2H copy plus
+// hipStreamSynchronize leaves the GPU idle for ~40 us (interrupt wake-up + the launches that follow).  Instead
+// the scan kernel stores R with system scope into a pinned, coherent host word; the host enqueues every
+// R-independent launch first and then polls that word.  Slots are handed out round-robin so concurrent calls
+// (trainer + viewer thread) never share one.  acquire() returns nullptr if pinned memory is unavailable, and
+// the caller falls back to copy + synchronize.
+constexpr uint32_t kMailboxEmpty = 0xFFFFFFFFu;
+volatile uint32_t *mailbox_acquire();
+// spins until *slot != kMailboxEmpty; gives up (returns false) when the stream reports an error or is idle
+// without the slot having been written
+bool mailbox_wait(volatile uint32_t *slot, hipStream_t stream, uint32_t *value);
+
 // ---- optional per-kernel timing with HIP events on the launching stream (bench.py roofline) ----
 enum ProfId {
   PROF_PREPROCESS_FWD = 0,

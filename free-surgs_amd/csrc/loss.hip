@@ -25,6 +25,7 @@ namespace {
 constexpr int SS_TILE = 32;            // output tile edge
 constexpr int SS_HALO = 5;             // 11-tap window
 constexpr int SS_IN = SS_TILE + 2 * SS_HALO;  // 42
+constexpr int SS_BLK = 4;              // outputs per thread along the filtered axis
 constexpr float SS_C1 = 0.01f * 0.01f;
 constexpr float SS_C2 = 0.03f * 0.03f;
 
@@ -75,51 +76,77 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
     sy[ly][lx] = b;
   }
   __syncthreads();
-  // horizontal 11-tap pass of the five moments
-  for (int i = threadIdx.x; i < SS_IN * SS_TILE; i += 256) {
-    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  // Both 11-tap passes are register-blocked: a thread produces SS_BLK consecutive outputs from SS_BLK + 10 inputs
+  // it reads once (3.5 LDS reads per output and map instead of 11).  Every output still accumulates its taps in
+  // the order k = 0..10.
+  // horizontal pass of the five moments: SS_IN rows x (SS_TILE / SS_BLK) segments
+  for (int task = threadIdx.x; task < SS_IN * (SS_TILE / SS_BLK); task += 256) {
+    const int ly = task / (SS_TILE / SS_BLK), lx = (task - ly * (SS_TILE / SS_BLK)) * SS_BLK;
+    float a[SS_BLK + 10], b[SS_BLK + 10], aa[SS_BLK + 10], bb[SS_BLK + 10], ab[SS_BLK + 10];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      float g = kGauss[k], a = sx[ly][lx + k], b = sy[ly][lx + k];
-      m1 = fmaf(g, a, m1);
-      m2 = fmaf(g, b, m2);
-      e11 = fmaf(g, a * a, e11);
-      e22 = fmaf(g, b * b, e22);
-      e12 = fmaf(g, a * b, e12);
+    for (int j = 0; j < SS_BLK + 10; j++) {
+      a[j] = sx[ly][lx + j];
+      b[j] = sy[ly][lx + j];
+      aa[j] = a[j] * a[j];
+      bb[j] = b[j] * b[j];
+      ab[j] = a[j] * b[j];
     }
-    hz[0][ly][lx] = m1; hz[1][ly][lx] = m2; hz[2][ly][lx] = e11; hz[3][ly][lx] = e22; hz[4][ly][lx] = e12;
+#pragma unroll
+    for (int o = 0; o < SS_BLK; o++) {
+      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float g = kGauss[k];
+        m1 = fmaf(g, a[o + k], m1);
+        m2 = fmaf(g, b[o + k], m2);
+        e11 = fmaf(g, aa[o + k], e11);
+        e22 = fmaf(g, bb[o + k], e22);
+        e12 = fmaf(g, ab[o + k], e12);
+      }
+      hz[0][ly][lx + o] = m1; hz[1][ly][lx + o] = m2; hz[2][ly][lx + o] = e11; hz[3][ly][lx + o] = e22;
+      hz[4][ly][lx + o] = e12;
+    }
   }
   __syncthreads();
   float l1_acc = 0.f, ss_acc = 0.f;
   const size_t cplane = (size_t)C * plane;
-  for (int i = threadIdx.x; i < SS_TILE * SS_TILE; i += 256) {
-    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
-    int gy = y0 + ly, gx = x0 + lx;
-    if (gy >= H || gx >= W) continue;
-    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  {
+    // vertical pass: thread = (column lx, SS_BLK consecutive rows); 32 columns x 8 row groups = 256 threads
+    static_assert(SS_TILE * (SS_TILE / SS_BLK) == 256, "one task per thread");
+    const int lx = threadIdx.x & (SS_TILE - 1), ly0 = (threadIdx.x / SS_TILE) * SS_BLK;
+    float mom[5][SS_BLK];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      float g = kGauss[k];
-      m1 = fmaf(g, hz[0][ly + k][lx], m1);
-      m2 = fmaf(g, hz[1][ly + k][lx], m2);
-      e11 = fmaf(g, hz[2][ly + k][lx], e11);
-      e22 = fmaf(g, hz[3][ly + k][lx], e22);
-      e12 = fmaf(g, hz[4][ly + k][lx], e12);
+    for (int m = 0; m < 5; m++) {
+      float v[SS_BLK + 10];
+#pragma unroll
+      for (int j = 0; j < SS_BLK + 10; j++) v[j] = hz[m][ly0 + j][lx];
+#pragma unroll
+      for (int o = 0; o < SS_BLK; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(kGauss[k], v[o + k], acc);
+        mom[m][o] = acc;
+      }
     }
-    float A1 = 2.f * m1 * m2 + SS_C1;
-    float A2 = 2.f * (e12 - m1 * m2) + SS_C2;
-    float B1 = m1 * m1 + m2 * m2 + SS_C1;
-    float B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + SS_C2;
-    float inv = 1.0f / (B1 * B2);
-    float S = A1 * A2 * inv;
-    ss_acc += S;
-    float a = sx[ly + SS_HALO][lx + SS_HALO], b = sy[ly + SS_HALO][lx + SS_HALO];
-    l1_acc += fabsf(a - b);
-    size_t p = ch * plane + (size_t)gy * W + gx;
-    maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/dm1
-    maps[cplane + p] = -S / B2;                                                       // d/de11
-    maps[2 * cplane + p] = 2.f * A1 * inv;                                            // d/de12
+#pragma unroll
+    for (int o = 0; o < SS_BLK; o++) {
+      const int ly = ly0 + o, gy = y0 + ly, gx = x0 + lx;
+      if (gy >= H || gx >= W) continue;
+      const float m1 = mom[0][o], m2 = mom[1][o], e11 = mom[2][o], e22 = mom[3][o], e12 = mom[4][o];
+      float A1 = 2.f * m1 * m2 + SS_C1;
+      float A2 = 2.f * (e12 - m1 * m2) + SS_C2;
+      float B1 = m1 * m1 + m2 * m2 + SS_C1;
+      float B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + SS_C2;
+      float inv = 1.0f / (B1 * B2);
+      float S = A1 * A2 * inv;
+      ss_acc += S;
+      float a = sx[ly + SS_HALO][lx + SS_HALO], b = sy[ly + SS_HALO][lx + SS_HALO];
+      l1_acc += fabsf(a - b);
+      size_t p = ch * plane + (size_t)gy * W + gx;
+      maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/dm1
+      maps[cplane + p] = -S / B2;                                                       // d/de11
+      maps[2 * cplane + p] = 2.f * A1 * inv;                                            // d/de12
+    }
   }
   float t1 = block_sum_256(l1_acc, red);
   float t2 = block_sum_256(ss_acc, red);
@@ -184,40 +211,54 @@ __global__ __launch_bounds__(256) void photometric_bwd_kernel(int C, int H, int 
     sm[0][ly][lx] = a; sm[1][ly][lx] = b; sm[2][ly][lx] = c;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < SS_IN * SS_TILE; i += 256) {
-    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
-    float a = 0.f, b = 0.f, c = 0.f;
+  // register-blocked separable filter of the three maps (see photometric_fwd_kernel)
+  for (int task = threadIdx.x; task < SS_IN * (SS_TILE / SS_BLK); task += 256) {
+    const int ly = task / (SS_TILE / SS_BLK), lx = (task - ly * (SS_TILE / SS_BLK)) * SS_BLK;
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      float g = kGauss[k];
-      a = fmaf(g, sm[0][ly][lx + k], a);
-      b = fmaf(g, sm[1][ly][lx + k], b);
-      c = fmaf(g, sm[2][ly][lx + k], c);
+    for (int m = 0; m < 3; m++) {
+      float v[SS_BLK + 10];
+#pragma unroll
+      for (int j = 0; j < SS_BLK + 10; j++) v[j] = sm[m][ly][lx + j];
+#pragma unroll
+      for (int o = 0; o < SS_BLK; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(kGauss[k], v[o + k], acc);
+        hz[m][ly][lx + o] = acc;
+      }
     }
-    hz[0][ly][lx] = a; hz[1][ly][lx] = b; hz[2][ly][lx] = c;
   }
   __syncthreads();
   const float up = upstream ? upstream[0] : 1.0f;
   const float invN = 1.0f / ((float)C * (float)H * (float)W);
   const float k_l1 = up * (1.0f - lambda_dssim) * invN, k_ss = -up * lambda_dssim * invN;
-  for (int i = threadIdx.x; i < SS_TILE * SS_TILE; i += 256) {
-    int ly = i / SS_TILE, lx = i - ly * SS_TILE;
-    int gy = y0 + ly, gx = x0 + lx;
-    if (gy >= H || gx >= W) continue;
-    float a = 0.f, b = 0.f, c = 0.f;
+  {
+    const int lx = threadIdx.x & (SS_TILE - 1), ly0 = (threadIdx.x / SS_TILE) * SS_BLK;
+    float f[3][SS_BLK];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      float g = kGauss[k];
-      a = fmaf(g, hz[0][ly + k][lx], a);
-      b = fmaf(g, hz[1][ly + k][lx], b);
-      c = fmaf(g, hz[2][ly + k][lx], c);
+    for (int m = 0; m < 3; m++) {
+      float v[SS_BLK + 10];
+#pragma unroll
+      for (int j = 0; j < SS_BLK + 10; j++) v[j] = hz[m][ly0 + j][lx];
+#pragma unroll
+      for (int o = 0; o < SS_BLK; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(kGauss[k], v[o + k], acc);
+        f[m][o] = acc;
+      }
     }
-    size_t pp = (size_t)gy * W + gx, p = ch * plane + pp;
-    float m = mask ? mask[pp] : 1.0f;
-    float x = img[p] * m, y = gt[p] * m;
-    float d = x - y;
-    float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    dimg[p] = m * (k_l1 * sgn + k_ss * (a + 2.f * x * b + y * c));
+#pragma unroll
+    for (int o = 0; o < SS_BLK; o++) {
+      const int gy = y0 + ly0 + o, gx = x0 + lx;
+      if (gy >= H || gx >= W) continue;
+      size_t pp = (size_t)gy * W + gx, p = ch * plane + pp;
+      float m = mask ? mask[pp] : 1.0f;
+      float x = img[p] * m, y = gt[p] * m;
+      float d = x - y;
+      float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      dimg[p] = m * (k_l1 * sgn + k_ss * (f[0][o] + 2.f * x * f[1][o] + y * f[2][o]));
+    }
   }
 }
 

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
                                                         const float4 *__restrict__ conic_op,
                                                         const float *__restrict__ depth,
                                                         uint32_t *__restrict__ tile_count,
-                                                        unsigned long long *__restrict__ keys) {
+                                                        unsigned long long *__restrict__ keys,
+                                                        const uint32_t *__restrict__ total_pairs,
+                                                        uint32_t max_pairs) {
+  // launched before the host has seen R: a list that does not fit the caller's buffers is never written
+  if (SCATTER && *total_pairs > max_pairs) return;
   __shared__ float4 rec_a[256];  // mean2D x,y | conic A,B
   __shared__ float4 rec_b[256];  // conic C | tau | depth bits | Gaussian index
   __shared__ uint4 rec_c[256];   // rect x0,y0 | width | ceil(2^32 / width)
@@ -225,7 +229,8 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
 // replaced by the absolute start of its sub-list (the scatter cursor)
 template <int PER>  // PER > 0: at most PER tiles per thread, counters held in registers between the two sweeps
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *__restrict__ tile_count,
-                                                          int2 *__restrict__ ranges, uint32_t *__restrict__ total_out) {
+                                                          int2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
+                                                          uint32_t *host_total) {
   static_assert(BIN_SUBS == 8, "two uint4 per tile");
   __shared__ uint32_t part[1024];
   const int per = (ntiles + 1023) / 1024;
@@ -288,7 +293,11 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *
     for (int k = 0; k < per; k++)
       if (t0 + k < ntiles) emit(t0 + k, tc4[2 * (t0 + k)], tc4[2 * (t0 + k) + 1]);
   }
-  if (threadIdx.x == 0) *total_out = grand;
+  if (threadIdx.x == 0) {
+    *total_out = grand;
+    // pinned host word polled by run_binning (fsgs_host.h mailbox): the host learns R without a stream sync
+    if (host_total) __hip_atomic_store(host_total, grand, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 constexpr int SORT_LDS_KEYS = 2048;  // 16 KB of LDS per workgroup; longer lists sort in global memory
@@ -323,8 +332,11 @@ __device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
 
 __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 *__restrict__ ranges,
                                                          unsigned long long *__restrict__ keys,
-                                                         uint32_t *__restrict__ plist) {
+                                                         uint32_t *__restrict__ plist,
+                                                         const uint32_t *__restrict__ total_pairs,
+                                                         uint32_t max_pairs) {
   __shared__ unsigned long long lds[SORT_LDS_KEYS];
+  if (*total_pairs > max_pairs) return;  // see bin_pairs_kernel: the lists were not written
   const int tile = blockIdx.x;
   const int2 rg = ranges[tile];
   const int n = rg.y - rg.x;
@@ -962,35 +974,45 @@ int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, i
   if (P > 0) {
     ProfScope ps(PROF_EMIT, stream);  // count pass
     hipLaunchKernelGGL((bin_pairs_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
-                       B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys);
+                       B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys, B.total, 0u);
   }
+  volatile uint32_t *slot = mailbox_acquire();
   {
     ProfScope ps(PROF_SCAN, stream);
     if (ntiles <= 8 * 1024)
-      hipLaunchKernelGGL(scan_tiles_kernel<8>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
+      hipLaunchKernelGGL(scan_tiles_kernel<8>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total,
+                         (uint32_t *)slot);
     else
-      hipLaunchKernelGGL(scan_tiles_kernel<0>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total);
+      hipLaunchKernelGGL(scan_tiles_kernel<0>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total,
+                         (uint32_t *)slot);
   }
   FSGS_HIP(hipGetLastError());
-  FSGS_HIP(hipMemcpyAsync(&R, B.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  FSGS_HIP(hipStreamSynchronize(stream));  // the one host sync (UPSTREAM R2 does the same)
-  *num_rendered = (int64_t)R;
-  if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
-  if (R > 0) {
+  // Everything below is enqueued BEFORE the host knows R; the kernels themselves refuse to run when the lists
+  // would not fit (R > max_pairs), so the GPU never waits for the host here.
+  const uint32_t cap32 = (uint32_t)(max_pairs > 0x7FFFFFFF ? 0x7FFFFFFF : max_pairs);
+  if (P > 0) {
     {
       ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
       hipLaunchKernelGGL((bin_pairs_kernel<true>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
-                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys);
+                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys, B.total, cap32);
     }
     {
       ProfScope ps(PROF_SORT_TILE, stream);
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist);
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist,
+                         B.total, cap32);
       if (ntiles <= ORDER_MAX_TILES)
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
                            (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order);
     }
     FSGS_HIP(hipGetLastError());
   }
+  if (!slot || !mailbox_wait(slot, stream, &R)) {
+    // no pinned mailbox (or the stream failed): the classic copy + synchronize (UPSTREAM R2 does the same)
+    FSGS_HIP(hipMemcpyAsync(&R, B.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    FSGS_HIP(hipStreamSynchronize(stream));
+  }
+  *num_rendered = (int64_t)R;
+  if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
   return FSGS_OK;
 }
 

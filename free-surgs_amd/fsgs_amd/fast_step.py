@@ -35,10 +35,16 @@ class _Buffers:
         self.maps = f(3, 3, H, W)
         self.sums = torch.empty((int(_lib.load().fsgs_photometric_scratch_bytes(3, H, W)),), dtype=torch.uint8,
                                 device=dev)
-        self.rgb_out = f(3)
+        # every scalar loss term of a view in ONE buffer: [rgb loss, L1 mean, SSIM mean, pearson, local pearson, -, -, -]
+        # so that the weighted sum is a single dot product
+        self.terms = torch.zeros((8,), dtype=torch.float32, device=dev)
+        self.rgb_out = self.terms[0:3]
         self.stats = torch.empty((5 * (n_patches + 1),), dtype=torch.float64, device=dev)
         self.coef = f(8 * (n_patches + 1))
-        self.pe_out = f(2)
+        self.pe_out = self.terms[3:5]
+        tw = np.zeros((8,), np.float32)
+        tw[0], tw[3], tw[4] = LOSS_W_MAPPING["rgb"], LOSS_W_MAPPING["pearson"], LOSS_W_MAPPING["local_pearson"]
+        self.term_w = torch.tensor(tw, device=dev)
         self.d_image = f(3, H, W)
         self.d_depth_sil = torch.zeros((3, H, W), dtype=torch.float32, device=dev)  # planes 1,2 stay zero
         self.up_rgb = torch.tensor([LOSS_W_MAPPING["rgb"]], dtype=torch.float32, device=dev)
@@ -175,8 +181,7 @@ class FastStepper:
                         pc.params[name].grad.add_(t)
                     # render() itself raises max_radii2D for EVERY rendered view (gaussian_renderer/__init__.py:79)
                     pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
-                loss_k = (LOSS_W_MAPPING["rgb"] * b.rgb_out[0] + LOSS_W_MAPPING["pearson"] * b.pe_out[0]
-                          + LOSS_W_MAPPING["local_pearson"] * b.pe_out[1])
+                loss_k = torch.dot(b.terms, b.term_w)
                 total = loss_k if total is None else total + loss_k
                 if first:  # densification statistics come from view 0 only (train.py:260-263)
                     radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()

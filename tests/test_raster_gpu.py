@@ -258,3 +258,21 @@ def test_large_grid_and_screen_filling_gaussians(oracle32):
     col = rng.uniform(0, 1, (n_small + n_big, 3)).astype(np.float32)
     R = _compare(oracle32, cam, xyz, col, op, s, rot)
     assert R > 9360  # the big ones alone reach most tiles
+
+
+def test_pair_capacity_overflow_is_reported_and_retried(oracle32):
+    """The binning kernels are enqueued before the host has seen R.  With a pair buffer that is too small they
+    must not write anything, the C ABI must answer FSGS_ERR_CAPACITY together with the needed R, and the Python
+    shim's retry with a larger buffer must then produce the oracle's image."""
+    from fsgs_amd import rasterizer
+
+    cam = synth.make_camera(160, 128)
+    xyz, col, op, scl, rot = synth.random_small_scene(400, cam, seed=5)
+    key = (400, 160, 128)
+    rasterizer._capacity[key] = 32  # far below the real R
+    try:
+        R = _compare(oracle32, cam, xyz, col, op, scl, rot)
+        assert R > 32
+        assert rasterizer._capacity[key] >= R
+    finally:
+        rasterizer._capacity.pop(key, None)
