@@ -272,7 +272,8 @@ constexpr int PE_CHUNK = 4096;  // pixels per workgroup
 __global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int box, const int64_t *__restrict__ row0,
                                                             const int64_t *__restrict__ col0,
                                                             const float *__restrict__ src,
-                                                            const float *__restrict__ tgt, double *__restrict__ stats) {
+                                                            const float *__restrict__ tgt,
+                                                            double *__restrict__ partials, int n0, int nb) {
   __shared__ float red[4];
   const int r = blockIdx.y;
   int ry = 0, rx = 0, rh = H, rw = W;
@@ -294,21 +295,33 @@ __global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int bo
   float t0 = block_sum_256(a0, red), t1 = block_sum_256(a1, red), t2 = block_sum_256(a2, red);
   float t3 = block_sum_256(a3, red), t4 = block_sum_256(a4, red);
   if (threadIdx.x == 0) {
-    double *st = stats + 5 * r;
-    atomicAdd(st + 0, (double)t0); atomicAdd(st + 1, (double)t1); atomicAdd(st + 2, (double)t2);
-    atomicAdd(st + 3, (double)t3); atomicAdd(st + 4, (double)t4);
+    // one partial per workgroup, summed in a fixed order by the finish kernel: hundreds of same-address double
+    // atomics (~46 ns each) used to take longer than reading the two images, and made the sum order-dependent
+    double *st = partials + 5 * (size_t)(r == 0 ? blockIdx.x : n0 + (r - 1) * nb + blockIdx.x);
+    st[0] = (double)t0; st[1] = (double)t1; st[2] = (double)t2; st[3] = (double)t3; st[4] = (double)t4;
   }
 }
 
 // per region: coefficients of the gradient + the loss value
 //   co = cov / ((sd_s+eps)(sd_t+eps)), cov = E[st]-E[s]E[t] (biased, mean()), sd unbiased
 //   coef[r] = {mean_s, mean_t, 1/(N*D), cov/(D*(sd_t+eps)*(N-1)*sd_t), cov/(D*(sd_s+eps)*(N-1)*sd_s), loss}
-__global__ void pearson_finish_kernel(int H, int W, int box, int nregions, const double *__restrict__ stats,
-                                      float *__restrict__ coef, float *__restrict__ out) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nregions) {
+// one 64-thread workgroup per region
+__global__ __launch_bounds__(64) void pearson_finish_kernel(int H, int W, int box, int nregions,
+                                                            const double *__restrict__ partials, int n0, int nb,
+                                                            float *__restrict__ coef, float *__restrict__ out) {
+  const int r = blockIdx.x;
+  const int cnt = r == 0 ? n0 : nb;
+  const double *base = partials + 5 * (size_t)(r == 0 ? 0 : n0 + (r - 1) * nb);
+  double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < cnt; i += 64)
+#pragma unroll
+    for (int q = 0; q < 5; q++) st[q] += base[5 * i + q];
+#pragma unroll
+  for (int q = 0; q < 5; q++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) st[q] += __shfl_xor(st[q], off, 64);
+  if (threadIdx.x == 0) {
     double N = r == 0 ? (double)H * W : (double)box * box;
-    const double *st = stats + 5 * r;
     double ms = st[0] / N, mt = st[1] / N;
     double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
     vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
@@ -320,10 +333,7 @@ __global__ void pearson_finish_kernel(int H, int W, int box, int nregions, const
     c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
     c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
     c[5] = (float)(1.0 - cov / D);
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    out[0] = coef[5];  // global loss  (written by this block's thread 0 above when r == 0)
+    if (r == 0) out[0] = c[5];  // global loss
   }
 }
 __global__ void pearson_local_mean_kernel(int nregions, const float *__restrict__ coef, float *__restrict__ out) {
@@ -416,21 +426,30 @@ int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const 
   return FSGS_OK;
 }
 
+size_t fsgs_pearson_scratch_bytes(int H, int W, int n_patches, int box) {
+  if (H <= 0 || W <= 0 || n_patches < 0 || box < 0) return 0;
+  const size_t n0 = ((size_t)H * W + PE_CHUNK - 1) / PE_CHUNK, nb = ((size_t)box * box + PE_CHUNK - 1) / PE_CHUNK;
+  return (n0 + (size_t)n_patches * nb) * 5 * sizeof(double) + 64;
+}
+
 int fsgs_pearson_forward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
-                         const float *src, const float *tgt, double *stats, float *coef, float *out2,
+                         const float *src, const float *tgt, void *scratch, float *coef, float *out2,
                          fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (H <= 0 || W <= 0 || n_patches < 0 || n_patches > 64 || !src || !tgt || !stats || !coef || !out2)
+  if (H <= 0 || W <= 0 || n_patches < 0 || n_patches > 64 || !src || !tgt || !scratch || !coef || !out2)
     return FSGS_ERR_INVALID;
   if (n_patches > 0 && (!patch_row0 || !patch_col0 || box <= 1 || box > H || box > W)) return FSGS_ERR_INVALID;
   const int nreg = n_patches + 1;
-  FSGS_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 5 * nreg, stream));
+  const int n0 = (int)(((size_t)H * W + PE_CHUNK - 1) / PE_CHUNK);
+  const int nb = n_patches > 0 ? (int)(((size_t)box * box + PE_CHUNK - 1) / PE_CHUNK) : 0;
+  double *partials = (double *)scratch;  // caller-sized by fsgs_pearson_scratch_bytes; every slot is written
   {
     ProfScope ps(PROF_PEARSON, stream);
-    dim3 grid((H * W + PE_CHUNK - 1) / PE_CHUNK, nreg);
+    dim3 grid(n0 > nb ? n0 : nb, nreg);
     hipLaunchKernelGGL(pearson_stats_kernel, grid, dim3(256), 0, stream, H, W, box, patch_row0, patch_col0, src, tgt,
-                       stats);
-    hipLaunchKernelGGL(pearson_finish_kernel, dim3(1), dim3(128), 0, stream, H, W, box, nreg, stats, coef, out2);
+                       partials, n0, nb);
+    hipLaunchKernelGGL(pearson_finish_kernel, dim3(nreg), dim3(64), 0, stream, H, W, box, nreg, partials, n0, nb, coef,
+                       out2);
     hipLaunchKernelGGL(pearson_local_mean_kernel, dim3(1), dim3(64), 0, stream, nreg, coef, out2);
   }
   FSGS_HIP(hipGetLastError());

@@ -303,31 +303,49 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *
 constexpr int SORT_LDS_KEYS = 2048;  // 16 KB of LDS per workgroup; longer lists sort in global memory
 
 // compare-exchange network over m (power of two) virtual elements, n real ones; every exchange puts the
-// smaller key at the lower index, so the +inf padding (indices >= n) never moves and is never touched
-template <typename Mem>
+// smaller key at the lower index, so the +inf padding (indices >= n) never moves and is never touched.
+// Exchange t of a step belongs to chunk t >> 6, and in every step whose partner distance is < 128 (mirror steps
+// with k <= 128, shuffle steps with j <= 64) the 64 exchanges of a chunk stay inside elements
+// [128 chunk, 128 chunk + 128).  A chunk is always handled by the same wave, so between two such steps a wave
+// only needs its own LDS traffic in order (WAVE_LOCAL): of the 36 steps of a 256-key sort only one needs the
+// workgroup barrier on either side.  Lists sorted in global memory keep the barrier everywhere.
+template <bool WAVE_LOCAL, typename Mem>
 __device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
-  for (int k = 2; k <= m; k <<= 1) {
+  bool prev_local = false;
+  auto sync_before = [&](bool local) {
+    if (WAVE_LOCAL && local && prev_local) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
+    prev_local = local;
+  };
+  const int half = m >> 1;
+  for (int k = 2, lk = 1; k <= m; k <<= 1, lk++) {
     const int hk = k >> 1;
-    for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {  // first step of the merge: mirror partner
-      int blk = t / hk, off = t - blk * hk;
-      int i = blk * k + off, l = blk * k + k - 1 - off;
+    sync_before(k <= 128);
+    for (int t = threadIdx.x; t < half; t += blockDim.x) {  // first step of the merge: mirror partner
+      const int blk = t >> (lk - 1), off = t & (hk - 1);
+      const int i = (blk << lk) + off, l = (blk << lk) + k - 1 - off;
       if (l < n) {
         unsigned long long a = keys[i], b = keys[l];
         if (a > b) { keys[i] = b; keys[l] = a; }
       }
     }
-    __syncthreads();
     for (int j = k >> 2; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
-        int i = 2 * j * (t / j) + (t % j), l = i + j;
+      sync_before(j <= 64);
+      for (int t = threadIdx.x; t < half; t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
         if (l < n) {
           unsigned long long a = keys[i], b = keys[l];
           if (a > b) { keys[i] = b; keys[l] = a; }
         }
       }
-      __syncthreads();
     }
   }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 *__restrict__ ranges,
@@ -346,12 +364,10 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 
   unsigned long long *gk = keys + rg.x;
   if (n <= SORT_LDS_KEYS) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = gk[i];
-    __syncthreads();
-    bitonic_sort_ascending(lds, n, m);
+    bitonic_sort_ascending<true>(lds, n, m);
     for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)lds[i];
   } else {  // rare: a tile with more than 2048 Gaussians sorts in place in global memory (L2 resident)
-    __syncthreads();
-    bitonic_sort_ascending(gk, n, m);
+    bitonic_sort_ascending<false>(gk, n, m);
     for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)gk[i];
   }
 }
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
   for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
     int2 rg = ranges[i];
     int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    int band = (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+    int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
     atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // bin 0 = longest lists
     atomicAdd(&band_size[band], 1u);
   }
@@ -396,15 +412,17 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
     uint32_t loc[8], s = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) { loc[q] = hist[band][t * 8 + q]; s += loc[q]; }
-    part[band][t] = s;
-    __syncthreads();
-    for (int off = 1; off < 128; off <<= 1) {
-      uint32_t v = t >= off ? part[band][t - off] : 0u;
-      __syncthreads();
-      part[band][t] += v;
-      __syncthreads();
+    // 128 threads per band = two waves: wave-level inclusive scan + the other wave's total
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
     }
-    uint32_t run = part[band][t] - s;
+    if (lane == 63) part[band][t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - s + ((t >> 6) ? part[band][0] : 0u);
 #pragma unroll
     for (int q = 0; q < 8; q++) { hist[band][t * 8 + q] = run; run += loc[q]; }
   }
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
   for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
     int2 rg = ranges[i];
     int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    int band = (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+    int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
     uint32_t rank = atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // rank inside the band, longest first
     uint32_t pos = 0;
 #pragma unroll

@@ -39,7 +39,8 @@ class _Buffers:
         # so that the weighted sum is a single dot product
         self.terms = torch.zeros((8,), dtype=torch.float32, device=dev)
         self.rgb_out = self.terms[0:3]
-        self.stats = torch.empty((5 * (n_patches + 1),), dtype=torch.float64, device=dev)
+        self.stats = torch.empty((int(_lib.load().fsgs_pearson_scratch_bytes(H, W, n_patches, BOX)),),
+                                 dtype=torch.uint8, device=dev)
         self.coef = f(8 * (n_patches + 1))
         self.pe_out = self.terms[3:5]
         tw = np.zeros((8,), np.float32)

@@ -78,7 +78,8 @@ class _Pearson(torch.autograd.Function):
         n = 0 if row0 is None else int(row0.numel())
         r0 = None if n == 0 else row0.detach().contiguous().to(torch.int64)
         c0 = None if n == 0 else col0.detach().contiguous().to(torch.int64)
-        stats = torch.empty((5 * (n + 1),), dtype=torch.float64, device=s.device)
+        stats = torch.empty((int(lib.fsgs_pearson_scratch_bytes(H, W, n, int(box))),), dtype=torch.uint8,
+                            device=s.device)
         coef = torch.empty((8 * (n + 1),), dtype=torch.float32, device=s.device)
         out = torch.empty((2,), dtype=torch.float32, device=s.device)
         with torch.cuda.device(s.device):

@@ -193,10 +193,13 @@ int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const 
 
 /* Global loss over the whole [H,W] image and the mean loss over n_patches (<= 64) box x box patches
  * whose top-left corners (row, col) are int64 DEVICE arrays (what torch.randint produced).
- * stats double[5*(n_patches+1)] scratch, coef float[8*(n_patches+1)] (kept for backward),
- * out2 float[2] = {global loss, mean patch loss} on the device. */
+ * scratch: fsgs_pearson_scratch_bytes(H, W, n_patches, box) bytes of per-workgroup partial sums (need not
+ * be zeroed; the sums are reduced in a fixed order, so the result is run-to-run deterministic),
+ * coef float[8*(n_patches+1)] (kept for backward), out2 float[2] = {global loss, mean patch loss} on the
+ * device. */
+size_t fsgs_pearson_scratch_bytes(int H, int W, int n_patches, int box);
 int fsgs_pearson_forward(int H, int W, int n_patches, int box, const int64_t *patch_row0, const int64_t *patch_col0,
-                         const float *src, const float *tgt, double *stats, float *coef, float *out2,
+                         const float *src, const float *tgt, void *scratch, float *coef, float *out2,
                          fsgs_stream_t stream);
 /* grad [H,W] = sum_r region_weight[r] * dloss_r/d(tgt or src); region_weight float[n_patches+1] on the
  * device (r = 0 global).  wrt_src = 0: gradient w.r.t. tgt (the rendered depth, train.py:256-257). */
