@@ -151,7 +151,7 @@ def main():
     def one_step(it):
         ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
         if bucket is not None:
-            bucket.attach(pc)
+            bucket.attach(pc, zero=not use_fast)
         sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None
         if use_fast:
             return stepper.mapping_step([ts], grad_sync=sync), None

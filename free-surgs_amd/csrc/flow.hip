@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(size_t M, FlowCam c, cons
   }
 }
 
+// every workgroup ends with a handful of same-address atomics, which serialise (tens of ns each): with 1024
+// workgroups that chain was longer than the streaming pass itself, so the grid is capped at one workgroup per CU
 int flow_blocks(size_t M) {
   size_t b = (M + 255) / 256;
-  return (int)(b > 1024 ? 1024 : (b ? b : 1));
+  return (int)(b > 256 ? 256 : (b ? b : 1));
 }
 
 FlowCam make_flow_cam(const float *K9, int W, int H, float edge) {

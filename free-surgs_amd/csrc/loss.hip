@@ -337,11 +337,15 @@ __global__ __launch_bounds__(64) void pearson_finish_kernel(int H, int W, int bo
   }
 }
 __global__ void pearson_local_mean_kernel(int nregions, const float *__restrict__ coef, float *__restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float acc = 0.f;
-    for (int r = 1; r < nregions; r++) acc += coef[8 * r + 5];  // sequential like the reference's python loop
-    out[1] = nregions > 1 ? acc / (float)(nregions - 1) : 0.f;
-  }
+  // one wave: lane r fetches region r's loss (parallel loads), lane 0 then adds them in the order of the
+  // reference's python loop (nregions <= 65)
+  const int lane = threadIdx.x;
+  const float mine = (lane >= 1 && lane < nregions) ? coef[8 * lane + 5] : 0.f;
+  const float last = nregions > 64 ? coef[8 * 64 + 5] : 0.f;
+  float acc = 0.f;
+  for (int r = 1; r < nregions && r < 64; r++) acc += readlane(mine, r);
+  if (nregions > 64) acc += last;
+  if (lane == 0) out[1] = nregions > 1 ? acc / (float)(nregions - 1) : 0.f;
 }
 
 // d(loss_r)/d tgt_i = -(s_i-ms)/(N D) + cov/(D (sd_t+eps) (N-1) sd_t) (t_i - mt), weighted by weight[r]

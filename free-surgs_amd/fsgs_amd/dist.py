@@ -45,9 +45,11 @@ class GradBucket:
     def matches(self, pc):
         return all(tuple(pc.params[k].shape) == self.shapes[k] for k in PARAM_NAMES)
 
-    def attach(self, pc):
-        """Make autograd accumulate straight into the bucket (zeroes it)."""
-        self.flat.zero_()
+    def attach(self, pc, zero=True):
+        """Point every parameter's .grad at its view of the bucket.  zero=True for autograd (which accumulates);
+        the autograd-free stepper overwrites every element each step and skips the 70 MB memset."""
+        if zero:
+            self.flat.zero_()
         for k in PARAM_NAMES:
             pc.params[k].grad = self.views[k]
 
