@@ -218,12 +218,12 @@ def main():
         flow_fw = torch.zeros((2, H, W), device=device)
         targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), cam["K"], flow_fw, rigid)
         for _ in range(3):
-            stepper.tracking_step(1, targets, rigid)
+            stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         nt = 20
         for _ in range(nt):
-            stepper.tracking_step(1, targets, rigid)
+            stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
         torch.cuda.synchronize()
         tracking = {"iters_per_sec": nt / (time.perf_counter() - t1), "ms_per_iter": (time.perf_counter() - t1) / nt * 1e3,
                     "what": "render(gs_grad=False, cam_grad=True) + masked rgb loss + flow loss + pose Adam"}

@@ -134,6 +134,86 @@ __global__ __launch_bounds__(256) void flow_bwd_kernel(size_t M, FlowCam c, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fused forward + backward (the autograd-free tracking step): ONE streaming pass produces, per workgroup,
+// {sum |e|, #valid, #NaN, the 12 UNSCALED sums of dcam [x;1]^T}; the finish kernel adds the partials in a fixed
+// order (doubles), forms the loss and applies 1/(2n) -- the only thing the backward needed from the forward.
+// ---------------------------------------------------------------------------------------------------
+constexpr int FLOW_PER_THREAD = 16;  // 4096 points per workgroup: ~320 partials at 1280x1024
+constexpr int FLOW_VALS = 16;  // 15 used
+__global__ __launch_bounds__(256) void flow_fused_kernel(size_t M, FlowCam c, const float *__restrict__ w2c,
+                                                         const float *__restrict__ pts,
+                                                         const int64_t *__restrict__ pix_vu,
+                                                         const float *__restrict__ flow,
+                                                         float *__restrict__ partials) {
+  __shared__ float red[FLOW_VALS][4];
+  float a[15];
+#pragma unroll
+  for (int k = 0; k < 15; k++) a[k] = 0.f;
+  const size_t base = (size_t)blockIdx.x * (256 * FLOW_PER_THREAD) + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < FLOW_PER_THREAD; q++) {
+    const size_t i = base + (size_t)q * 256;
+    if (i >= M) break;
+    FlowPoint p = flow_point(c, w2c, pts, pix_vu, flow, i);
+    if (!p.valid) continue;
+    const float e = fabsf(p.eu) + fabsf(p.ev);
+    if (e != e) a[2] += 1.f; else a[0] += e;
+    a[1] += 1.f;
+    float su = p.eu > 0.f ? 1.f : (p.eu < 0.f ? -1.f : 0.f);
+    float sv = p.ev > 0.f ? 1.f : (p.ev < 0.f ? -1.f : 0.f);
+    float ipz = 1.0f / p.pz;
+    float dp0 = su * ipz, dp1 = sv * ipz, dp2 = -(su * p.u + sv * p.v) * ipz;
+    float dc0 = c.K[0] * dp0 + c.K[3] * dp1 + c.K[6] * dp2;
+    float dc1 = c.K[1] * dp0 + c.K[4] * dp1 + c.K[7] * dp2;
+    float dc2 = c.K[2] * dp0 + c.K[5] * dp1 + c.K[8] * dp2;
+    float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    float *g = a + 3;
+    g[0] = fmaf(dc0, x, g[0]); g[1] = fmaf(dc0, y, g[1]); g[2] = fmaf(dc0, z, g[2]); g[3] += dc0;
+    g[4] = fmaf(dc1, x, g[4]); g[5] = fmaf(dc1, y, g[5]); g[6] = fmaf(dc1, z, g[6]); g[7] += dc1;
+    g[8] = fmaf(dc2, x, g[8]); g[9] = fmaf(dc2, y, g[9]); g[10] = fmaf(dc2, z, g[10]); g[11] += dc2;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 15; k++) {
+    float t = wave_sum(a[k]);
+    if (lane == 0) red[k][wid] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < FLOW_VALS)
+    partials[(size_t)blockIdx.x * FLOW_VALS + threadIdx.x] =
+        threadIdx.x < 15 ? red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3] : 0.f;
+}
+
+// out2 = {loss, #valid};  dw2c[r][c] = accumulate * dw2c[r][c] + upstream * dloss/dw2c[r][c]  (accumulate == 0
+// overwrites without reading; row 3 of the flow term is zero)
+__global__ __launch_bounds__(1024) void flow_fused_finish_kernel(const float *__restrict__ partials, int nblocks,
+                                                                float upstream, float accumulate,
+                                                                float *__restrict__ out2, float *__restrict__ dw2c) {
+  __shared__ double red[64][17];
+  const int v = threadIdx.x & 15, row = threadIdx.x >> 4;  // 16 values x 64 block stripes
+  double s = 0.0;
+  for (int b = row; b < nblocks; b += 64) s += (double)partials[(size_t)b * FLOW_VALS + v];
+  red[row][v] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int r = 0; r < 64; r++) t += red[r][threadIdx.x];
+    red[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double n = red[0][1];
+  const bool live = n > 0 && red[0][2] == 0;
+  if (threadIdx.x == 0) {
+    out2[0] = live ? (float)(red[0][0] / (2.0 * n)) : 0.f;
+    out2[1] = (float)n;
+  }
+  if (threadIdx.x < 16) {
+    const float g = (live && threadIdx.x < 12) ? upstream / (2.f * (float)n) * (float)red[0][3 + threadIdx.x] : 0.f;
+    dw2c[threadIdx.x] = accumulate != 0.f ? fmaf(accumulate, dw2c[threadIdx.x], g) : g;
+  }
+}
+
 // every workgroup ends with a handful of same-address atomics, which serialise (tens of ns each): with 1024
 // workgroups that chain was longer than the streaming pass itself, so the grid is capped at one workgroup per CU
 int flow_blocks(size_t M) {
@@ -166,6 +246,32 @@ int fsgs_flow_pose_loss_forward(int64_t M, const float *pts_world, const int64_t
       hipLaunchKernelGGL(flow_fwd_kernel, dim3(flow_blocks((size_t)M)), dim3(256), 0, stream, (size_t)M, c, w2c,
                          pts_world, pix_vu, flow_fw, acc3);
     hipLaunchKernelGGL(flow_finish_kernel, dim3(1), dim3(1), 0, stream, acc3, out2);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+size_t fsgs_flow_scratch_bytes(int64_t M) {
+  if (M < 0) return 0;
+  const size_t nb = ((size_t)M + 256 * FLOW_PER_THREAD - 1) / (256 * FLOW_PER_THREAD);
+  return (nb ? nb : 1) * FLOW_VALS * sizeof(float) + 64;
+}
+
+int fsgs_flow_pose_loss_fused(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                              const float *K9_host, const float *flow_fw, int W, int H, float edge, float upstream,
+                              float accumulate, void *scratch, float *out2, float *dw2c, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M < 0 || !w2c || !K9_host || !flow_fw || !scratch || !out2 || !dw2c || W <= 0 || H <= 0) return FSGS_ERR_INVALID;
+  if (M > 0 && (!pts_world || !pix_vu)) return FSGS_ERR_INVALID;
+  FlowCam c = make_flow_cam(K9_host, W, H, edge);
+  const int nb = (int)(((size_t)M + 256 * FLOW_PER_THREAD - 1) / (256 * FLOW_PER_THREAD));
+  {
+    ProfScope ps(PROF_FLOW, stream);
+    if (nb > 0)
+      hipLaunchKernelGGL(flow_fused_kernel, dim3(nb), dim3(256), 0, stream, (size_t)M, c, w2c, pts_world, pix_vu,
+                         flow_fw, (float *)scratch);
+    hipLaunchKernelGGL(flow_fused_finish_kernel, dim3(1), dim3(1024), 0, stream, (const float *)scratch, nb, upstream,
+                       accumulate, out2, dw2c);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

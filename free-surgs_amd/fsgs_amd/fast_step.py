@@ -52,6 +52,12 @@ class _Buffers:
         w = np.full((n_patches + 1,), LOSS_W_MAPPING["local_pearson"] / max(n_patches, 1), np.float32)
         w[0] = LOSS_W_MAPPING["pearson"]
         self.pe_w = torch.tensor(w, device=dev)
+        tk = np.zeros((8,), np.float32)
+        tk[0], tk[5] = LOSS_W_TRACKING["rgb"], LOSS_W_TRACKING["flow"]
+        self.trk_w = torch.tensor(tk, device=dev)
+        self.flow_out = self.terms[5:7]  # {flow loss, #valid points}
+        self.flow_scratch = None
+        self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
         self.bwd_scratch = torch.empty((P * 56 + 512,), dtype=torch.uint8, device=dev)
         self.sizes = {}
@@ -210,7 +216,10 @@ class FastStepper:
                 stream = _lib.current_stream()
                 wd = w2c.detach().contiguous()
                 args, state, sbytes, cap, nr = self._render_forward(wd, b)
-                mask = ((b.depth_sil[0] > 0) * rigid_mask).to(torch.float32).contiguous()
+                # presence mask depth > 0 (heaviside(x, 0) = 1 for x > 0) times the rigid mask (train.py:176-178)
+                mask = torch.heaviside(b.depth_sil[0], b.zero)
+                if rigid_mask is not None:  # None = every pixel rigid (no Sampson mask for this frame)
+                    mask = mask * rigid_mask
                 gt = self.frames.colors[t]
                 _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
                                                              0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
@@ -218,24 +227,26 @@ class FastStepper:
                 _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
                                                               _lib.ptr(b.maps), None, 0.2, _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
-                acc = torch.empty((3,), dtype=torch.float64, device=dev)
-                fl_out = torch.empty((2,), dtype=torch.float32, device=dev)
-                M = int(targets.pts.shape[0])
-                _lib.check(lib.fsgs_flow_pose_loss_forward(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
-                                                           targets.K9, _lib.ptr(targets.flow), W, H, 20.0, _lib.ptr(acc),
-                                                           _lib.ptr(fl_out), stream), "fsgs_flow_pose_loss_forward")
-                d_flow = torch.empty((4, 4), dtype=torch.float32, device=dev)
-                _lib.check(lib.fsgs_flow_pose_loss_backward(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
-                                                            targets.K9, _lib.ptr(targets.flow), W, H, 20.0, _lib.ptr(acc),
-                                                            None, _lib.ptr(d_flow), stream), "fsgs_flow_pose_loss_backward")
-                d_w2c = torch.empty((4, 4), dtype=torch.float32, device=dev)
-                grads = self._grad_struct([None] * 6, b.means2D_grad, d_w2c)
+                d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
+                grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)
                 self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False)
-                d_total = LOSS_W_TRACKING["rgb"] * d_w2c + LOSS_W_TRACKING["flow"] * d_flow
-                rgb, flow = LOSS_W_TRACKING["rgb"] * b.rgb_out[0], LOSS_W_TRACKING["flow"] * fl_out[0]
+                # flow loss forward + backward in one pass; its finish kernel also forms the weighted sum with the
+                # rasteriser's pose gradient:  d_total = w_rgb * d_total + w_flow * dflow/dw2c
+                M = int(targets.pts.shape[0])
+                need = int(lib.fsgs_flow_scratch_bytes(M))
+                if b.flow_scratch is None or b.flow_scratch.numel() < need:
+                    b.flow_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+                _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
+                                                         targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
+                                                         float(LOSS_W_TRACKING["flow"]), float(LOSS_W_TRACKING["rgb"]),
+                                                         _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
+                                                         _lib.ptr(d_total), stream), "fsgs_flow_pose_loss_fused")
+                weighted = b.terms * b.trk_w  # [w_rgb * rgb, ., ., ., ., w_flow * flow, ., .]
+                rgb, flow = weighted[0], weighted[5]
+                total = torch.dot(b.terms, b.trk_w)
             w2c.backward(d_total)  # LearnPose.forward's backward: normalize + q2rot, 12 floats
             poses.scheduler.step()
             with torch.no_grad():
                 poses.optimizer.step()
                 poses.optimizer.zero_grad(set_to_none=True)
-        return (flow + rgb).detach(), rgb.detach(), flow.detach()
+        return total, rgb, flow

@@ -238,7 +238,7 @@ class Runner:
         out = None
         for _ in range(self.tracking_iter):
             if self.fast is not None:
-                out = self.fast.tracking_step(t, targets, rigid) + (None,)
+                out = self.fast.tracking_step(t, targets, None) + (None,)  # all-ones mask: skip the multiply
             else:
                 out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
         return out

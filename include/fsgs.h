@@ -221,6 +221,16 @@ int fsgs_flow_pose_loss_backward(int64_t M, const float *pts_world, const int64_
                                  const float *K9_host, const float *flow_fw, int W, int H, float edge,
                                  const double *acc3, const float *upstream, float *dw2c, fsgs_stream_t stream);
 
+/* Forward and backward in one streaming pass (the autograd-free tracking step): out2 = {loss, #valid} and
+ * dw2c[4,4] = accumulate * dw2c + upstream * dloss/dw2c (accumulate = 0 overwrites without reading dw2c, so the
+ * caller can fold the weighted sum with the rasteriser's pose gradient into this call).  upstream / accumulate
+ * are HOST scalars (the loss weights).  scratch: fsgs_flow_scratch_bytes(M) bytes, need not be zeroed; partial
+ * sums are added in a fixed order. */
+size_t fsgs_flow_scratch_bytes(int64_t M);
+int fsgs_flow_pose_loss_fused(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
+                              const float *K9_host, const float *flow_fw, int W, int H, float edge, float upstream,
+                              float accumulate, void *scratch, float *out2, float *dw2c, fsgs_stream_t stream);
+
 /* ---- LearnPose.forward and its adjoint (scene/pose_optimizer.py:822-877) --------------------------------- */
 
 /* r [1,4,N] quaternions (r,x,y,z), t [3,N] translations, cam_id -> w2c [4,4] row-major (all DEVICE). */

@@ -89,3 +89,39 @@ def test_pose_kernels_match_reference_golden():
         np.testing.assert_allclose(w2c.detach().cpu().numpy(), g[f"w2c_{cam}"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(r.grad.cpu().numpy(), g[f"dr_{cam}"], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(t.grad.cpu().numpy(), g[f"dt_{cam}"], rtol=1e-5, atol=1e-7)
+
+
+def test_fused_flow_pass_matches_the_reference_golden_and_accumulates():
+    """fsgs_flow_pose_loss_fused (one pass: loss + dL/dw2c, then dw2c = accumulate * dw2c + upstream * grad)
+    against the reference's captured loss / gradient, and its accumulate semantics."""
+    from fsgs_amd import _lib
+
+    lib = _lib.load()
+    g = np.load(os.path.join(G, "flow_loss.npz"))
+    for tag, rm in (("rigid", T(g["rigid"])), ("norigid", None)):
+        w2c = pose.pose_to_w2c(T(g["q"]).reshape(1, 4, 1), T(g["t"]).reshape(3, 1), 0).detach().contiguous()
+        tg = flow.FlowTargets(T(g["depth_prev"]), g["w2c_prev"], g["K"], T(g["flow"])[0], rm)
+        M = int(tg.pts.shape[0])
+        scratch = torch.empty((int(lib.fsgs_flow_scratch_bytes(M)),), dtype=torch.uint8, device=DEV)
+        out = torch.empty((2,), device=DEV)
+        base = torch.arange(16, dtype=torch.float32, device=DEV).reshape(4, 4) * 0.01
+        for up, acc in ((1.0, 0.0), (0.1, 1.0), (2.0, -0.5)):
+            dw = base.clone() if acc != 0.0 else torch.full((4, 4), float("nan"), device=DEV)  # acc = 0 never reads
+            with torch.cuda.device(DEV):
+                _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(tg.pts), _lib.ptr(tg.vu), _lib.ptr(w2c), tg.K9,
+                                                         _lib.ptr(tg.flow), tg.W, tg.H, 20.0, up, acc, _lib.ptr(scratch),
+                                                         _lib.ptr(out), _lib.ptr(dw), _lib.current_stream()),
+                           "fsgs_flow_pose_loss_fused")
+            np.testing.assert_allclose(out[0].item(), g[f"loss_{tag}"], rtol=2e-5)
+            want = up * g[f"dw2c_{tag}"]
+            want[3] = 0.0
+            if acc != 0.0:
+                want = want + acc * base.cpu().numpy()
+            np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-3, atol=2e-4 * max(1.0, abs(up)))
+    # nothing valid: loss 0, gradient 0 (scene/pose_optimizer.py:196-214)
+    dw = torch.ones((4, 4), device=DEV)
+    with torch.cuda.device(DEV):
+        _lib.check(lib.fsgs_flow_pose_loss_fused(0, None, None, _lib.ptr(w2c), tg.K9, _lib.ptr(tg.flow), tg.W, tg.H, 20.0,
+                                                 1.0, 0.0, _lib.ptr(scratch), _lib.ptr(out), _lib.ptr(dw),
+                                                 _lib.current_stream()), "fsgs_flow_pose_loss_fused")
+    assert out[0].item() == 0.0 and float(dw.abs().max()) == 0.0
