@@ -124,9 +124,30 @@ __global__ void selftest_transpose_reduce_kernel(const float *in, float *out) {
   for (int i = 0; i < 64; i++) v[i] = in[lane * 64 + i];
   out[lane] = fsgs::wave_transpose_reduce64(v, lane);
 }
+template <int N>
+__global__ void selftest_transpose_reduce_n_kernel(const float *in, float *out) {
+  const int lane = threadIdx.x & 63;
+  float v[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = in[lane * 64 + i];
+  if (N == 32) out[lane] = fsgs::wave_transpose_reduce32(reinterpret_cast<const float(&)[32]>(v), lane);
+  if (N == 16) out[lane] = fsgs::wave_transpose_reduce16(reinterpret_cast<const float(&)[16]>(v), lane);
+}
 }  // namespace
 
 extern "C" {
+int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int width, fsgs_stream_t stream) {
+  if (!in64x64 || !out64) return FSGS_ERR_INVALID;
+  if (width == 64) return fsgs_selftest_transpose_reduce(in64x64, out64, stream);
+  if (width == 32)
+    hipLaunchKernelGGL(selftest_transpose_reduce_n_kernel<32>, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);
+  else if (width == 16)
+    hipLaunchKernelGGL(selftest_transpose_reduce_n_kernel<16>, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);
+  else
+    return FSGS_ERR_INVALID;
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
 int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stream_t stream) {
   if (!in64x64 || !out64) return FSGS_ERR_INVALID;
   hipLaunchKernelGGL(selftest_transpose_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);

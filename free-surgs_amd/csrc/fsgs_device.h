@@ -93,6 +93,21 @@ __device__ __forceinline__ float wave_transpose_reduce32(const float (&v)[32], i
   return dpp_add<0xB1>(u);                                                  // lanes l, l^1: plain sum
 }
 
+// 16-value variant: lane l ends with the total of v[l >> 2] (four lanes hold the same value); ~40 VALU.
+__device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], int lane) {
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = swap32_add(v[i], v[i + 8]);     // lane bit 5 <-> index bit 3
+#pragma unroll
+  for (int i = 0; i < 4; i++) x[i] = swap16_add(w[i], w[i + 4]);     // lane bit 4 <-> index bit 2
+  const bool b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+  for (int i = 0; i < 2; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 2], b3);  // lane bit 3 <-> index bit 1
+  float z = fold_dpp<0x141>(y[0], y[1], b2);                                // lane bit 2 <-> index bit 0
+  z = dpp_add<0x4E>(z);                                                     // lanes l, l^2, l^1, l^3: plain sum
+  return dpp_add<0xB1>(z);
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_max_i(int v) {
   int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);

@@ -611,14 +611,25 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // SPLIT (fused 6-channel pass): channels 0..2 are the RGB pass, 3..5 the depth/silhouette pass of the
 // reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
 // `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
-template <int C, bool SPLIT>
+// POSE_ONLY (the tracking step: gs_grad = False, no parameter gradients, no dL/d(depth, silhouette)): only the
+// camera-pose gradient is wanted, which needs the five moments and nothing else -- the colours do not depend on
+// the pose, the opacity gradient and the densification statistic are not used (SURVEY a1 note v).  8 slots per
+// Gaussian, so the transposing reduction of a Gaussian pair shrinks to 16 values, and only the RGB channels
+// carry a gradient.
+template <int C, bool SPLIT, bool POSE_ONLY = false>
 __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
     const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
     float *__restrict__ dcolors) {
+  static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   constexpr int REC4 = C > 4 ? 4 : 3;
+  constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : C;  // channels that carry dL/dpixel
+  constexpr int GP = 2;                                // Gaussians per transposing reduction
+  constexpr int SL = POSE_ONLY ? 8 : 16;               // slots per Gaussian
+  constexpr int NV = GP * SL;                          // values per lane entering the reduction
+  constexpr int REP = 64 / NV;                         // lanes that end up with the same total
   __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
   const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
@@ -633,7 +644,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   // gB = sum_ch g_ch B_ch is needed, so one register per pixel replaces accum_rec / last_color / last_alpha:
   //   gc = sum_ch g_ch c_ch;  dL/dalpha = T gc - (gB + T_final bg.g) / (1 - alpha);  gB += alpha T gc.
   // tb[k] = T_final * (bg . dL/dpixel); gBr / tbr: the same restricted to the RGB channels (SPLIT).
-  float px[4], py[4], T[4], tb[4], tbr[4], gB[4], gBr[4], g[4][C];
+  float px[4], py[4], T[4], tb[4], tbr[4], gB[4], gBr[4], g[4][CG];
   int last[4], qlast[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     qlast[k] = wave_max(last[k]);  // deepest contributor of quadrant k (scalar)
     float bgdot = 0.0f, bgdot_rgb = 0.0f;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) {
+    for (int ch = 0; ch < CG; ch++) {
       // channels >= 3 of the fused pass come from their own tensor; a missing tensor is a zero gradient
       const float *gp = ch < 3 ? dL_dcolor : dL_dcolor2;
       g[k][ch] = (inside && gp) ? gp[(ch < 3 ? ch : ch - 3) * HW + pix] : 0.0f;
@@ -661,11 +672,13 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
-  // gradient component slots of one Gaussian (16 per Gaussian, 2 Gaussians per transposing reduction):
-  //   0,1 mean2D x,y | 2,3,4 conic A,B,C | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
-  // after the reduction lanes l and l^1 both own (Gaussian u = l >> 5, component c = (l >> 1) & 15)
-  const int my_u = lane >> 5, my_c = (lane >> 1) & 15;
-  const bool c_used = !(lane & 1) && (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C));
+  // gradient component slots of one Gaussian (SL per Gaussian, GP Gaussians per transposing reduction):
+  //   0..4 moments of w (mean2D x,y | conic A,B,C) | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
+  //   POSE_ONLY: the five moments only
+  // after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
+  const int my_u = (lane / REP) / SL, my_c = (lane / REP) % SL;
+  const bool c_used = !(lane & (REP - 1)) && (POSE_ONLY ? my_c < 5
+                                                : (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C)));
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -686,13 +699,13 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       rec[lane * REC4 + 2] = make_float4(c6[2], c6[3], c6[4], c6[5]);
     }
     __syncthreads();
-    for (int jj = n - 1; jj >= 0; jj -= 2) {
-      float v[32];
+    for (int jj = n - 1; jj >= 0; jj -= GP) {
+      float v[NV];
 #pragma unroll
-      for (int i = 0; i < 32; i++) v[i] = 0.f;
+      for (int i = 0; i < NV; i++) v[i] = 0.f;
       bool any_group = false;
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < GP; u++) {
         const int j = jj - u;
         if (j < 0) continue;       // wave-uniform
         const int pos = lo + j;    // 0-based index in the tile list
@@ -705,7 +718,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
         const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
         const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y;
         const float bcol[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-        float *s = &v[16 * u];
+        float *s = &v[SL * u];
         bool any = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -717,10 +730,10 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
           const float wgt = e.alpha * T[k];
           float gc = 0.0f, gc_rgb = 0.0f;
 #pragma unroll
-          for (int ch = 0; ch < C; ch++) {
+          for (int ch = 0; ch < CG; ch++) {
             gc = fmaf(g[k][ch], bcol[ch], gc);
             if (SPLIT && ch == 2) gc_rgb = gc;
-            s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
+            if (!POSE_ONLY) s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
           }
           const float dL_dalpha = fmaf(T[k], gc, -inv1ma * (gB[k] + tb[k]));
           gB[k] = fmaf(wgt, gc, gB[k]);
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
           // and are applied once, after the tile and atomic sums, by unpack_moments()
           const float w = e.G * dL_dalpha;
           const float wdx = w * e.dx, wdy = w * e.dy;
-          s[5] += w;
+          if (!POSE_ONLY) s[5] += w;
           s[0] += wdx;
           s[1] += wdy;
           s[2] = fmaf(wdx, e.dx, s[2]);
@@ -743,14 +756,21 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
         }
         any_group = any_group || (__ballot(any) != 0ull);
       }
-      if (!any_group) continue;  // wave-uniform: neither of the two touched any pixel of the tile
-      // 64 x 32 transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
-      const float tot = wave_transpose_reduce32(v, lane);
+      if (!any_group) continue;  // wave-uniform: none of the GP Gaussians touched any pixel of the tile
+      // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
+      float tot;
+      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16(v, lane);
+      else tot = wave_transpose_reduce32(v, lane);
       const int j_mine = jj - my_u;
-      const uint32_t g0 = readlane(gid, jj), g1 = readlane(gid, max(jj - 1, 0));
-      const uint32_t gsel = my_u ? g1 : g0;
+      uint32_t gsel = readlane(gid, jj);
+#pragma unroll
+      for (int u = 1; u < GP; u++) {
+        const uint32_t gu = readlane(gid, max(jj - u, 0));
+        gsel = my_u == u ? gu : gsel;
+      }
       if (j_mine >= 0 && c_used && tot != 0.f) {
-        float *dst = my_c < 8 ? grad_acc + (size_t)gsel * kAccStride + my_c : dcolors + (size_t)gsel * C + (my_c - 8);
+        float *dst = (POSE_ONLY || my_c < 8) ? grad_acc + (size_t)gsel * kAccStride + my_c
+                                             : dcolors + (size_t)gsel * C + (my_c - 8);
         atomicAdd(dst, tot);
       }
     }
@@ -1042,11 +1062,11 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
-template <int C, bool SPLIT = false>
+template <int C, bool SPLIT = false, bool POSE_ONLY = false>
 int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
                      colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
   return 0;
 }

@@ -402,12 +402,21 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   if (cam_grad) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
   if (num_rendered > 0 && (dL_dimage || dL_ddepth_sil)) {
     ProfScope ps(PROF_BLEND_BWD, stream);
-    launch_blend_bwd<6, true>(cam, ntiles, ntiles <= ORDER_MAX_TILES ? (const uint32_t *)(sb + SL.order) : nullptr,
-                              (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
-                              (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),
-                              (const float *)(sb + SL.colors), (const float *)(sb + SL.final_T),
-                              (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
-                              stream);
+    const uint32_t *order = ntiles <= ORDER_MAX_TILES ? (const uint32_t *)(sb + SL.order) : nullptr;
+    // tracking (pose gradient only, rgb loss only): the lean variant -- see blend_bwd_kernel
+    const bool pose_only = cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
+    if (pose_only)
+      launch_blend_bwd<6, false, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+                                       (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
+                                       (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                       (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
+                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+    else
+      launch_blend_bwd<6, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
+                                (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),
+                                (const float *)(sb + SL.colors), (const float *)(sb + SL.final_T),
+                                (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
+                                stream);
   }
   FSGS_HIP(hipGetLastError());
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);

@@ -75,6 +75,7 @@ _PROTOTYPES = {
     "fsgs_version": (C.c_char_p, []),
     "fsgs_last_error": (C.c_char_p, []),
     "fsgs_selftest_transpose_reduce": (_i, [_vp, _vp, _vp]),
+    "fsgs_selftest_transpose_reduce_n": (_i, [_vp, _vp, _i, _vp]),
     "fsgs_profile_enable": (_i, [C.c_uint64]),
     "fsgs_profile_count": (_i, []),
     "fsgs_profile_name": (C.c_char_p, [_i]),

@@ -74,6 +74,9 @@ const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP
 /* Self-test of the wave-level transposing reduction used by the backward blend:
  * in[lane*64 + i] (64 lanes x 64 values) -> out[l] = sum over lanes of in[lane*64 + l]. */
 int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stream_t stream);
+/* The narrower variants: width = 64, 32 or 16 values per lane (the first `width` columns of in); lane l
+ * receives the total of column l / (64 / width). */
+int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int width, fsgs_stream_t stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launching stream.
  * mask: bit i enables kernel id i (ids: fsgs_profile_name); 0 disables.  Enabling resets totals.

@@ -218,6 +218,11 @@ def test_wave_transposing_reduction_selftest():
     out = torch.zeros(64, device=DEV)
     _lib.check(lib.fsgs_selftest_transpose_reduce(_lib.ptr(a), _lib.ptr(out), _lib.current_stream()), "selftest")
     np.testing.assert_allclose(out.cpu().numpy(), m.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    for width in (32, 16):  # lane l receives column l / (64 / width)
+        _lib.check(lib.fsgs_selftest_transpose_reduce_n(_lib.ptr(a), _lib.ptr(out), width, _lib.current_stream()),
+                   "selftest")
+        want = m.astype(np.float64).sum(0)[np.arange(64) // (64 // width)]
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
 
 
 def test_heavy_tile_takes_the_global_memory_sort_path(oracle32):
