@@ -199,7 +199,7 @@ def main():
         # gfx950 FETCH_SIZE x2 correction calibrated on the Adam kernel) for exactly this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "blend_bwd_kernel<%d; %s>" % (C, "true" if fused else "false")
+            key = "blend_bwd_kernel<%d; %s; false>" % (C, "true" if fused else "false")
             if pmc.get("config") == args.config and key in pmc["kernels"] and world == 1:
                 roofline["traffic"] = pmc["kernels"][key]["traffic_bytes"]
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"

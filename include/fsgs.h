@@ -103,9 +103,10 @@ int fsgs_raster_state_layout(int P, int width, int height, int64_t max_pairs, si
 /* Forward: kernels R1-R6 of SURVEY.md s2.1.
  *  means3D[P,3] colors[P,C] opacities[P] scales[P,3] rotations[P,4] (r,x,y,z), fp32 row-major.
  *  out_color[C,H,W] planar, out_depth[H,W] (depth-fork third output), radii[P] int32.
- *  num_rendered [host]: receives R = sum of tiles touched.  The call synchronises the
- *  stream once to read R (as UPSTREAM does); if R > max_pairs it returns
- *  FSGS_ERR_CAPACITY without rendering and the caller retries with bigger buffers. */
+ *  num_rendered [host]: receives R = number of (tile, Gaussian) pairs.  The host learns R from a pinned
+ *  mailbox word the scan kernel writes (no stream synchronisation; the call returns while the blend is still
+ *  queued); if R > max_pairs the call returns FSGS_ERR_CAPACITY, nothing is rendered (the binning kernels
+ *  refuse on the device) and the caller retries with bigger buffers. */
 int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P,
                         const float *means3D, const float *colors, const float *opacities,
                         const float *scales, const float *rotations,
