@@ -52,6 +52,12 @@ class FsgsRenderGrads(C.Structure):
                                           "means2D", "w2c")]
 
 
+class FsgsDensifyGroup(C.Structure):
+    _fields_ = [("in_param", C.c_void_p), ("in_exp_avg", C.c_void_p), ("in_exp_avg_sq", C.c_void_p),
+                ("out_param", C.c_void_p), ("out_exp_avg", C.c_void_p), ("out_exp_avg_sq", C.c_void_p),
+                ("row", C.c_int32), ("role", C.c_int32)]
+
+
 class FsgsAdamGroup(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_int64), ("lr", C.c_float), ("step", C.c_int32)]
@@ -119,6 +125,9 @@ _PROTOTYPES = {
     "fsgs_pose_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fsgs_pose_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fsgs_adam_step": (_i, [_i, C.POINTER(FsgsAdamGroup), C.c_double, C.c_double, C.c_double, _vp]),
+    "fsgs_densify_plan": (_i, [_i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
+    "fsgs_densify_apply": (_i, [_i, _vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(FsgsDensifyGroup), _vp, _vp, _vp,
+                                _vp]),
     "fsgs_densify_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pearson_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }

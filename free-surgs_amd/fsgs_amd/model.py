@@ -188,6 +188,72 @@ class GaussianCloud:
             prune = prune | big_vs | big_ws
         self.prune_points(prune)
 
+    def densify_and_prune_device(self, max_grad, min_opacity, max_screen_size):
+        """densify_and_prune as ONE plan + ONE gather on the device (csrc/densify.hip): same decisions, same
+        output order and the same torch.normal draws as the reference sequence above, without its ~12
+        cat / boolean-index reallocations of every tensor and Adam moment.  One host read (the four totals)."""
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        P = self.num_points
+        dev = self.params["_xyz"].device
+        if not self.params["_xyz"].is_cuda:
+            raise RuntimeError("device-side densification needs CUDA/HIP tensors; there is no CPU fallback")
+        radius = float(self.variables["scene_radius"])
+        acc = self.variables["xyz_gradient_accum"].detach().reshape(-1).contiguous().float()
+        den = self.variables["denom"].detach().reshape(-1).contiguous().float()
+        counts = torch.empty((4, P), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream()
+            _lib.check(lib.fsgs_densify_plan(P, _lib.ptr(acc), _lib.ptr(den), _lib.ptr(self.params["_scaling"].detach()),
+                                             _lib.ptr(self.params["_opacity"].detach()), float(max_grad),
+                                             float(min_opacity), float(np.float32(radius * 0.01)),
+                                             float(np.float32(0.1 * radius)), int(bool(max_screen_size)),
+                                             _lib.ptr(counts), stream), "fsgs_densify_plan")
+            incl = torch.cumsum(counts, dim=1, dtype=torch.int32)
+            totals = [int(v) for v in incl[:, -1].tolist()] if P > 0 else [0, 0, 0, 0]  # the one host read
+            K0, K1, NS, K3 = totals
+            Pn = K0 + K1 + 2 * K3
+            # the reference's torch.normal(mean=zeros[2 NS,3], std=stds): randn of that shape, then * std
+            normals = torch.randn((2 * NS, 3), device=dev) if NS > 0 else torch.zeros((0, 3), device=dev)
+            roles = {"_xyz": 1, "_scaling": 2, "_rotation": 3}
+            new_p, new_m, new_v, keep = {}, {}, {}, []
+            arr = (_lib.FsgsDensifyGroup * len(PARAM_NAMES))()
+            for k, name in enumerate(PARAM_NAMES):
+                old = self.params[name].detach()
+                row = int(old.numel() // max(P, 1))
+                st = self.optimizer.state.get(self.params[name], None) if self.optimizer is not None else None
+                has = st is not None and "exp_avg" in st
+                new_p[name] = torch.empty((Pn,) + tuple(old.shape[1:]), dtype=torch.float32, device=dev)
+                if has:
+                    new_m[name], new_v[name] = torch.empty_like(new_p[name]), torch.empty_like(new_p[name])
+                    m, v = st["exp_avg"].contiguous(), st["exp_avg_sq"].contiguous()
+                    keep += [m, v]
+                arr[k].in_param = old.data_ptr()
+                arr[k].in_exp_avg = m.data_ptr() if has else None
+                arr[k].in_exp_avg_sq = v.data_ptr() if has else None
+                arr[k].out_param = new_p[name].data_ptr()
+                arr[k].out_exp_avg = new_m[name].data_ptr() if has else None
+                arr[k].out_exp_avg_sq = new_v[name].data_ptr() if has else None
+                arr[k].row, arr[k].role = row, roles.get(name, 0)
+            src = torch.empty((max(Pn, 1),), dtype=torch.int32, device=dev)
+            aux = torch.empty((max(Pn, 1),), dtype=torch.int32, device=dev)
+            tot = (C.c_int32 * 4)(*totals)
+            _lib.check(lib.fsgs_densify_apply(P, _lib.ptr(counts), _lib.ptr(incl), tot, len(PARAM_NAMES), arr,
+                                              _lib.ptr(normals), _lib.ptr(src), _lib.ptr(aux), stream),
+                       "fsgs_densify_apply")
+        self._swap_params(new_p, lambda n, old_m: None)
+        for group in self.optimizer.param_groups:  # the moments were gathered by the same launch
+            st = self.optimizer.state.get(group["params"][0], None)
+            if st is not None and "exp_avg" in st:
+                st["exp_avg"], st["exp_avg_sq"] = new_m[group["name"]], new_v[group["name"]]
+        self.variables["xyz_gradient_accum"] = torch.zeros((Pn, 1), device=dev)
+        self.variables["denom"] = torch.zeros((Pn, 1), device=dev)
+        self.variables["max_radii2D"] = torch.zeros((Pn,), device=dev)
+        return {"kept": K0, "cloned": K1, "split": NS, "children_kept": 2 * K3}
+
     def reset_opacity(self):
         op = self.get_opacity.detach()
         new = inverse_sigmoid(torch.min(op, torch.ones_like(op) * 0.01))

@@ -200,7 +200,10 @@ class Runner:
         if it % 300 == 0 and it < 15000:
             fdist.sync_densification_stats(self.pc)
             size_threshold = 20 if it > 4000 else None
-            self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
+            if self.fast is not None:  # one plan + one gather on the device (csrc/densify.hip)
+                self.pc.densify_and_prune_device(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
+            else:
+                self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
         if it % 3000 == 0:
             self.pc.reset_opacity()
 

@@ -24,6 +24,7 @@
  *   fsgs_pearson_*                    <- utils/loss_utils.py:98-127
  *   fsgs_flow_pose_loss_*             <- scene/pose_optimizer.py:164-218
  *   fsgs_adam_step                    <- torch.optim.Adam steps of train.py:194,272
+ *   fsgs_densify_plan / _apply        <- GaussianModel.densify_and_prune, scene/gaussian_model.py:523-676
  */
 #ifndef FSGS_H
 #define FSGS_H
@@ -265,6 +266,41 @@ int fsgs_adam_step(int ngroups, const FsgsAdamGroup *groups, double beta1, doubl
  * denom += 1   (scene/gaussian_model.py:678-681, train.py:298-303).  viewspace_grad [P,3]. */
 int fsgs_densify_stats(int P, const int32_t *radii, const float *viewspace_grad, float *max_radii2D,
                        float *xyz_gradient_accum, float *denom, fsgs_stream_t stream);
+
+/* ---- device-side densify / prune with optimizer-state compaction (scene/gaussian_model.py:523-676) --------- */
+
+/* Step 1: the per-Gaussian decisions of GaussianModel.densify_and_prune(max_grad, min_opacity, max_screen_size).
+ * scaling [P,3] / opacity [P] are the RAW parameters (_scaling, _opacity).  small_extent = 0.01 * scene_radius
+ * (clone vs split), big_extent = 0.1 * scene_radius, prune_big = (max_screen_size != 0).  The reference's
+ * screen-size term compares max_radii2D AFTER densification_postfix has zeroed it, i.e. it never fires; it is
+ * therefore not an input.  counts4 int32 [4,P]: original kept | clone kept | selected for the split | children
+ * kept (per copy).  The caller forms their inclusive prefix sums (incl4, same shape) and reads the four totals. */
+int fsgs_densify_plan(int P, const float *xyz_gradient_accum, const float *denom, const float *scaling,
+                      const float *opacity, float max_grad, float min_opacity, float small_extent, float big_extent,
+                      int prune_big, int32_t *counts4, fsgs_stream_t stream);
+
+#define FSGS_DENSIFY_ROLE_PLAIN 0
+#define FSGS_DENSIFY_ROLE_XYZ 1
+#define FSGS_DENSIFY_ROLE_SCALING 2
+#define FSGS_DENSIFY_ROLE_ROTATION 3
+typedef struct FsgsDensifyGroup {
+  const float *in_param;    /* [P, row] */
+  const float *in_exp_avg;  /* Adam moments of the old tensor, or NULL (no optimizer state yet) */
+  const float *in_exp_avg_sq;
+  float *out_param;         /* [P', row], P' = totals[0] + totals[1] + 2 * totals[3] */
+  float *out_exp_avg;       /* or NULL: kept rows keep their moments, new rows get zeros */
+  float *out_exp_avg_sq;
+  int32_t row;              /* floats per Gaussian */
+  int32_t role;             /* FSGS_DENSIFY_ROLE_*: xyz / scaling rows of split children are recomputed */
+} FsgsDensifyGroup;
+
+/* Step 2: gather every group into its new buffers in the reference's output order
+ * [kept originals | kept clones | kept children copy 1 | kept children copy 2].  totals4 (HOST) = last column of
+ * incl4.  normals [2 * totals4[2], 3]: the N(0,1) draws, in the row order of the reference's torch.normal call
+ * (all selected, copy-major).  src / aux: int32 [P'] scratch. */
+int fsgs_densify_apply(int P, const int32_t *counts4, const int32_t *incl4, const int32_t totals4[4], int ngroups,
+                       const FsgsDensifyGroup *groups, const float *normals, int32_t *src, int32_t *aux,
+                       fsgs_stream_t stream);
 
 #ifdef __cplusplus
 }
