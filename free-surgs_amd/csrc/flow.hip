@@ -214,6 +214,88 @@ __global__ __launch_bounds__(1024) void flow_fused_finish_kernel(const float *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sampson-distance rigid mask, once per tracked frame (train.py:157-165; PoseModel.compute_epipolar_loss /
+// get_matches, scene/pose_optimizer.py:700-746; adaptive_thresholding, utils/general_utils.py:96-116).
+// Every pixel x1 = (u, v, 1) of frame t-2 is matched to x2 = x1 + flow; with l1 = F x1, l2 = F^T x2 the squared
+// Sampson distance is (x2 . l1)^2 / (l1x^2 + l1y^2 + l2x^2 + l2y^2)  (the public definition the reference takes
+// from kornia.geometry.epipolar.sampson_epipolar_distance, squared = True; kornia is not part of the reference
+// tree: parity unpinned).  threshold = mean + factor * std (unbiased); the reference then evaluates
+// `dist < (dist <= threshold)`, a float-vs-bool comparison, i.e. rigid = dist <= threshold AND dist < 1.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SAMPSON_CHUNK = 4096;
+struct Mat9 {
+  float m[9];
+};
+__global__ __launch_bounds__(256) void sampson_kernel(int H, int W, Mat9 F, const float *__restrict__ flow,
+                                                      float *__restrict__ dist, double *__restrict__ partials) {
+  __shared__ double red[2][4];
+  const size_t HW = (size_t)H * W;
+  const size_t begin = (size_t)blockIdx.x * SAMPSON_CHUNK;
+  double s1 = 0.0, s2 = 0.0;
+  for (size_t p = begin + threadIdx.x; p < begin + SAMPSON_CHUNK && p < HW; p += 256) {
+    const int v = (int)(p / W), u = (int)(p - (size_t)v * W);
+    const float x1 = (float)u, y1 = (float)v;
+    const float x2 = x1 + flow[p], y2 = y1 + flow[HW + p];
+    const float* f = F.m;
+    const float l1x = f[0] * x1 + f[1] * y1 + f[2], l1y = f[3] * x1 + f[4] * y1 + f[5], l1z = f[6] * x1 + f[7] * y1 + f[8];
+    const float l2x = f[0] * x2 + f[3] * y2 + f[6], l2y = f[1] * x2 + f[4] * y2 + f[7];
+    const float num = x2 * l1x + y2 * l1y + l1z;
+    const float d = (num * num) / (l1x * l1x + l1y * l1y + l2x * l2x + l2y * l2y);
+    dist[p] = d;
+    s1 += (double)d;
+    s2 += (double)d * (double)d;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * (size_t)blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[2 * (size_t)blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+// every workgroup re-reduces the (few hundred, L2-resident) partials, then masks its own chunk
+__global__ __launch_bounds__(256) void sampson_mask_kernel(int H, int W, int nparts, float factor,
+                                                           const double *__restrict__ partials,
+                                                           const float *__restrict__ dist,
+                                                           uint8_t *__restrict__ rigid, float *__restrict__ stats3) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    s1 += partials[2 * (size_t)i];
+    s2 += partials[2 * (size_t)i + 1];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+  __syncthreads();
+  const double N = (double)H * (double)W;
+  const double S1 = red[0][0] + red[0][1] + red[0][2] + red[0][3], S2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double mean = S1 / N;
+  double var = N > 1.0 ? (S2 - N * mean * mean) / (N - 1.0) : 0.0;
+  var = var > 0.0 ? var : 0.0;
+  // mean().item() and std().item() are fp32 values widened to python floats; the sum is then formed in double
+  const float thr = (float)((double)(float)mean + (double)factor * (double)(float)sqrt(var));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats3[0] = (float)mean;
+    stats3[1] = (float)sqrt(var);
+    stats3[2] = thr;
+  }
+  const size_t HW = (size_t)H * W;
+  const size_t begin = (size_t)blockIdx.x * SAMPSON_CHUNK;
+  for (size_t p = begin + threadIdx.x; p < begin + SAMPSON_CHUNK && p < HW; p += 256) {
+    const float d = dist[p];
+    rigid[p] = (d <= thr && d < 1.0f) ? 1 : 0;  // dist < float(dist <= thr)
+  }
+}
+
 // every workgroup ends with a handful of same-address atomics, which serialise (tens of ns each): with 1024
 // workgroups that chain was longer than the streaming pass itself, so the grid is capped at one workgroup per CU
 int flow_blocks(size_t M) {
@@ -273,6 +355,26 @@ int fsgs_flow_pose_loss_fused(int64_t M, const float *pts_world, const int64_t *
     hipLaunchKernelGGL(flow_fused_finish_kernel, dim3(1), dim3(1024), 0, stream, (const float *)scratch, nb, upstream,
                        accumulate, out2, dw2c);
   }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+size_t fsgs_sampson_scratch_bytes(int H, int W) {
+  if (H <= 0 || W <= 0) return 0;
+  const size_t nb = ((size_t)H * W + SAMPSON_CHUNK - 1) / SAMPSON_CHUNK;
+  return nb * 2 * sizeof(double) + 64;
+}
+
+int fsgs_sampson_rigid_mask(int H, int W, const float *flow_fw, const float *F9_host, float factor, void *scratch,
+                            float *dist, uint8_t *rigid, float *stats3, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (H <= 0 || W <= 0 || !flow_fw || !F9_host || !scratch || !dist || !rigid || !stats3) return FSGS_ERR_INVALID;
+  Mat9 F;
+  for (int i = 0; i < 9; i++) F.m[i] = F9_host[i];
+  const int nb = (int)(((size_t)H * W + SAMPSON_CHUNK - 1) / SAMPSON_CHUNK);
+  hipLaunchKernelGGL(sampson_kernel, dim3(nb), dim3(256), 0, stream, H, W, F, flow_fw, dist, (double *)scratch);
+  hipLaunchKernelGGL(sampson_mask_kernel, dim3(nb), dim3(256), 0, stream, H, W, nb, factor, (const double *)scratch,
+                     dist, rigid, stats3);
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
 }

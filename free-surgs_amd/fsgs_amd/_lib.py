@@ -122,6 +122,8 @@ _PROTOTYPES = {
     "fsgs_flow_scratch_bytes": (_sz, [_i64]),
     "fsgs_flow_pose_loss_fused": (_i, [_i64, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, C.c_float,
                                        C.c_float, _vp, _vp, _vp, _vp]),
+    "fsgs_sampson_scratch_bytes": (_sz, [_i, _i]),
+    "fsgs_sampson_rigid_mask": (_i, [_i, _i, _vp, C.POINTER(C.c_float), C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pose_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fsgs_pose_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fsgs_adam_step": (_i, [_i, C.POINTER(FsgsAdamGroup), C.c_double, C.c_double, C.c_double, _vp]),

@@ -233,15 +233,25 @@ class Runner:
     def tracking(self, t):
         from .flow import FlowTargets
 
-        # Sampson-distance rigid mask (train.py:158-165) is once-per-frame kornia work outside the hot path
-        # (SURVEY.md s8f #3): all-ones here, as the reference uses for t <= 1
-        rigid = torch.ones((self.h, self.w), dtype=torch.bool, device=self.frames.colors[0].device)
+        # Sampson-distance rigid mask of frame t-2 under the optimised poses t-2, t-1 (train.py:157-165); all rigid
+        # for t <= 1.  Once per frame: two launches (csrc/flow.hip), no sync beyond reading the two 4x4 poses.
+        dev = self.frames.colors[0].device
+        rigid = None
+        if t > 1 and self.frames.flows_fw is not None:
+            from .epipolar import fundamental_from_w2c, rigid_mask
+
+            with torch.no_grad():
+                Fm = fundamental_from_w2c(self.poses.get_pose(t - 2), self.poses.get_pose(t - 1), self.frames.K)
+            rigid, self.last_sampson, _ = rigid_mask(self.frames.flows_fw[t - 2], Fm)
+        all_rigid = rigid is None
+        if all_rigid:
+            rigid = torch.ones((self.h, self.w), dtype=torch.bool, device=dev)
         depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
         targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
         out = None
         for _ in range(self.tracking_iter):
             if self.fast is not None:
-                out = self.fast.tracking_step(t, targets, None) + (None,)  # all-ones mask: skip the multiply
+                out = self.fast.tracking_step(t, targets, None if all_rigid else rigid) + (None,)
             else:
                 out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
         return out

@@ -23,6 +23,7 @@
  *   fsgs_photometric_loss_*           <- utils/loss_utils.py:41-96 (rgb_loss_func)
  *   fsgs_pearson_*                    <- utils/loss_utils.py:98-127
  *   fsgs_flow_pose_loss_*             <- scene/pose_optimizer.py:164-218
+ *   fsgs_sampson_rigid_mask           <- train.py:157-165, scene/pose_optimizer.py:700-746
  *   fsgs_adam_step                    <- torch.optim.Adam steps of train.py:194,272
  *   fsgs_densify_plan / _apply        <- GaussianModel.densify_and_prune, scene/gaussian_model.py:523-676
  */
@@ -235,6 +236,15 @@ size_t fsgs_flow_scratch_bytes(int64_t M);
 int fsgs_flow_pose_loss_fused(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
                               const float *K9_host, const float *flow_fw, int W, int H, float edge, float upstream,
                               float accumulate, void *scratch, float *out2, float *dw2c, fsgs_stream_t stream);
+
+/* Sampson-distance rigid mask of a tracked frame (train.py:157-165; scene/pose_optimizer.py:700-746;
+ * utils/general_utils.py:96-116).  flow_fw [2,H,W] forward flow of the earlier frame, F9_host the row-major 3x3
+ * fundamental matrix (HOST).  dist [H,W] squared Sampson distance; rigid uint8 [H,W] = (dist <= mean +
+ * factor * std) & (dist < 1) -- the reference's `dist < adaptive_thresholding(dist)`; stats3 float[3] on the
+ * device = {mean, std (unbiased), threshold}.  scratch: fsgs_sampson_scratch_bytes(H, W).  No host sync. */
+size_t fsgs_sampson_scratch_bytes(int H, int W);
+int fsgs_sampson_rigid_mask(int H, int W, const float *flow_fw, const float *F9_host, float factor, void *scratch,
+                            float *dist, uint8_t *rigid, float *stats3, fsgs_stream_t stream);
 
 /* ---- LearnPose.forward and its adjoint (scene/pose_optimizer.py:822-877) --------------------------------- */
 

@@ -125,3 +125,51 @@ def test_fused_flow_pass_matches_the_reference_golden_and_accumulates():
                                                  1.0, 0.0, _lib.ptr(scratch), _lib.ptr(out), _lib.ptr(dw),
                                                  _lib.current_stream()), "fsgs_flow_pose_loss_fused")
     assert out[0].item() == 0.0 and float(dw.abs().max()) == 0.0
+
+
+def _two_view_flow(H, W, K, w2c_1, w2c_2, depth, moving=None):
+    """forward flow of a static scene seen from two poses (optionally with an independently moving block)."""
+    Kt = T(np.asarray(K, np.float32))
+    v, u = torch.meshgrid(torch.arange(H, device=DEV).float(), torch.arange(W, device=DEV).float(), indexing="ij")
+    z = depth
+    cam1 = torch.stack([(u - Kt[0, 2]) / Kt[0, 0] * z, (v - Kt[1, 2]) / Kt[1, 1] * z, z, torch.ones_like(z)], 0).reshape(4, -1)
+    A, B = T(np.asarray(w2c_1, np.float32)), T(np.asarray(w2c_2, np.float32))
+    world = torch.linalg.inv(A) @ cam1
+    cam2 = (B @ world)[:3]
+    p = Kt @ cam2
+    fl = torch.stack([p[0] / p[2] - u.reshape(-1), p[1] / p[2] - v.reshape(-1)], 0).reshape(2, H, W)
+    if moving is not None:
+        y0, y1, x0, x1, du, dv = moving
+        fl[0, y0:y1, x0:x1] += du
+        fl[1, y0:y1, x0:x1] += dv
+    return fl.contiguous()
+
+
+def test_sampson_rigid_mask_matches_torch_statement_and_flags_the_moving_block():
+    from fsgs_amd import epipolar, synth
+
+    H, W = 256, 320
+    K = synth.intrinsics(W, H)
+    w1 = synth.pose_matrix((1, 0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+    w2 = synth.pose_matrix((1, 0.004, -0.006, 0.002), (0.02, -0.01, 0.004))
+    u = torch.arange(W, device=DEV).float()[None] / W
+    v = torch.arange(H, device=DEV).float()[:, None] / H
+    depth = 1.0 + 0.3 * torch.sin(6.28 * u) * torch.cos(6.28 * v)
+    fl = _two_view_flow(H, W, K, w1, w2, depth, moving=(100, 140, 180, 240, 6.0, -4.0))
+    fl = fl + 0.02 * torch.randn_like(fl)  # flow-estimator noise
+    F = epipolar.fundamental_from_w2c(w1, w2, K)
+    rigid, dist, stats = epipolar.rigid_mask(fl, F, 2.0)
+    want = epipolar.sampson_distance_torch(fl, F)
+    scale = want.abs().max().item()
+    assert (dist - want).abs().max().item() <= 2e-4 * scale
+    np.testing.assert_allclose(stats[0].item(), want.mean().item(), rtol=1e-4)
+    np.testing.assert_allclose(stats[1].item(), want.std().item(), rtol=1e-4)
+    wm = epipolar.rigid_mask_torch(want, 2.0)
+    assert (rigid != wm).float().mean().item() <= 1e-4  # pixels within rounding of the threshold
+    # epipolar-consistent pixels are rigid, the independently moving block mostly is not
+    assert rigid[:90].float().mean().item() > 0.99
+    assert rigid[100:140, 180:240].float().mean().item() < 0.2
+    # exact two-view flow without the block and without noise: distances are rounding-level
+    fl0 = _two_view_flow(H, W, K, w1, w2, depth)
+    _, d0, _ = epipolar.rigid_mask(fl0, F, 2.0)
+    assert d0.max().item() < 1e-3

@@ -172,3 +172,45 @@ def test_densify_prune_and_opacity_reset_match_reference():
     pc.reset_opacity()
     np.testing.assert_allclose(pc.params["_opacity"].detach().numpy(), g["r_opacity"], rtol=1e-6)
     assert not np.any(pc.optimizer.state[pc.params["_opacity"]]["exp_avg"].numpy())
+
+
+def test_fundamental_matrix_and_sampson_statement_known_answers():
+    """fsgs_amd/epipolar.py restates kornia's essential_from_Rt / fundamental_from_essential /
+    sampson_epipolar_distance (kornia is not in the reference tree).  Known answers: exact two-view correspondences
+    satisfy x2^T F x1 = 0 and have zero Sampson distance; a pixel displaced by d perpendicular to its epipolar
+    line has squared distance ~ d^2 / 2 (both images share the error); the reference's `dist < mask` quirk."""
+    from fsgs_amd import epipolar, synth
+
+    H, W = 48, 64
+    K = synth.intrinsics(W, H).astype(np.float64)
+    w1 = synth.pose_matrix((1, 0.01, -0.02, 0.005), (0.01, 0.02, -0.01)).astype(np.float64)
+    w2 = synth.pose_matrix((1, -0.02, 0.01, 0.02), (0.05, -0.03, 0.02)).astype(np.float64)
+    F = epipolar.fundamental_from_w2c(w1, w2, K).astype(np.float64)
+    rng = np.random.default_rng(0)
+    Xw = np.concatenate([rng.uniform(-0.3, 0.3, (50, 2)), rng.uniform(0.8, 1.5, (50, 1)), np.ones((50, 1))], 1)
+    p1 = (K @ (w1 @ Xw.T)[:3]).T
+    p2 = (K @ (w2 @ Xw.T)[:3]).T
+    x1 = p1 / p1[:, 2:]
+    x2 = p2 / p2[:, 2:]
+    resid = np.einsum("ni,ij,nj->n", x2, F, x1)
+    scale = np.linalg.norm(F) * np.linalg.norm(x1, axis=1) * np.linalg.norm(x2, axis=1)
+    assert np.max(np.abs(resid) / scale) < 1e-5
+    # dense statement on a pixel grid: flow from exact geometry -> ~0; plus a perpendicular offset d -> d^2/2
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    z = 1.0 + 0.2 * np.sin(u / 9.0) * np.cos(v / 7.0)
+    cam1 = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z, np.ones_like(z)], 0).reshape(4, -1)
+    q = K @ (w2 @ np.linalg.inv(w1) @ cam1)[:3]
+    flow = np.stack([q[0] / q[2] - u.reshape(-1), q[1] / q[2] - v.reshape(-1)], 0).reshape(2, H, W)
+    d0 = epipolar.sampson_distance_torch(T(flow.astype(np.float32)), F).numpy()
+    assert d0.max() < 1e-3
+    l = (F @ np.stack([u.reshape(-1), v.reshape(-1), np.ones(H * W)], 0))[:2]  # epipolar line normals in image 2
+    n = l / np.linalg.norm(l, axis=0, keepdims=True)
+    d = 0.8
+    flow_off = flow + (d * n).reshape(2, H, W)
+    d1 = epipolar.sampson_distance_torch(T(flow_off.astype(np.float32)), F).numpy()
+    np.testing.assert_allclose(d1, np.full_like(d1, d * d / 2), rtol=0.15)
+    # dist < (dist <= thr): rigid needs BOTH dist <= thr and dist < 1
+    dist = torch.tensor([[0.1, 0.5, 0.99, 1.0, 1.5, 30.0]])
+    thr = dist.mean().item() + 2.0 * dist.std().item()
+    m = epipolar.rigid_mask_torch(dist, 2.0)
+    assert thr > 1.5 and m.tolist() == [[True, True, True, False, False, False]]
