@@ -64,10 +64,12 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
                        scales, rotations, g);
   }
   FSGS_HIP(hipGetLastError());
-  rc = run_binning(cam, P, B, max_pairs, num_rendered, stream);
+  BinningTicket tk;
+  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream);
+  if (rc == FSGS_ERR_CAPACITY) *num_rendered = (int64_t)ntiles * BIN_SUBS * 32;  // not even one key per segment
   if (rc != FSGS_OK) return rc;
   const int2 *ranges = B.ranges;
-  const uint32_t *order = (ntiles <= ORDER_MAX_TILES && *num_rendered > 0) ? B.order : nullptr;
+  const uint32_t *order = B.order;
   const uint32_t *plist = B.plist;
   const float2 *xy = B.xy;
   const float4 *co = B.co;
@@ -81,7 +83,8 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
     case 6: launch_blend_fwd<6>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
   }
   FSGS_HIP(hipGetLastError());
-  return FSGS_OK;
+  // only now does the host look at R (the blend is already queued behind the binning)
+  return finish_binning(cam, B, max_pairs, tk, num_rendered, stream);
 }
 
 int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, const float *colors,

@@ -133,35 +133,33 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams ca
 }
 
 // ------------------------------------------------------------------------------------------------
-// R2-R5  binning: per-tile lists built directly, no global sort
-//   count   : one thread per Gaussian walks its 3-sigma tile rect, keeps the tiles its alpha >= 1/255
-//             footprint can reach (rect_touched, exact) and bumps tile_count[tile]
-//   scan    : ONE workgroup turns the counts into [start,end) ranges (tiles <= 8 K) and the total R
-//   scatter : same walk, claims slot = start + atomic cursor and writes the 64-bit key
-//             (depth bits << 32 | Gaussian index)
-//   sort    : one workgroup per tile sorts its keys in LDS (normalised bitonic network, virtual +inf
-//             padding) and leaves the Gaussian indices in `plist`
+// R2-R5  binning: per-tile lists built directly -- one pass, no global sort, no count pass, no scan
+//   scatter : the (Gaussian, tile) candidates of a wave are flattened over its lanes; a candidate that passes the
+//             exact footprint test (rect_touched: some pixel of the tile can reach alpha >= 1/255) claims
+//             slot = atomic cursor of its (tile, sub-list) and writes the 64-bit key (depth bits << 32 | index)
+//             into that sub-list's FIXED-CAPACITY segment: segment (tile, s) starts at (tile*8 + s) * cap_sub,
+//             cap_sub = max_pairs / (8 tiles).  288 GB of HBM buy the slack; a segment that overflows is
+//             reported (FSGS_ERR_CAPACITY + the capacity that would have sufficed) and the caller retries.
+//   sort    : one workgroup per tile gathers its eight segments into LDS, sorts (normalised bitonic network,
+//             virtual +inf padding), leaves the Gaussian indices in `plist` at the tile's base and writes
+//             ranges[tile] = [base, base + n)
+//   order   : one workgroup: longest-first dispatch order of the tiles, R = sum n, and the mailbox word
 // The resulting order inside a tile is (depth, index) ascending = UPSTREAM's order including ties,
 // independent of the order in which the atomics landed.
 // ------------------------------------------------------------------------------------------------
-// Count and scatter share one walker.  A thread-per-Gaussian loop over the tile rect is bound by the LARGEST rect
-// of the launch (one lane walks it alone, and in the scatter pass every step waits for a returning atomic), so
-// the (Gaussian, tile) candidates of the 64 Gaussians of a wave are flattened instead: an inclusive scan of the
-// rect areas, then lane l of step s takes candidate 64*s + l, finds its Gaussian by binary search in LDS and
-// tests that one tile.  BIN_UNROLL candidates per lane keep several atomics in flight.
+// A thread-per-Gaussian loop over the tile rect is bound by the LARGEST rect of the launch (one lane walks it
+// alone, and every step waits for a returning atomic), so the candidates of the 64 Gaussians of a wave are
+// flattened instead: an inclusive scan of the rect areas, then lane l of step s takes candidate 64*s + l, finds
+// its Gaussian by binary search in LDS and tests that one tile.  BIN_UNROLL candidates per lane keep several
+// atomics in flight.
 constexpr int BIN_UNROLL = 4;
-template <bool SCATTER>
-__global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uint32_t *__restrict__ tiles,
-                                                        const ushort4 *__restrict__ rect,
-                                                        const float2 *__restrict__ xy,
-                                                        const float4 *__restrict__ conic_op,
-                                                        const float *__restrict__ depth,
-                                                        uint32_t *__restrict__ tile_count,
-                                                        unsigned long long *__restrict__ keys,
-                                                        const uint32_t *__restrict__ total_pairs,
-                                                        uint32_t max_pairs) {
-  // launched before the host has seen R: a list that does not fit the caller's buffers is never written
-  if (SCATTER && *total_pairs > max_pairs) return;
+__global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const uint32_t *__restrict__ tiles,
+                                                          const ushort4 *__restrict__ rect,
+                                                          const float2 *__restrict__ xy,
+                                                          const float4 *__restrict__ conic_op,
+                                                          const float *__restrict__ depth,
+                                                          uint32_t *__restrict__ cursors,
+                                                          unsigned long long *__restrict__ keys, uint32_t cap_sub) {
   __shared__ float4 rec_a[256];  // mean2D x,y | conic A,B
   __shared__ float4 rec_b[256];  // conic C | tau | depth bits | Gaussian index
   __shared__ uint4 rec_c[256];   // rect x0,y0 | width | ceil(2^32 / width)
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
     const uint32_t w = (uint32_t)(rc.z - rc.x), h = (uint32_t)(rc.w - rc.y);
     if (tau >= 0.f) area = w * h;
     rec_a[threadIdx.x] = make_float4(p.x, p.y, co.x, co.y);
-    rec_b[threadIdx.x] = make_float4(co.z, tau, SCATTER ? depth[i] : 0.f, __uint_as_float((uint32_t)i));
+    rec_b[threadIdx.x] = make_float4(co.z, tau, depth[i], __uint_as_float((uint32_t)i));
     rec_c[threadIdx.x] = make_uint4(rc.x, rc.y, w, w > 1 ? 0xFFFFFFFFu / w + 1u : 0u);
   }
   uint32_t incl = area;
@@ -190,7 +188,7 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
   const uint32_t total = (uint32_t)readlane((int)incl, 63);
   __syncthreads();
   for (uint32_t base = 0; base < total; base += 64 * BIN_UNROLL) {
-    uint32_t slot[BIN_UNROLL], klo[BIN_UNROLL], khi[BIN_UNROLL];
+    uint32_t slot[BIN_UNROLL], seg[BIN_UNROLL], klo[BIN_UNROLL], khi[BIN_UNROLL];
     bool hit[BIN_UNROLL];
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++) {
@@ -212,91 +210,15 @@ __global__ __launch_bounds__(256) void bin_pairs_kernel(int P, int gx, const uin
           hit[u] = true;
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
-          // count pass: histogram; scatter pass: the scan left each sub-list's absolute start in its cursor
-          slot[u] = atomicAdd(&tile_count[bin_slot(ty * gx + tx, (int)klo[u])], 1u);
+          seg[u] = (uint32_t)bin_slot(ty * gx + tx, (int)klo[u]);
+          slot[u] = atomicAdd(&cursors[seg[u]], 1u);
         }
       }
     }
-    if (SCATTER) {
 #pragma unroll
-      for (int u = 0; u < BIN_UNROLL; u++)
-        if (hit[u]) keys[slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
-    }
-  }
-}
-
-// single workgroup: exclusive scan of the sub-list counts -> tile ranges, total -> *total_out; every counter is
-// replaced by the absolute start of its sub-list (the scatter cursor)
-template <int PER>  // PER > 0: at most PER tiles per thread, counters held in registers between the two sweeps
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(int ntiles, uint32_t *__restrict__ tile_count,
-                                                          int2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
-                                                          uint32_t *host_total) {
-  static_assert(BIN_SUBS == 8, "two uint4 per tile");
-  __shared__ uint32_t part[1024];
-  const int per = (ntiles + 1023) / 1024;
-  const int t0 = threadIdx.x * per;
-  uint4 *tc4 = reinterpret_cast<uint4 *>(tile_count);
-  constexpr int NR = PER > 0 ? PER : 1;
-  uint4 ra[NR], rb[NR];
-  uint32_t s = 0;
-  if (PER > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; k++) {  // unconditional, independent loads (clamped index), masked afterwards
-      const int t = min(t0 + k, ntiles - 1);
-      ra[k] = tc4[2 * t];
-      rb[k] = tc4[2 * t + 1];
-    }
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-      if (!(k < per && t0 + k < ntiles)) ra[k] = rb[k] = make_uint4(0, 0, 0, 0);
-      s += ra[k].x + ra[k].y + ra[k].z + ra[k].w + rb[k].x + rb[k].y + rb[k].z + rb[k].w;
-    }
-  } else {
-    for (int k = 0; k < per; k++)
-      if (t0 + k < ntiles) {
-        const uint4 a = tc4[2 * (t0 + k)], b = tc4[2 * (t0 + k) + 1];
-        s += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-      }
-  }
-  // workgroup exclusive scan of the 1024 per-thread sums: wave scan, then the 16 wave totals
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t incl = s;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-    if (lane >= off) incl += up;
-  }
-  if (lane == 63) part[wv] = incl;
-  __syncthreads();
-  uint32_t wave_base = 0, grand = 0;
-#pragma unroll
-  for (int w = 0; w < 16; w++) {
-    const uint32_t v = part[w];
-    if (w < wv) wave_base += v;
-    grand += v;
-  }
-  uint32_t run = wave_base + incl - s;
-  auto emit = [&](int tile, const uint4 a, const uint4 b) {
-    const uint32_t start = run;
-    uint4 sa, sb;
-    sa.x = run; run += a.x; sa.y = run; run += a.y; sa.z = run; run += a.z; sa.w = run; run += a.w;
-    sb.x = run; run += b.x; sb.y = run; run += b.y; sb.z = run; run += b.z; sb.w = run; run += b.w;
-    tc4[2 * tile] = sa;
-    tc4[2 * tile + 1] = sb;
-    ranges[tile] = make_int2((int)start, (int)run);
-  };
-  if (PER > 0) {
-#pragma unroll
-    for (int k = 0; k < NR; k++)
-      if (k < per && t0 + k < ntiles) emit(t0 + k, ra[k], rb[k]);
-  } else {
-    for (int k = 0; k < per; k++)
-      if (t0 + k < ntiles) emit(t0 + k, tc4[2 * (t0 + k)], tc4[2 * (t0 + k) + 1]);
-  }
-  if (threadIdx.x == 0) {
-    *total_out = grand;
-    // pinned host word polled by run_binning (fsgs_host.h mailbox): the host learns R without a stream sync
-    if (host_total) __hip_atomic_store(host_total, grand, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int u = 0; u < BIN_UNROLL; u++)
+      if (hit[u] && slot[u] < cap_sub)  // an overflowing segment keeps counting (the sort kernel reports it)
+        keys[(size_t)seg[u] * cap_sub + slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
   }
 }
 
@@ -348,27 +270,52 @@ __device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint32_t *__restrict__ cursors,
                                                          unsigned long long *__restrict__ keys,
-                                                         uint32_t *__restrict__ plist,
-                                                         const uint32_t *__restrict__ total_pairs,
-                                                         uint32_t max_pairs) {
+                                                         uint32_t *__restrict__ plist, int2 *__restrict__ ranges,
+                                                         uint32_t cap_sub, uint32_t *__restrict__ overflow_need) {
   __shared__ unsigned long long lds[SORT_LDS_KEYS];
-  if (*total_pairs > max_pairs) return;  // see bin_pairs_kernel: the lists were not written
   const int tile = blockIdx.x;
-  const int2 rg = ranges[tile];
-  const int n = rg.y - rg.x;
+  // the eight segment fill counts (wave-uniform loads); a count above the capacity = dropped keys
+  uint32_t cnt[BIN_SUBS], off[BIN_SUBS + 1], worst = 0;
+  off[0] = 0;
+#pragma unroll
+  for (int s = 0; s < BIN_SUBS; s++) {
+    const uint32_t c = cursors[tile * BIN_SUBS + s];
+    worst = max(worst, c);
+    cnt[s] = min(c, cap_sub);
+    off[s + 1] = off[s] + cnt[s];
+  }
+  if (worst > cap_sub && threadIdx.x == 0) atomicMax(overflow_need, worst);
+  const int n = (int)off[BIN_SUBS];
+  const size_t base = (size_t)tile * BIN_SUBS * cap_sub;  // of the tile's keys AND of its plist slice
+  if (threadIdx.x == 0) ranges[tile] = make_int2((int)base, (int)base + n);
   if (n <= 0) return;
   int m = 1;
   while (m < n) m <<= 1;
-  unsigned long long *gk = keys + rg.x;
+  unsigned long long *gk = keys + base;
   if (n <= SORT_LDS_KEYS) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = gk[i];
+#pragma unroll
+    for (int s = 0; s < BIN_SUBS; s++)
+      for (uint32_t i = threadIdx.x; i < cnt[s]; i += blockDim.x) lds[off[s] + i] = gk[(size_t)s * cap_sub + i];
     bitonic_sort_ascending<true>(lds, n, m);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)lds[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[base + i] = (uint32_t)lds[i];
   } else {  // rare: a tile with more than 2048 Gaussians sorts in place in global memory (L2 resident)
+    // close the gaps between the segments first: segment s moves down to off[s] (destination <= source; a chunk
+    // is read by everybody before anybody writes it, chunks ascend)
+    for (int s = 1; s < BIN_SUBS; s++) {
+      if (off[s] == (uint32_t)s * cap_sub) continue;  // already in place
+      for (uint32_t c0 = 0; c0 < cnt[s]; c0 += blockDim.x) {
+        const uint32_t i = c0 + threadIdx.x;
+        unsigned long long v = 0;
+        if (i < cnt[s]) v = gk[(size_t)s * cap_sub + i];
+        __syncthreads();
+        if (i < cnt[s]) gk[off[s] + i] = v;
+        __syncthreads();
+      }
+    }
     bitonic_sort_ascending<false>(gk, n, m);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[rg.x + i] = (uint32_t)gk[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[base + i] = (uint32_t)gk[i];
   }
 }
 
@@ -384,25 +331,69 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const int2 
 constexpr int ORDER_MAX_TILES = 1 << 20;
 constexpr int ORDER_BINS = 1024;
 constexpr int ORDER_XCD = 8;
-// bands of EQUAL WORK, not equal tile count: ranges[i].x is the prefix sum of the list lengths, so tile i
+// bands of EQUAL WORK, not equal tile count: with start_i = the prefix sum of the list lengths, tile i
 // belongs to band floor(8 * start_i / R).  Bands are interleaved round-robin (position 8*rank + band while
 // every band still has tiles, dense afterwards), so the order is a permutation of [0, ntiles).
 // nbands = 1: plain longest-first over the whole image (fastest: 568 vs 624 us for both blend kernels at C2,
 // because in-order dispatch stalls whenever one XCD is momentarily fuller than the others);
 // nbands = 8: XCD-banded (1.7x instead of 3x the algorithmic fabric traffic).  FsgsRasterCfg.flags bit 0.
+// Also the end of the binning: R = sum of the list lengths goes to `total_out` and, together with the overflow
+// report of the sort kernel, to the pinned host mailbox (bit 31 set = a segment overflowed, low bits = the segment
+// capacity that would have sufficed; otherwise R).
 __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands, const int2 *__restrict__ ranges,
-                                                          uint32_t *__restrict__ order) {
+                                                          uint32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ total_out,
+                                                          const uint32_t *__restrict__ overflow_need,
+                                                          uint32_t *host_word) {
   __shared__ uint32_t hist[ORDER_XCD][ORDER_BINS];
   __shared__ uint32_t part[ORDER_XCD][128];
   __shared__ uint32_t band_size[ORDER_XCD];
-  const unsigned long long R = (unsigned long long)max(ranges[ntiles - 1].y, 1);
+  __shared__ uint32_t wave_tot[16];
+  // prefix of the list lengths over the tiles (thread t owns tiles [t*per, (t+1)*per)) and their total
+  const int per = (ntiles + 1023) / 1024;
+  const int t0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (int q = 0; q < per; q++)
+    if (t0 + q < ntiles) {
+      const int2 rg = ranges[t0 + q];
+      mine += (uint32_t)(rg.y - rg.x);
+    }
+  uint32_t incl = mine;
+  {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+  }
   for (int i = threadIdx.x; i < ORDER_XCD * ORDER_BINS; i += blockDim.x) (&hist[0][0])[i] = 0;
   if (threadIdx.x < ORDER_XCD) band_size[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
-    int2 rg = ranges[i];
-    int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+  uint32_t start_of_mine = incl - mine, Rtot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const uint32_t v = wave_tot[w];
+    if (w < (int)(threadIdx.x >> 6)) start_of_mine += v;
+    Rtot += v;
+  }
+  if (threadIdx.x == 0) {
+    *total_out = Rtot;
+    const uint32_t need = *overflow_need;
+    if (host_word)
+      __hip_atomic_store(host_word, need ? (0x80000000u | need) : Rtot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const unsigned long long R = (unsigned long long)max(Rtot, 1u);
+  uint32_t run = start_of_mine;
+  for (int q = 0; q < per; q++) {
+    const int i = t0 + q;
+    if (i >= ntiles) break;
+    const int2 rg = ranges[i];
+    const int len = rg.y - rg.x;
+    const int n = min(len, ORDER_BINS - 1);
+    const int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)run * nbands / R);
+    run += (uint32_t)len;
     atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // bin 0 = longest lists
     atomicAdd(&band_size[band], 1u);
   }
@@ -414,23 +405,28 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
     for (int q = 0; q < 8; q++) { loc[q] = hist[band][t * 8 + q]; s += loc[q]; }
     // 128 threads per band = two waves: wave-level inclusive scan + the other wave's total
     const int lane = threadIdx.x & 63;
-    uint32_t incl = s;
+    uint32_t inc2 = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-      if (lane >= off) incl += up;
+      const uint32_t up = (uint32_t)__shfl_up((int)inc2, off, 64);
+      if (lane >= off) inc2 += up;
     }
-    if (lane == 63) part[band][t >> 6] = incl;
+    if (lane == 63) part[band][t >> 6] = inc2;
     __syncthreads();
-    uint32_t run = incl - s + ((t >> 6) ? part[band][0] : 0u);
+    uint32_t r2 = inc2 - s + ((t >> 6) ? part[band][0] : 0u);
 #pragma unroll
-    for (int q = 0; q < 8; q++) { hist[band][t * 8 + q] = run; run += loc[q]; }
+    for (int q = 0; q < 8; q++) { hist[band][t * 8 + q] = r2; r2 += loc[q]; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ntiles; i += blockDim.x) {
-    int2 rg = ranges[i];
-    int n = min(rg.y - rg.x, ORDER_BINS - 1);
-    int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)rg.x * nbands / R);
+  run = start_of_mine;
+  for (int q = 0; q < per; q++) {
+    const int i = t0 + q;
+    if (i >= ntiles) break;
+    const int2 rg = ranges[i];
+    const int len = rg.y - rg.x;
+    const int n = min(len, ORDER_BINS - 1);
+    const int band = nbands == 1 ? 0 : (int)min((unsigned long long)(nbands - 1), (unsigned long long)run * nbands / R);
+    run += (uint32_t)len;
     uint32_t rank = atomicAdd(&hist[band][ORDER_BINS - 1 - n], 1u);  // rank inside the band, longest first
     uint32_t pos = 0;
 #pragma unroll
@@ -972,7 +968,7 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
   L.tiles = c.take(4 * Pn);
   L.rect = c.take(8 * Pn);
   L.tile_count = c.take(4 * (size_t)ntiles * BIN_SUBS);
-  L.total = c.take(16);
+  L.total = c.take(16);  // {R, overflow report}
   L.keys = c.take(8 * Rn);
   L.total_bytes = c.total();
   return 0;
@@ -1000,57 +996,60 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   B.keys = (unsigned long long *)(xb + XL.keys);
   return FSGS_OK;
 }
-// everything between the preprocess kernel (which also builds the per-tile histogram; the caller zeroes
-// B.tile_count before launching it) and the blend: scan (+ the one host sync that reads R), scatter,
-// per-tile sort.  Three launches.
-int run_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, int64_t *num_rendered,
-                hipStream_t stream) {
+// Everything between the preprocess kernel and the blend: scatter, per-tile sort, dispatch order -- three
+// launches (+ one memset), all enqueued without knowing R.  The caller enqueues the forward blend right behind
+// them and only then calls finish_binning(), which polls the mailbox: the GPU never waits for the host.  If a
+// list segment overflowed, the blend ran on truncated (in-bounds) lists and its output is garbage; the call then
+// reports FSGS_ERR_CAPACITY with *num_rendered = the max_pairs that would have sufficed.
+struct BinningTicket {
+  volatile uint32_t *slot = nullptr;
+  uint32_t cap_sub = 0;
+};
+inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, BinningTicket &tk,
+                           hipStream_t stream) {
   const int ntiles = cam.gx * cam.gy;
   if (ntiles > 1024 * 64) return FSGS_ERR_INVALID;
-  uint32_t R = 0;
+  const int64_t cap = max_pairs / ((int64_t)ntiles * BIN_SUBS);
+  tk.cap_sub = (uint32_t)(cap > 0x0FFFFFFF ? 0x0FFFFFFF : cap);
+  if (tk.cap_sub == 0) return FSGS_ERR_CAPACITY;
+  // cursors [tiles * 8] followed by {R, overflow report}
   FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles * BIN_SUBS, stream));
+  FSGS_HIP(hipMemsetAsync(B.total, 0, 2 * sizeof(uint32_t), stream));
   if (P > 0) {
-    ProfScope ps(PROF_EMIT, stream);  // count pass
-    hipLaunchKernelGGL((bin_pairs_kernel<false>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
-                       B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys, B.total, 0u);
+    ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles, B.rect, B.xy,
+                       B.co, B.depth, B.tile_count, B.keys, tk.cap_sub);
   }
-  volatile uint32_t *slot = mailbox_acquire();
+  tk.slot = mailbox_acquire();
   {
-    ProfScope ps(PROF_SCAN, stream);
-    if (ntiles <= 8 * 1024)
-      hipLaunchKernelGGL(scan_tiles_kernel<8>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total,
-                         (uint32_t *)slot);
-    else
-      hipLaunchKernelGGL(scan_tiles_kernel<0>, dim3(1), dim3(1024), 0, stream, ntiles, B.tile_count, B.ranges, B.total,
-                         (uint32_t *)slot);
+    ProfScope ps(PROF_SORT_TILE, stream);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
+                       B.ranges, tk.cap_sub, B.total + 1);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
+                       (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order, B.total, B.total + 1,
+                       (uint32_t *)tk.slot);
   }
   FSGS_HIP(hipGetLastError());
-  // Everything below is enqueued BEFORE the host knows R; the kernels themselves refuse to run when the lists
-  // would not fit (R > max_pairs), so the GPU never waits for the host here.
-  const uint32_t cap32 = (uint32_t)(max_pairs > 0x7FFFFFFF ? 0x7FFFFFFF : max_pairs);
-  if (P > 0) {
-    {
-      ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
-      hipLaunchKernelGGL((bin_pairs_kernel<true>), dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles,
-                         B.rect, B.xy, B.co, B.depth, B.tile_count, B.keys, B.total, cap32);
-    }
-    {
-      ProfScope ps(PROF_SORT_TILE, stream);
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.ranges, B.keys, B.plist,
-                         B.total, cap32);
-      if (ntiles <= ORDER_MAX_TILES)
-        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
-                           (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order);
-    }
-    FSGS_HIP(hipGetLastError());
-  }
-  if (!slot || !mailbox_wait(slot, stream, &R)) {
+  return FSGS_OK;
+}
+inline int finish_binning(const CamParams &cam, FwdBuffers &B, int64_t max_pairs, const BinningTicket &tk,
+                          int64_t *num_rendered, hipStream_t stream) {
+  const int ntiles = cam.gx * cam.gy;
+  uint32_t word = 0;
+  if (!tk.slot || !mailbox_wait(tk.slot, stream, &word)) {
     // no pinned mailbox (or the stream failed): the classic copy + synchronize (UPSTREAM R2 does the same)
-    FSGS_HIP(hipMemcpyAsync(&R, B.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    uint32_t two[2] = {0, 0};
+    FSGS_HIP(hipMemcpyAsync(two, B.total, sizeof(two), hipMemcpyDeviceToHost, stream));
     FSGS_HIP(hipStreamSynchronize(stream));
+    word = two[1] ? (0x80000000u | two[1]) : two[0];
   }
-  *num_rendered = (int64_t)R;
-  if ((int64_t)R > max_pairs) return FSGS_ERR_CAPACITY;
+  if (word & 0x80000000u) {
+    const int64_t need_sub = (int64_t)(word & 0x7FFFFFFFu);
+    *num_rendered = need_sub * ntiles * BIN_SUBS;  // a max_pairs that fits every segment
+    return FSGS_ERR_CAPACITY;
+  }
+  *num_rendered = (int64_t)word;
+  (void)max_pairs;
   return FSGS_OK;
 }
 

@@ -361,15 +361,18 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
                        B.colors, B.flags);
   }
   FSGS_HIP(hipGetLastError());
-  rc = run_binning(cam, P, B, max_pairs, num_rendered, stream);
+  BinningTicket tk;
+  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream);
+  if (rc == FSGS_ERR_CAPACITY) *num_rendered = (int64_t)ntiles * BIN_SUBS * 32;  // not even one key per segment
   if (rc != FSGS_OK) return rc;
   {
     ProfScope ps(PROF_BLEND_FWD, stream);
-    launch_blend_fwd<6, false>(cam, ntiles, (ntiles <= ORDER_MAX_TILES && *num_rendered > 0) ? B.order : nullptr, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T, B.n_contrib,
-                               out_image, out_depth_sil, nullptr, stream);
+    launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T,
+                               B.n_contrib, out_image, out_depth_sil, nullptr, stream);
   }
   FSGS_HIP(hipGetLastError());
-  return FSGS_OK;
+  // only now does the host look at R (the blend is already queued behind the binning)
+  return finish_binning(cam, B, max_pairs, tk, num_rendered, stream);
 }
 
 int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,

@@ -73,7 +73,10 @@ _capacity = {}
 
 
 def _capacity_for(P, W, H):
-    return _capacity.get((P, W, H), max(1 << 16, 8 * P))
+    """max_pairs is split evenly over (tiles x 8) fixed-capacity list segments (csrc/raster_kernels.h binning): start
+    with room for 16 keys per segment or 8 pairs per Gaussian, whichever is more; grown on FSGS_ERR_CAPACITY."""
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return _capacity.get((P, W, H), max(1 << 16, 8 * P, ntiles * 8 * 16))
 
 
 def _f32c(t):
@@ -146,7 +149,8 @@ def state_views(st):
         "ranges": view(3, torch.int32, 2 * ntiles, (ntiles, 2)),
         "final_T": view(4, torch.float32, H * W, (H, W)),
         "n_contrib": view(5, torch.int32, H * W, (H, W)),
-        "point_list": view(6, torch.int32, st.num_rendered, (st.num_rendered,)),
+        # per-tile lists live at ranges[tile] inside the whole max_pairs slice (fixed-capacity segments, not contiguous)
+        "point_list": view(6, torch.int32, st.max_pairs, (st.max_pairs,)),
     }
 
 
