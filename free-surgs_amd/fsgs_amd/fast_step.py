@@ -57,6 +57,7 @@ class _Buffers:
         self.trk_w = torch.tensor(tk, device=dev)
         self.flow_out = self.terms[5:7]  # {flow loss, #valid points}
         self.flow_scratch = None
+        self.d_flow = f(4, 4)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
         self.bwd_scratch = torch.empty((P * 56 + 512,), dtype=torch.uint8, device=dev)
@@ -120,6 +121,12 @@ class FastStepper:
         rasterizer.last_num_rendered = int(nr.value)
         return args, state, sz[0], cap, int(nr.value)
 
+    def _side_stream(self, dev):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != torch.device(dev):
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
+
     def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
                          param_grads):
         cfg = self._cfg()
@@ -152,23 +159,34 @@ class FastStepper:
                 w2c = self.poses.get_pose(ts).detach().contiguous()
                 args, state, sbytes, cap, nr = self._render_forward(w2c, b)
                 gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
-                # losses forward
+                # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound, plus the
+                # two randint launches) are independent until the render backward: they run on two HIP streams.
+                side = self._side_stream(dev)
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+                side.wait_event(fwd_done)
+                with torch.cuda.stream(side):
+                    sstream = _lib.current_stream()
+                    cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+                    dep = b.depth_sil[0]
+                    _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                        _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
+                                                        _lib.ptr(b.pe_out), sstream), "fsgs_pearson_forward")
+                    _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                         _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
+                                                         0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
+                    side_done = torch.cuda.Event()
+                    side_done.record()
+                    for t_ in cr:  # drawn on the side stream, last used there
+                        t_.record_stream(side)
                 _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, 0.2,
                                                              _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
                                                              stream), "fsgs_photometric_loss_forward")
-                cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
-                dep = b.depth_sil[0]
-                _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                    _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
-                                                    _lib.ptr(b.pe_out), stream), "fsgs_pearson_forward")
-                # losses backward (upstream factors are device constants)
                 _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None,
                                                               _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
                                                               _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
-                _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                     _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w), 0,
-                                                     _lib.ptr(b.d_depth_sil[0]), stream), "fsgs_pearson_backward")
+                torch.cuda.current_stream().wait_event(side_done)
                 # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
                 first = k == 0
                 tgt = []
@@ -216,6 +234,26 @@ class FastStepper:
                 stream = _lib.current_stream()
                 wd = w2c.detach().contiguous()
                 args, state, sbytes, cap, nr = self._render_forward(wd, b)
+                # flow loss forward + backward in ONE pass, on a second stream: it only needs the pose, so it runs
+                # beside the photometric kernels and the backward blend (dflow = w_flow * dloss/dw2c)
+                side = self._side_stream(dev)
+                pose_ready = torch.cuda.Event()
+                pose_ready.record()
+                side.wait_event(pose_ready)
+                M = int(targets.pts.shape[0])
+                need = int(lib.fsgs_flow_scratch_bytes(M))
+                if b.flow_scratch is None or b.flow_scratch.numel() < need:
+                    b.flow_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+                with torch.cuda.stream(side):
+                    _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
+                                                             targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
+                                                             float(LOSS_W_TRACKING["flow"]), 0.0,
+                                                             _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
+                                                             _lib.ptr(b.d_flow), _lib.current_stream()),
+                               "fsgs_flow_pose_loss_fused")
+                    flow_done = torch.cuda.Event()
+                    flow_done.record()
+                    wd.record_stream(side)
                 # presence mask depth > 0 (heaviside(x, 0) = 1 for x > 0) times the rigid mask (train.py:176-178)
                 mask = torch.heaviside(b.depth_sil[0], b.zero)
                 if rigid_mask is not None:  # None = every pixel rigid (no Sampson mask for this frame)
@@ -230,17 +268,11 @@ class FastStepper:
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
                 grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)
                 self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False)
-                # flow loss forward + backward in one pass; its finish kernel also forms the weighted sum with the
-                # rasteriser's pose gradient:  d_total = w_rgb * d_total + w_flow * dflow/dw2c
-                M = int(targets.pts.shape[0])
-                need = int(lib.fsgs_flow_scratch_bytes(M))
-                if b.flow_scratch is None or b.flow_scratch.numel() < need:
-                    b.flow_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
-                _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
-                                                         targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
-                                                         float(LOSS_W_TRACKING["flow"]), float(LOSS_W_TRACKING["rgb"]),
-                                                         _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
-                                                         _lib.ptr(d_total), stream), "fsgs_flow_pose_loss_fused")
+                torch.cuda.current_stream().wait_event(flow_done)
+                # d_total = w_rgb * dL_rgb/dw2c + w_flow * dL_flow/dw2c
+                if float(LOSS_W_TRACKING["rgb"]) != 1.0:
+                    d_total.mul_(float(LOSS_W_TRACKING["rgb"]))
+                d_total.add_(b.d_flow)
                 weighted = b.terms * b.trk_w  # [w_rgb * rgb, ., ., ., ., w_flow * flow, ., .]
                 rgb, flow = weighted[0], weighted[5]
                 total = torch.dot(b.terms, b.trk_w)
