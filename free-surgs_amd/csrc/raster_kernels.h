@@ -967,8 +967,9 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
   size_t ntiles = (size_t)((W + FSGS_TILE - 1) / FSGS_TILE) * ((H + FSGS_TILE - 1) / FSGS_TILE);
   L.tiles = c.take(4 * Pn);
   L.rect = c.take(8 * Pn);
-  L.tile_count = c.take(4 * (size_t)ntiles * BIN_SUBS);
-  L.total = c.take(16);  // {R, overflow report}
+  // cursors [tiles * 8] directly followed by {R, overflow report}: one memset clears both
+  L.tile_count = c.take(4 * (size_t)ntiles * BIN_SUBS + 16);
+  L.total = L.tile_count + 4 * (size_t)ntiles * BIN_SUBS;
   L.keys = c.take(8 * Rn);
   L.total_bytes = c.total();
   return 0;
@@ -1013,8 +1014,8 @@ inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t m
   tk.cap_sub = (uint32_t)(cap > 0x0FFFFFFF ? 0x0FFFFFFF : cap);
   if (tk.cap_sub == 0) return FSGS_ERR_CAPACITY;
   // cursors [tiles * 8] followed by {R, overflow report}
-  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)ntiles * BIN_SUBS, stream));
-  FSGS_HIP(hipMemsetAsync(B.total, 0, 2 * sizeof(uint32_t), stream));
+  // (+4 words, not +2: a size that is a multiple of 16 bytes stays ONE fill kernel)
+  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * ((size_t)ntiles * BIN_SUBS + 4), stream));
   if (P > 0) {
     ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles, B.rect, B.xy,

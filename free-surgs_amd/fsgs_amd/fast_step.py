@@ -233,9 +233,8 @@ class FastStepper:
                 b = self._buffers(pc.num_points, H, W, int(P_CORR * (H // BOX) * (W // BOX)), dev)
                 stream = _lib.current_stream()
                 wd = w2c.detach().contiguous()
-                args, state, sbytes, cap, nr = self._render_forward(wd, b)
                 # flow loss forward + backward in ONE pass, on a second stream: it only needs the pose, so it runs
-                # beside the photometric kernels and the backward blend (dflow = w_flow * dloss/dw2c)
+                # beside the render's preprocess and binning kernels (dflow = w_flow * dloss/dw2c)
                 side = self._side_stream(dev)
                 pose_ready = torch.cuda.Event()
                 pose_ready.record()
@@ -254,6 +253,7 @@ class FastStepper:
                     flow_done = torch.cuda.Event()
                     flow_done.record()
                     wd.record_stream(side)
+                args, state, sbytes, cap, nr = self._render_forward(wd, b)
                 # presence mask depth > 0 (heaviside(x, 0) = 1 for x > 0) times the rigid mask (train.py:176-178)
                 mask = torch.heaviside(b.depth_sil[0], b.zero)
                 if rigid_mask is not None:  # None = every pixel rigid (no Sampson mask for this frame)
