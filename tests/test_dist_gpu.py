@@ -1,0 +1,97 @@
+"""Frame-sharded data parallelism WITH the HIP step driver: two ranks (two processes on the one GPU of the test
+box, gloo carrying the device tensors -- RCCL will not put two ranks on one GPU) each render their own camera
+with FastStepper, all-reduce the flat gradient bucket in place and step Adam.  The replicas must stay
+bit-identical, and equal the single-process step that sums both views (the reference's 2-view mapping,
+train.py:236-259) up to the order in which the gradient atomics landed."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _world(dev):
+    from fsgs_amd import synth
+    from fsgs_amd.model import GaussianCloud
+    from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
+
+    W, H, P, n = 320, 256, 4000, 2
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=0)
+    pc = GaussianCloud(sc, sh_degree=3, device=dev)
+    pc.cam = settings_from_cam(cam, dev)
+    pc.active_sh_degree = 2
+    pc.training_setup()
+    poses = PoseTrack(n, dev)
+    poses.set_pose(1, q=synth.PERTURBED_POSE["q"], t=synth.PERTURBED_POSE["t"])
+    g = torch.Generator().manual_seed(0)
+    colors = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(n)]
+    monos = [(torch.rand(H, W, generator=g) + 0.5).to(dev) for _ in range(n)]
+    return pc, poses, FrameData(colors, monos, K=cam["K"]), (H, W)
+
+
+def _corners(H, W, dev):
+    g = torch.Generator().manual_seed(5)
+    n = int(0.5 * (H // 128) * (W // 128))
+    return (torch.randint(0, H - 128, (n,), generator=g).to(dev), torch.randint(0, W - 128, (n,), generator=g).to(dev))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from fsgs_amd import dist as fdist
+    from fsgs_amd.fast_step import FastStepper
+    from fsgs_amd.model import PARAM_NAMES
+
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    fdist.init_from_env(backend="gloo")
+    pc, poses, frames, (H, W) = _world(dev)
+    cr = _corners(H, W, dev)
+    bucket = fdist.GradBucket(pc)
+    fs = FastStepper(pc, poses, frames)
+    for step in range(2):
+        bucket.attach(pc, zero=False)  # the stepper overwrites every gradient element
+        loss = fs.mapping_step([rank], grad_sync=lambda p: fdist.sync_gradients(p, bucket), corners=cr)
+        assert all(pc.params[k].grad.data_ptr() == bucket.views[k].data_ptr() for k in PARAM_NAMES)
+    torch.cuda.synchronize()
+    torch.save({k: pc.params[k].detach().cpu() for k in PARAM_NAMES} | {"loss": loss.detach().cpu()},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path):
+    from fsgs_amd.fast_step import FastStepper
+    from fsgs_amd.model import PARAM_NAMES
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in PARAM_NAMES:
+        assert torch.equal(a[k], b[k]), k  # replicas bit-identical: same reduced gradient, same Adam
+    # single process, both views in one step (summed loss)
+    pc, poses, frames, (H, W) = _world("cuda:0")
+    cr = _corners(H, W, "cuda:0")
+    fs = FastStepper(pc, poses, frames)
+    for step in range(2):
+        total = fs.mapping_step([0, 1], corners=cr)
+    assert abs((a["loss"] + b["loss"]).item() - total.item()) <= 1e-5 * abs(total.item())
+    for k in PARAM_NAMES:
+        ref = pc.params[k].detach().cpu()
+        # Adam divides by sqrt(v): elements whose gradient is rounding noise can move by lr either way
+        frac_off = ((a[k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
+        assert frac_off < 2e-3, (k, frac_off)
