@@ -203,6 +203,12 @@ def main():
             if pmc.get("config") == args.config and key in pmc["kernels"] and world == 1:
                 roofline["traffic"] = pmc["kernels"][key]["traffic_bytes"]
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+                wi = pmc["kernels"][key].get("valu_wave_insts")
+                if wi:  # what actually bounds this kernel: VALU issue (4 cycles per wave64 instruction and SIMD)
+                    issue_s = wi * 4.0 / (256 * 4 * 2.4e9)
+                    roofline["valu"] = {"wave_insts": wi, "issue_bound_ms": issue_s * 1e3,
+                                        "frac_of_issue_bound": issue_s / avg_s,
+                                        "source": "SQ_INSTS_VALU, profiles/r01_v8_sq_counters.txt"}
         except Exception:
             pass
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
