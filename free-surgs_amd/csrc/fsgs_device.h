@@ -271,4 +271,16 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
   return (bid % NXCD) * per + bid / NXCD;
 }
 
+// ---- the one definition of the Adam element update (optim.hip and the fused backward of render.hip) ----
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1, float b2, float omb2,
+                                         float eps, float step_size, float inv_bc2_sqrt) {
+  // torch.optim.Adam: lerp_(grad, 1-beta1); mul_(beta2).addcmul_(grad, grad, value=1-beta2); sqrt/bc2 + eps; addcdiv_
+  // (1-beta) is formed in DOUBLE on the host like torch does: 1 - 0.999f would be off by 4.7e-5 relative)
+  m = fmaf(omb1, g - m, m);
+  v = fmaf(omb2, g * g, b2 * v);
+  float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+
+
 }  // namespace fsgs

@@ -179,13 +179,48 @@ constexpr int MODE_GS_GRAD = 1;     // means3D gradient flows to _xyz (gs_grad=T
 constexpr int MODE_CAM_GRAD = 2;    // reduce dL/dw2c (cam_grad=True)
 constexpr int MODE_PARAM_GRAD = 4;  // gradients of features / opacity / scaling / rotation (+ _xyz through the SH direction)
 
+// ADAM = true (single-view mapping step on one GPU): the gradient of every parameter is consumed on the spot by
+// the Adam update of that element instead of being written out and read back by the optimizer kernel
+// (2 x 71 MB at P = 300 k).  Every workgroup reads only its own 256 Gaussians' parameters, and reads them
+// before it updates them, so updating in place is race-free.  Group order: xyz, f_dc, f_rest, opacity, scaling,
+// rotation.
+struct AdamDev {
+  float *m[6], *v[6];
+  float step_size[6], inv_bc2_sqrt[6];
+  float omb1, b2, omb2, eps;
+};
+template <bool ADAM>
+struct GradSink {
+  const RenderGradsDev &out;
+  const RenderDev &a;
+  const AdamDev &ad;
+  __device__ __forceinline__ void put(int group, size_t idx, float g) const {
+    float *gp = group == 0 ? out.xyz : group == 1 ? out.f_dc : group == 2 ? out.f_rest : group == 3 ? out.opacity
+              : group == 4 ? out.scaling : out.rotation;
+    if (!ADAM) {
+      gp[idx] = g;
+      return;
+    }
+    const float *cp = group == 0 ? a.xyz : group == 1 ? a.f_dc : group == 2 ? a.f_rest : group == 3 ? a.opacity
+                    : group == 4 ? a.scaling : a.rotation;
+    float *pp = const_cast<float *>(cp);
+    float pv = pp[idx], mv = ad.m[group][idx], vv = ad.v[group][idx];
+    adam_one(pv, g, mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[group], ad.inv_bc2_sqrt[group]);
+    pp[idx] = pv;
+    ad.m[group][idx] = mv;
+    ad.v[group][idx] = vv;
+  }
+};
+
+template <bool ADAM>
 __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
                                                              const float4 *__restrict__ conic_op,
                                                              const float *__restrict__ grad_acc,
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
-                                                             RenderGradsDev out) {
+                                                             RenderGradsDev out, AdamDev ad) {
+  const GradSink<ADAM> sink{out, a, ad};
   __shared__ float red[12][4];
   __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];  // coefficients in, their gradients out
   const int b0 = blockIdx.x * blockDim.x;
@@ -228,16 +263,16 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
     }
     if (mode & MODE_PARAM_GRAD) {
       // activations
-      out.scaling[3 * i] = gg.ds[0] * act.scale.x;
-      out.scaling[3 * i + 1] = gg.ds[1] * act.scale.y;
-      out.scaling[3 * i + 2] = gg.ds[2] * act.scale.z;
+      sink.put(4, 3 * (size_t)i, gg.ds[0] * act.scale.x);
+      sink.put(4, 3 * (size_t)i + 1, gg.ds[1] * act.scale.y);
+      sink.put(4, 3 * (size_t)i + 2, gg.ds[2] * act.scale.z);
       float qd = act.q.x * gg.dq[0] + act.q.y * gg.dq[1] + act.q.z * gg.dq[2] + act.q.w * gg.dq[3];
       float inv = 1.0f / act.qnorm;
-      out.rotation[4 * i] = (gg.dq[0] - act.q.x * qd) * inv;
-      out.rotation[4 * i + 1] = (gg.dq[1] - act.q.y * qd) * inv;
-      out.rotation[4 * i + 2] = (gg.dq[2] - act.q.z * qd) * inv;
-      out.rotation[4 * i + 3] = (gg.dq[3] - act.q.w * qd) * inv;
-      out.opacity[i] = gg.dop * act.op * (1.0f - act.op);
+      sink.put(5, 4 * (size_t)i, (gg.dq[0] - act.q.x * qd) * inv);
+      sink.put(5, 4 * (size_t)i + 1, (gg.dq[1] - act.q.y * qd) * inv);
+      sink.put(5, 4 * (size_t)i + 2, (gg.dq[2] - act.q.z * qd) * inv);
+      sink.put(5, 4 * (size_t)i + 3, (gg.dq[3] - act.q.w * qd) * inv);
+      sink.put(3, (size_t)i, gg.dop * act.op * (1.0f - act.op));
       // SH colour
       float vx = xw[0] - a.cam_center[0], vy = xw[1] - a.cam_center[1], vz = xw[2] - a.cam_center[2];
       float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
@@ -251,7 +286,7 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
-        out.f_dc[3 * i + c] = b[0] * gcol;
+        sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
         for (int k = 1; k < a.K; k++) {
           const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
           if (k < nk) {
@@ -272,20 +307,56 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
       dxyz[2] += (ddz - dz * dot) * inv_n;
     }
   } else if (i < P && (mode & MODE_PARAM_GRAD)) {
-    out.scaling[3 * i] = out.scaling[3 * i + 1] = out.scaling[3 * i + 2] = 0.f;
-    out.rotation[4 * i] = out.rotation[4 * i + 1] = out.rotation[4 * i + 2] = out.rotation[4 * i + 3] = 0.f;
-    out.opacity[i] = 0.f;
+    // zero gradient: plain mode writes the zeros, Adam mode still decays the moments and applies them
 #pragma unroll
-    for (int c = 0; c < 3; c++) out.f_dc[3 * i + c] = 0.f;
+    for (int c = 0; c < 3; c++) sink.put(4, 3 * (size_t)i + c, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; c++) sink.put(5, 4 * (size_t)i + c, 0.f);
+    sink.put(3, (size_t)i, 0.f);
+#pragma unroll
+    for (int c = 0; c < 3; c++) sink.put(1, 3 * (size_t)i + c, 0.f);
     for (int k = 0; k < row; k++) my_rest[k] = 0.f;
   }
-  if (stage) {  // coalesced store of the workgroup's SH-rest gradients
+  if (stage) {  // coalesced store (or coalesced Adam update) of the workgroup's SH-rest gradients
     __syncthreads();
-    stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
+    if (!ADAM) {
+      stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
+    } else {
+      // 76 % of all parameters live here: 16-byte accesses to p, m, v like the stand-alone Adam kernel
+      const size_t first = (size_t)b0 * row;
+      float *pp = const_cast<float *>(a.f_rest) + first, *mp = ad.m[2] + first, *vp = ad.v[2] + first;
+      const bool vec = ((first & 3) == 0) && (((((uintptr_t)pp) | ((uintptr_t)mp) | ((uintptr_t)vp)) & 15) == 0);
+      const size_t n4 = vec ? (stage_cnt >> 2) : 0;
+      constexpr int U = 4;  // 12 independent 16-byte loads in flight per thread
+      for (size_t q0 = threadIdx.x; q0 < n4; q0 += 256 * U) {
+        float4 p4[U], m4[U], v4[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const size_t q = q0 + (size_t)u * 256;
+          if (q < n4) { p4[u] = ((float4 *)pp)[q]; m4[u] = ((float4 *)mp)[q]; v4[u] = ((float4 *)vp)[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const size_t q = q0 + (size_t)u * 256;
+          if (q >= n4) break;
+          const float4 g4 = ((const float4 *)s_rest)[q];
+          adam_one(p4[u].x, g4.x, m4[u].x, v4[u].x, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+          adam_one(p4[u].y, g4.y, m4[u].y, v4[u].y, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+          adam_one(p4[u].z, g4.z, m4[u].z, v4[u].z, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+          adam_one(p4[u].w, g4.w, m4[u].w, v4[u].w, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+          ((float4 *)pp)[q] = p4[u]; ((float4 *)mp)[q] = m4[u]; ((float4 *)vp)[q] = v4[u];
+        }
+      }
+      for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += 256) sink.put(2, first + e, s_rest[e]);
+    }
   }
   if (i < P) {
     out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f;
-    if (out.xyz) { out.xyz[3 * i] = dxyz[0]; out.xyz[3 * i + 1] = dxyz[1]; out.xyz[3 * i + 2] = dxyz[2]; }
+    if (ADAM || out.xyz) {
+      sink.put(0, 3 * (size_t)i, dxyz[0]);
+      sink.put(0, 3 * (size_t)i + 1, dxyz[1]);
+      sink.put(0, 3 * (size_t)i + 2, dxyz[2]);
+    }
   }
   if (mode & MODE_CAM_GRAD) {  // dL/dw2c[r][c] = sum_i g_r [x;1]_c   (scene/pose_optimizer.py:985-987 adjoint)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -375,20 +446,46 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   return finish_binning(cam, B, max_pairs, tk, num_rendered, stream);
 }
 
-int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+}  // extern "C"
+
+namespace {
+// adam == nullptr: gradients are written to `grads`; otherwise they feed the in-place Adam update (grads->means2D is
+// still written: the densification statistic needs it)
+int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
-                         int param_grads, const FsgsRenderGrads *grads, void *scratch, size_t scratch_bytes,
-                         fsgs_stream_t stream_) {
+                         int param_grads, const FsgsRenderGrads *grads, const FsgsFusedAdam *adam, void *scratch,
+                         size_t scratch_bytes, fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
   if (P == 0) return FSGS_OK;
   if (!args_ok(args, P) || !radii || !scratch || !grads->means2D) return FSGS_ERR_INVALID;
   if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
-  if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
-  if (param_grads && (!grads->features_dc || !grads->opacity || !grads->scaling || !grads->rotation ||
-                      (args->max_sh_degree > 0 && !grads->features_rest)))
-    return FSGS_ERR_INVALID;
+  if (!adam) {
+    if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
+    if (param_grads && (!grads->features_dc || !grads->opacity || !grads->scaling || !grads->rotation ||
+                        (args->max_sh_degree > 0 && !grads->features_rest)))
+      return FSGS_ERR_INVALID;
+  }
+  AdamDev ad;
+  std::memset(&ad, 0, sizeof(ad));
+  if (adam) {
+    if (!gs_grad || !param_grads) return FSGS_ERR_INVALID;
+    for (int g = 0; g < 6; g++) {
+      const bool needed = !(g == 2 && args->max_sh_degree == 0);
+      if (needed && (!adam->exp_avg[g] || !adam->exp_avg_sq[g] || adam->step[g] < 1)) return FSGS_ERR_INVALID;
+      ad.m[g] = adam->exp_avg[g];
+      ad.v[g] = adam->exp_avg_sq[g];
+      const double bc1 = 1.0 - pow(adam->beta1, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
+      const double bc2 = 1.0 - pow(adam->beta2, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
+      ad.step_size[g] = (float)((double)adam->lr[g] / bc1);      // exactly fsgs_adam_step's host arithmetic
+      ad.inv_bc2_sqrt[g] = (float)(1.0 / sqrt(bc2));
+    }
+    ad.omb1 = (float)(1.0 - adam->beta1);
+    ad.b2 = (float)adam->beta2;
+    ad.omb2 = (float)(1.0 - adam->beta2);
+    ad.eps = (float)adam->eps;
+  }
   const int W = cfg->image_width, H = cfg->image_height;
   if (max_pairs < 0 || num_rendered < 0 || num_rendered > max_pairs) return FSGS_ERR_STATE;
   StateLayout SL = state_layout(P, W, H, max_pairs, 6);
@@ -427,11 +524,42 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                      grads->rotation, grads->means2D, grads->w2c};
   {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
-    hipLaunchKernelGGL(render_pre_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), radii,
-                       (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6, (const uint32_t *)(sb + SL.flags), mode, out);
+    if (adam)
+      hipLaunchKernelGGL(render_pre_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args),
+                         radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
+    else
+      hipLaunchKernelGGL(render_pre_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args),
+                         radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                         const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                         const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
+                         int param_grads, const FsgsRenderGrads *grads, void *scratch, size_t scratch_bytes,
+                         fsgs_stream_t stream) {
+  return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
+                              dL_ddepth_sil, gs_grad, cam_grad, param_grads, grads, nullptr, scratch, scratch_bytes,
+                              stream);
+}
+
+int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                              const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                              const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
+                              float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
+  if (!adam || !means2D_grad) return FSGS_ERR_INVALID;
+  FsgsRenderGrads g;
+  std::memset(&g, 0, sizeof(g));
+  g.means2D = means2D_grad;
+  return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
+                              dL_ddepth_sil, 1, 0, 1, &g, adam, scratch, scratch_bytes, stream);
 }
 
 }  // extern "C"

@@ -52,6 +52,11 @@ class FsgsRenderGrads(C.Structure):
                                           "means2D", "w2c")]
 
 
+class FsgsFusedAdam(C.Structure):
+    _fields_ = [("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6), ("lr", C.c_float * 6),
+                ("step", C.c_int32 * 6), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
 class FsgsDensifyGroup(C.Structure):
     _fields_ = [("in_param", C.c_void_p), ("in_exp_avg", C.c_void_p), ("in_exp_avg_sq", C.c_void_p),
                 ("out_param", C.c_void_p), ("out_exp_avg", C.c_void_p), ("out_exp_avg_sq", C.c_void_p),
@@ -108,6 +113,11 @@ _PROTOTYPES = {
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _i, _i, _i,
          C.POINTER(FsgsRenderGrads), _vp, _sz, _vp],
+    ),
+    "fsgs_render_backward_adam": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp,
+         C.POINTER(FsgsFusedAdam), _vp, _vp, _sz, _vp],
     ),
     "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
     "fsgs_photometric_scratch_bytes": (_sz, [_i, _i, _i]),

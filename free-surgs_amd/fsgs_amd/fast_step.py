@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, losses, rasterizer
+from . import _lib, losses, optim, rasterizer
 from .model import PARAM_NAMES
 from .render_ops import _args_struct
 
@@ -72,6 +72,7 @@ class FastStepper:
         self.cfg_key = None
         self.lib = _lib.load()
         self.last = {}
+        self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
 
     # ---- helpers -----------------------------------------------------------------------------------------
     def _buffers(self, P, H, W, n_patches, dev):
@@ -120,6 +121,26 @@ class FastStepper:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
         rasterizer.last_num_rendered = int(nr.value)
         return args, state, sz[0], cap, int(nr.value)
+
+    def _fused_adam_struct(self):
+        """FsgsFusedAdam for the six groups of pc.optimizer (state created on first use, step counters advanced:
+        exactly what FusedAdam.step() does before its launch)."""
+        opt = self.pc.optimizer
+        adam = _lib.FsgsFusedAdam()
+        by_name = {g["name"]: g for g in opt.param_groups}
+        for k, name in enumerate(PARAM_NAMES):
+            g = by_name[name]
+            p = g["params"][0]
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] = int(st["step"]) + 1
+            adam.exp_avg[k], adam.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            adam.lr[k], adam.step[k] = float(g["lr"]), int(st["step"])
+            adam.beta1, adam.beta2, adam.eps = float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+        return adam
 
     def _side_stream(self, dev):
         st = getattr(self, "_side", None)
@@ -187,6 +208,21 @@ class FastStepper:
                                                               _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
                 torch.cuda.current_stream().wait_event(side_done)
+                # single view, single rank: the backward feeds Adam directly (no gradient tensors at all)
+                fuse_adam = (self.fuse_adam and len(timesteps) == 1 and grad_sync is None and step_optimizer
+                             and isinstance(pc.optimizer, optim.FusedAdam))
+                if fuse_adam:
+                    adam = self._fused_adam_struct()
+                    cfg = self._cfg()
+                    _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
+                                                             _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
+                                                             _lib.ptr(b.d_depth_sil), C.byref(adam),
+                                                             _lib.ptr(b.means2D_grad), _lib.ptr(b.bwd_scratch),
+                                                             b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
+                    step_optimizer = False  # done
+                    total = torch.dot(b.terms, b.term_w)
+                    radii0 = b.radii
+                    break
                 # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
                 first = k == 0
                 tgt = []
@@ -212,8 +248,6 @@ class FastStepper:
                     radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
             if grad_sync is not None:
                 grad_sync(pc)
-            from . import optim
-
             optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
                                 pc.variables["xyz_gradient_accum"], pc.variables["denom"])
             self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil}

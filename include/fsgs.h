@@ -158,7 +158,7 @@ int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
 
 /* out_image [3,H,W] = the RGB pass; out_depth_sil [3,H,W] = (depth, silhouette, depth^2) pass of
  * gaussian_renderer/__init__.py:68-73; radii [P].  cfg->channels is ignored; cfg->bg[0..2] is used for
- * both passes (scene/pose_optimizer.py:624).  Synchronises once like fsgs_raster_forward. */
+ * both passes (scene/pose_optimizer.py:624).  R reaches the host like in fsgs_raster_forward. */
 int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args,
                         float *out_image, float *out_depth_sil, int32_t *radii,
                         void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
@@ -173,6 +173,24 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          const float *dL_dimage, const float *dL_ddepth_sil,
                          int gs_grad, int cam_grad, int param_grads, const FsgsRenderGrads *grads,
                          void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+
+/* The same backward with gs_grad = 1, param_grads = 1, cam_grad = 0, FOLLOWED BY the Adam step of the six
+ * GaussianModel groups (train.py:268-272), without materialising the gradients: every parameter element is updated
+ * in place (args->xyz ... args->rotation are written!) together with its two moments.  Only valid when this is
+ * the step's single contribution to the gradient (one view, one rank).  Arithmetic identical to
+ * fsgs_render_backward + fsgs_adam_step.  Group order of the arrays: xyz, features_dc, features_rest, opacity,
+ * scaling, rotation; step = the step count INCLUDING this step (>= 1).  means2D_grad [P,3] is still written. */
+typedef struct FsgsFusedAdam {
+  float *exp_avg[6];
+  float *exp_avg_sq[6];
+  float lr[6];
+  int32_t step[6];
+  double beta1, beta2, eps;
+} FsgsFusedAdam;
+int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                              const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                              const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
+                              float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
 
 /* ---- simple-knn -------------------------------------------------------------- */
 

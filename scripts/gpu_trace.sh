@@ -10,8 +10,8 @@ python - "$f" <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last 2 steps: find the last two adam_kernel launches
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+# one step = between the last two densify_stats launches (the last kernel of a mapping step)
+idx = [i for i, r in enumerate(rows) if "densify_stats_kernel" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 seg = rows[a + 1:b + 1]
 t0 = int(seg[0]["Start_Timestamp"]); t1 = int(seg[-1]["End_Timestamp"])

@@ -91,3 +91,32 @@ def test_fast_tracking_step_equals_autograd_step():
     assert abs(out[0][0] - out[1][0]) <= 1e-4 * abs(out[0][0])
     assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=2e-4)  # Adam steps are +-lr sized: compare poses
     assert torch.allclose(out[0][2], out[1][2], rtol=0, atol=2e-4)
+
+
+def test_adam_fused_into_the_backward_equals_backward_then_adam():
+    """fsgs_render_backward_adam (single view, single rank: the gradient of every parameter is consumed by its
+    Adam update inside the preprocess backward) against the two-launch form, over three consecutive steps."""
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    a = _world()
+    b = _world()
+    fa, fb = FastStepper(a[0], a[1], a[2]), FastStepper(b[0], b[1], b[2])
+    fa.fuse_adam = False
+    assert fb.fuse_adam
+    for step in range(3):
+        a[0].update_learning_rate(step + 1)
+        b[0].update_learning_rate(step + 1)
+        la = fa.mapping_step([1], corners=corners)
+        lb = fb.mapping_step([1], corners=corners)
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())
+    for k in PARAM_NAMES:
+        pa, pb = a[0].params[k], b[0].params[k]
+        sa, sb = a[0].optimizer.state[pa], b[0].optimizer.state[pb]
+        assert int(sa["step"]) == int(sb["step"]) == 3
+        # identical arithmetic; only the atomic summation order of the blend backward differs between two runs
+        diff = (pa.detach() - pb.detach()).abs()
+        assert (diff > 1e-5 * pa.detach().abs().max()).float().mean().item() < 2e-3, k
+        for key in ("exp_avg", "exp_avg_sq"):
+            scale = sa[key].abs().max().item()
+            assert ((sa[key] - sb[key]).abs() > 1e-4 * scale).float().mean().item() < 2e-3, (k, key)
+    assert torch.equal(a[0].variables["denom"], b[0].variables["denom"])
