@@ -249,6 +249,9 @@ def main():
                 args.config, W, H, P, CONFIGS[args.config][3]),
                 "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
+                "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"
+                              if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step: one multi-tensor launch after the gradient all-reduce"
+                              if use_fast else "FusedAdam / torch path"),
                 "parallelism": "dp%d" % world, "loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking,
         }
