@@ -112,6 +112,7 @@ def main():
                          "stepper (fast_step.FastStepper); same arithmetic, more host overhead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the extra tracking-iteration timing")
+    ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     args = ap.parse_args()
 
@@ -140,9 +141,9 @@ def main():
     except ImportError:
         hip_losses = False
 
-    bucket = fdist.GradBucket(pc) if world > 1 else None
     n_frames = len(frames.colors)
     use_fast = fused and hip_losses and not args.autograd
+    bucket = fdist.GradBucket(pc) if (world > 1 and not use_fast) else None
     if use_fast:
         from fsgs_amd.fast_step import FastStepper
 
@@ -150,11 +151,13 @@ def main():
 
     def one_step(it):
         ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
-        if bucket is not None:
-            bucket.attach(pc, zero=not use_fast)
-        sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None
         if use_fast:
-            return stepper.mapping_step([ts], grad_sync=sync), None
+            # N > 1: ONE all-reduce of the compact [P,14] gradient (56 B / Gaussian), then Adam from it
+            red = fdist.all_reduce_compact if world > 1 else ((lambda t_: None) if args.dp_path else None)
+            return stepper.mapping_step([ts], reduce_compact=red), None
+        if bucket is not None:
+            bucket.attach(pc)
+        sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None
         return mapping_step(pc, poses, frames, [ts], fused=fused, hip_losses=hip_losses, grad_sync=sync)
 
     def barrier():
@@ -250,7 +253,7 @@ def main():
                 "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"
-                              if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step: one multi-tensor launch after the gradient all-reduce"
+                              if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step, from the all-reduced compact [P,14] gradient (fsgs_adam_step_compact)"
                               if use_fast else "FusedAdam / torch path"),
                 "parallelism": "dp%d" % world, "loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking,

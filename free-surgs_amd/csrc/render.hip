@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void render_pre_fwd_kernel(int P, CamParams ca
 
 struct RenderGradsDev {
   float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation, *means2D, *w2c;
+  float *compact;  // [P, 14] (OUT_COMPACT)
 };
 
 // mode bits
@@ -189,12 +190,32 @@ struct AdamDev {
   float step_size[6], inv_bc2_sqrt[6];
   float omb1, b2, omb2, eps;
 };
-template <bool ADAM>
+// OUT_COMPACT (several views per step, several ranks): 14 floats per Gaussian instead of 59.  The gradient of the
+// 48 SH coefficients is the outer product  basis_k(dir) x gcol_c  where the basis depends only on the Gaussian
+// (world position, frame-0 camera centre: the same on every rank and for every view) and gcol = the clamped
+// dL/dcolour is all a view contributes.  Sums over views / ranks therefore only need gcol[3]; the outer
+// product is formed once, inside the Adam kernel (adam_compact_kernel).  Row layout:
+// [0..2] d xyz | [3..5] gcol | [6] d opacity | [7..9] d scaling | [10..13] d rotation.
+constexpr int OUT_GRADS = 0, OUT_ADAM = 1, OUT_COMPACT = 2;
+constexpr int COMPACT_ROW = 14;
+__device__ __forceinline__ size_t compact_index(int group, size_t idx) {
+  // group-relative element index -> position in the compact row
+  return group == 0 ? (idx / 3) * COMPACT_ROW + idx % 3
+       : group == 3 ? idx * COMPACT_ROW + 6
+       : group == 4 ? (idx / 3) * COMPACT_ROW + 7 + idx % 3
+                    : (idx >> 2) * COMPACT_ROW + 10 + (idx & 3);
+}
+template <int OUT>
 struct GradSink {
   const RenderGradsDev &out;
   const RenderDev &a;
   const AdamDev &ad;
+  static constexpr bool ADAM = OUT == OUT_ADAM;
   __device__ __forceinline__ void put(int group, size_t idx, float g) const {
+    if (OUT == OUT_COMPACT) {
+      if (group != 1 && group != 2) out.compact[compact_index(group, idx)] = g;
+      return;
+    }
     float *gp = group == 0 ? out.xyz : group == 1 ? out.f_dc : group == 2 ? out.f_rest : group == 3 ? out.opacity
               : group == 4 ? out.scaling : out.rotation;
     if (!ADAM) {
@@ -212,7 +233,41 @@ struct GradSink {
   }
 };
 
-template <bool ADAM>
+// Adam update of the workgroup's SH-rest block from gradients parked in LDS: 76 % of all parameters live here, so
+// p, m, v move with 16-byte accesses, 12 of them in flight per thread, like the stand-alone Adam kernel
+__device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const AdamDev &ad, const float *s_rest,
+                                                   size_t first, size_t stage_cnt) {
+  float *pp = const_cast<float *>(a.f_rest) + first, *mp = ad.m[2] + first, *vp = ad.v[2] + first;
+  const bool vec = ((first & 3) == 0) && (((((uintptr_t)pp) | ((uintptr_t)mp) | ((uintptr_t)vp)) & 15) == 0);
+  const size_t n4 = vec ? (stage_cnt >> 2) : 0;
+  constexpr int U = 4;
+  for (size_t q0 = threadIdx.x; q0 < n4; q0 += 256 * U) {
+    float4 p4[U], m4[U], v4[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t q = q0 + (size_t)u * 256;
+      if (q < n4) { p4[u] = ((float4 *)pp)[q]; m4[u] = ((float4 *)mp)[q]; v4[u] = ((float4 *)vp)[q]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t q = q0 + (size_t)u * 256;
+      if (q >= n4) break;
+      const float4 g4 = ((const float4 *)s_rest)[q];
+      adam_one(p4[u].x, g4.x, m4[u].x, v4[u].x, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+      adam_one(p4[u].y, g4.y, m4[u].y, v4[u].y, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+      adam_one(p4[u].z, g4.z, m4[u].z, v4[u].z, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+      adam_one(p4[u].w, g4.w, m4[u].w, v4[u].w, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+      ((float4 *)pp)[q] = p4[u]; ((float4 *)mp)[q] = m4[u]; ((float4 *)vp)[q] = v4[u];
+    }
+  }
+  for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += 256) {
+    float pv = pp[e], mv = mp[e], vv = vp[e];
+    adam_one(pv, s_rest[e], mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
+    pp[e] = pv; mp[e] = mv; vp[e] = vv;
+  }
+}
+
+template <int OUT>
 __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
                                                              const float4 *__restrict__ conic_op,
@@ -220,7 +275,8 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
                                                              RenderGradsDev out, AdamDev ad) {
-  const GradSink<ADAM> sink{out, a, ad};
+  const GradSink<OUT> sink{out, a, ad};
+  constexpr bool ADAM = OUT == OUT_ADAM;
   __shared__ float red[12][4];
   __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];  // coefficients in, their gradients out
   const int b0 = blockIdx.x * blockDim.x;
@@ -286,16 +342,17 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
-        sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
+        if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = gcol;
+        else sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
         for (int k = 1; k < a.K; k++) {
           const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
           if (k < nk) {
             float coef = my_rest[at];
-            my_rest[at] = b[k] * gcol;
+            if (OUT != OUT_COMPACT) my_rest[at] = b[k] * gcol;
             ddx = fmaf(gcol * coef, bx[k], ddx);
             ddy = fmaf(gcol * coef, by[k], ddy);
             ddz = fmaf(gcol * coef, bz[k], ddz);
-          } else {
+          } else if (OUT != OUT_COMPACT) {
             my_rest[at] = 0.f;
           }
         }
@@ -314,45 +371,24 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
     for (int c = 0; c < 4; c++) sink.put(5, 4 * (size_t)i + c, 0.f);
     sink.put(3, (size_t)i, 0.f);
 #pragma unroll
-    for (int c = 0; c < 3; c++) sink.put(1, 3 * (size_t)i + c, 0.f);
-    for (int k = 0; k < row; k++) my_rest[k] = 0.f;
+    for (int c = 0; c < 3; c++) {
+      if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = 0.f;
+      else sink.put(1, 3 * (size_t)i + c, 0.f);
+    }
+    if (OUT != OUT_COMPACT)
+      for (int k = 0; k < row; k++) my_rest[k] = 0.f;
   }
-  if (stage) {  // coalesced store (or coalesced Adam update) of the workgroup's SH-rest gradients
+  if (stage && OUT != OUT_COMPACT) {  // coalesced store (or coalesced Adam update) of the SH-rest gradients
     __syncthreads();
     if (!ADAM) {
       stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
     } else {
-      // 76 % of all parameters live here: 16-byte accesses to p, m, v like the stand-alone Adam kernel
-      const size_t first = (size_t)b0 * row;
-      float *pp = const_cast<float *>(a.f_rest) + first, *mp = ad.m[2] + first, *vp = ad.v[2] + first;
-      const bool vec = ((first & 3) == 0) && (((((uintptr_t)pp) | ((uintptr_t)mp) | ((uintptr_t)vp)) & 15) == 0);
-      const size_t n4 = vec ? (stage_cnt >> 2) : 0;
-      constexpr int U = 4;  // 12 independent 16-byte loads in flight per thread
-      for (size_t q0 = threadIdx.x; q0 < n4; q0 += 256 * U) {
-        float4 p4[U], m4[U], v4[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const size_t q = q0 + (size_t)u * 256;
-          if (q < n4) { p4[u] = ((float4 *)pp)[q]; m4[u] = ((float4 *)mp)[q]; v4[u] = ((float4 *)vp)[q]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const size_t q = q0 + (size_t)u * 256;
-          if (q >= n4) break;
-          const float4 g4 = ((const float4 *)s_rest)[q];
-          adam_one(p4[u].x, g4.x, m4[u].x, v4[u].x, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
-          adam_one(p4[u].y, g4.y, m4[u].y, v4[u].y, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
-          adam_one(p4[u].z, g4.z, m4[u].z, v4[u].z, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
-          adam_one(p4[u].w, g4.w, m4[u].w, v4[u].w, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
-          ((float4 *)pp)[q] = p4[u]; ((float4 *)mp)[q] = m4[u]; ((float4 *)vp)[q] = v4[u];
-        }
-      }
-      for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += 256) sink.put(2, first + e, s_rest[e]);
+      adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt);
     }
   }
   if (i < P) {
     out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f;
-    if (ADAM || out.xyz) {
+    if (OUT != OUT_GRADS || out.xyz) {
       sink.put(0, 3 * (size_t)i, dxyz[0]);
       sink.put(0, 3 * (size_t)i + 1, dxyz[1]);
       sink.put(0, 3 * (size_t)i + 2, dxyz[2]);
@@ -373,6 +409,46 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
       float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
       if (t != 0.f) atomicAdd(out.w2c + threadIdx.x, t);
     }
+  }
+}
+
+// Adam step of all six groups from the compact per-Gaussian gradient (see OUT_COMPACT): the SH gradients
+// basis_k x gcol_c are formed here, in LDS, and never exist in HBM.  The basis uses the position BEFORE this
+// step's update, i.e. the one the forward pass saw.
+__global__ __launch_bounds__(256) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc, AdamDev ad) {
+  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];
+  const RenderGradsDev none{};
+  const GradSink<OUT_ADAM> sink{none, a, ad};
+  const int b0 = blockIdx.x * blockDim.x;
+  const int i = b0 + threadIdx.x;
+  const int row = (a.K - 1) * 3;
+  const size_t stage_cnt = (size_t)min(256, P - b0) * row;
+  if (i < P) {
+    const float *g = gc + (size_t)i * COMPACT_ROW;
+    const float vx = a.xyz[3 * i] - a.cam_center[0], vy = a.xyz[3 * i + 1] - a.cam_center[1],
+                vz = a.xyz[3 * i + 2] - a.cam_center[2];
+    const float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+    float b[16];
+    sh_basis(a.deg, vx * inv_n, vy * inv_n, vz * inv_n, b);
+    const int nk = (a.deg + 1) * (a.deg + 1);
+    float *my_rest = s_rest + (size_t)threadIdx.x * row;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float gcol = g[3 + c];
+      sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
+      for (int k = 1; k < a.K; k++) my_rest[(k - 1) * 3 + c] = k < nk ? b[k] * gcol : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) sink.put(0, 3 * (size_t)i + c, g[c]);
+    sink.put(3, (size_t)i, g[6]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) sink.put(4, 3 * (size_t)i + c, g[7 + c]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) sink.put(5, 4 * (size_t)i + c, g[10 + c]);
+  }
+  if (row > 0) {
+    __syncthreads();
+    adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt);
   }
 }
 
@@ -449,19 +525,38 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
 }  // extern "C"
 
 namespace {
+int fill_adam(const FsgsFusedAdam *adam, int max_sh_degree, AdamDev &ad) {
+  std::memset(&ad, 0, sizeof(ad));
+  for (int g = 0; g < 6; g++) {
+    const bool needed = !(g == 2 && max_sh_degree == 0);
+    if (needed && (!adam->exp_avg[g] || !adam->exp_avg_sq[g] || adam->step[g] < 1)) return FSGS_ERR_INVALID;
+    ad.m[g] = adam->exp_avg[g];
+    ad.v[g] = adam->exp_avg_sq[g];
+    const double bc1 = 1.0 - pow(adam->beta1, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
+    const double bc2 = 1.0 - pow(adam->beta2, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
+    ad.step_size[g] = (float)((double)adam->lr[g] / bc1);  // exactly fsgs_adam_step's host arithmetic
+    ad.inv_bc2_sqrt[g] = (float)(1.0 / sqrt(bc2));
+  }
+  ad.omb1 = (float)(1.0 - adam->beta1);
+  ad.b2 = (float)adam->beta2;
+  ad.omb2 = (float)(1.0 - adam->beta2);
+  ad.eps = (float)adam->eps;
+  return FSGS_OK;
+}
+
 // adam == nullptr: gradients are written to `grads`; otherwise they feed the in-place Adam update (grads->means2D is
 // still written: the densification statistic needs it)
 int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
-                         int param_grads, const FsgsRenderGrads *grads, const FsgsFusedAdam *adam, void *scratch,
-                         size_t scratch_bytes, fsgs_stream_t stream_) {
+                         int param_grads, const FsgsRenderGrads *grads, const FsgsFusedAdam *adam, float *compact,
+                         void *scratch, size_t scratch_bytes, fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
   if (P == 0) return FSGS_OK;
   if (!args_ok(args, P) || !radii || !scratch || !grads->means2D) return FSGS_ERR_INVALID;
   if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
-  if (!adam) {
+  if (!adam && !compact) {
     if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
     if (param_grads && (!grads->features_dc || !grads->opacity || !grads->scaling || !grads->rotation ||
                         (args->max_sh_degree > 0 && !grads->features_rest)))
@@ -470,22 +565,10 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   AdamDev ad;
   std::memset(&ad, 0, sizeof(ad));
   if (adam) {
-    if (!gs_grad || !param_grads) return FSGS_ERR_INVALID;
-    for (int g = 0; g < 6; g++) {
-      const bool needed = !(g == 2 && args->max_sh_degree == 0);
-      if (needed && (!adam->exp_avg[g] || !adam->exp_avg_sq[g] || adam->step[g] < 1)) return FSGS_ERR_INVALID;
-      ad.m[g] = adam->exp_avg[g];
-      ad.v[g] = adam->exp_avg_sq[g];
-      const double bc1 = 1.0 - pow(adam->beta1, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
-      const double bc2 = 1.0 - pow(adam->beta2, (double)(adam->step[g] < 1 ? 1 : adam->step[g]));
-      ad.step_size[g] = (float)((double)adam->lr[g] / bc1);      // exactly fsgs_adam_step's host arithmetic
-      ad.inv_bc2_sqrt[g] = (float)(1.0 / sqrt(bc2));
-    }
-    ad.omb1 = (float)(1.0 - adam->beta1);
-    ad.b2 = (float)adam->beta2;
-    ad.omb2 = (float)(1.0 - adam->beta2);
-    ad.eps = (float)adam->eps;
+    if (!gs_grad || !param_grads || compact) return FSGS_ERR_INVALID;
+    if (fill_adam(adam, args->max_sh_degree, ad) != FSGS_OK) return FSGS_ERR_INVALID;
   }
+  if (compact && (!gs_grad || !param_grads)) return FSGS_ERR_INVALID;
   const int W = cfg->image_width, H = cfg->image_height;
   if (max_pairs < 0 || num_rendered < 0 || num_rendered > max_pairs) return FSGS_ERR_STATE;
   StateLayout SL = state_layout(P, W, H, max_pairs, 6);
@@ -521,16 +604,20 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   FSGS_HIP(hipGetLastError());
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);
   RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
-                     grads->rotation, grads->means2D, grads->w2c};
+                     grads->rotation, grads->means2D, grads->w2c, compact};
   {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     if (adam)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args),
-                         radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
+    else if (compact)
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad);
     else
-      hipLaunchKernelGGL(render_pre_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args),
-                         radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad);
   }
   FSGS_HIP(hipGetLastError());
@@ -546,8 +633,8 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          int param_grads, const FsgsRenderGrads *grads, void *scratch, size_t scratch_bytes,
                          fsgs_stream_t stream) {
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
-                              dL_ddepth_sil, gs_grad, cam_grad, param_grads, grads, nullptr, scratch, scratch_bytes,
-                              stream);
+                              dL_ddepth_sil, gs_grad, cam_grad, param_grads, grads, nullptr, nullptr, scratch,
+                              scratch_bytes, stream);
 }
 
 int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
@@ -559,7 +646,39 @@ int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderA
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
-                              dL_ddepth_sil, 1, 0, 1, &g, adam, scratch, scratch_bytes, stream);
+                              dL_ddepth_sil, 1, 0, 1, &g, adam, nullptr, scratch, scratch_bytes, stream);
+}
+
+int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                                 const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                                 const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
+                                 float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
+  if (!gcompact || !means2D_grad) return FSGS_ERR_INVALID;
+  FsgsRenderGrads g;
+  std::memset(&g, 0, sizeof(g));
+  g.means2D = means2D_grad;
+  return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
+                              dL_ddepth_sil, 1, 0, 1, &g, nullptr, gcompact, scratch, scratch_bytes, stream);
+}
+
+int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,
+                           fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P < 0 || !adam) return FSGS_ERR_INVALID;
+  if (P == 0) return FSGS_OK;
+  if (!args || !gcompact || !args->xyz || !args->features_dc || !args->opacity || !args->scaling || !args->rotation ||
+      !args->cam_center || args->active_sh_degree < 0 || args->active_sh_degree > 3 ||
+      args->max_sh_degree < args->active_sh_degree || args->max_sh_degree > 3 ||
+      (args->max_sh_degree > 0 && !args->features_rest))
+    return FSGS_ERR_INVALID;
+  AdamDev ad;
+  if (fill_adam(adam, args->max_sh_degree, ad) != FSGS_OK) return FSGS_ERR_INVALID;
+  {
+    ProfScope ps(PROF_ADAM, stream);
+    hipLaunchKernelGGL(adam_compact_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, to_dev(args), gcompact, ad);
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
 }
 
 }  // extern "C"

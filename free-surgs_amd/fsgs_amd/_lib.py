@@ -114,6 +114,12 @@ _PROTOTYPES = {
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _i, _i, _i,
          C.POINTER(FsgsRenderGrads), _vp, _sz, _vp],
     ),
+    "fsgs_render_backward_compact": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+         _sz, _vp],
+    ),
+    "fsgs_adam_step_compact": (_i, [_i, C.POINTER(FsgsRenderArgs), _vp, C.POINTER(FsgsFusedAdam), _vp]),
     "fsgs_render_backward_adam": (
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp,

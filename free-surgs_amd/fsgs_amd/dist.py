@@ -1,6 +1,7 @@
 """Frame-sharded data parallelism: one process per GPU, every rank holds the whole
-Gaussian cloud + Adam state and renders its own camera; ONE all-reduce(SUM) of the packed gradient
-buffer per step over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests), plus the
+Gaussian cloud + Adam state and renders its own camera; ONE all-reduce(SUM) per step over RCCL/xGMI -- of the
+compact [P,14] gradient with the HIP step driver (all_reduce_compact), of the packed [59 P] gradient
+buffer under autograd (GradBucket / sync_gradients) (backend "nccl" on ROCm; "gloo" in the CPU tests), plus the
 densification statistics (SUM, SUM, MAX).  The reference has no distributed code at all."""
 import os
 
@@ -56,6 +57,14 @@ class GradBucket:
     def all_reduce(self):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
+def all_reduce_compact(gc):
+    """all-reduce(SUM) of the compact [P,14] gradient of fast_step.FastStepper (56 B per Gaussian instead of 236 B:
+    the SH gradients are rank-1 in a rank-independent basis, see csrc/render.hip OUT_COMPACT).  16.8 MB at
+    P = 300 k -- what actually has to cross the point-to-point xGMI links."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(gc, op=dist.ReduceOp.SUM)
 
 
 def sync_gradients(pc, bucket=None):

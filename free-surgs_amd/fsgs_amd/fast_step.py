@@ -58,6 +58,7 @@ class _Buffers:
         self.flow_out = self.terms[5:7]  # {flow loss, #valid points}
         self.flow_scratch = None
         self.d_flow = f(4, 4)
+        self.gc = self.gc_view = None  # compact gradient [P,14] (lazily: only multi-view / multi-rank steps)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
         self.bwd_scratch = torch.empty((P * 56 + 512,), dtype=torch.uint8, device=dev)
@@ -73,6 +74,7 @@ class FastStepper:
         self.lib = _lib.load()
         self.last = {}
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
+        self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
 
     # ---- helpers -----------------------------------------------------------------------------------------
     def _buffers(self, P, H, W, n_patches, dev):
@@ -167,7 +169,12 @@ class FastStepper:
         return g
 
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
-    def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None):
+    def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None):
+        """One mapping iteration over `timesteps` (summed loss).  Gradient routes:
+          * one view, no reduction, optimizer stepped here  -> Adam inside the render backward (no gradient tensors);
+          * several views and / or `reduce_compact(tensor)` (the data-parallel all-reduce) -> the compact [P,14]
+            gradient is summed / reduced and consumed by fsgs_adam_step_compact;
+          * step_optimizer=False or the legacy `grad_sync(pc)` -> full gradients in the parameters' .grad."""
         pc, lib = self.pc, self.lib
         dev = pc.params["_xyz"].device
         H, W = int(pc.cam.image_height), int(pc.cam.image_width)
@@ -208,9 +215,9 @@ class FastStepper:
                                                               _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
                 torch.cuda.current_stream().wait_event(side_done)
+                fused_ok = step_optimizer and grad_sync is None and isinstance(pc.optimizer, optim.FusedAdam)
                 # single view, single rank: the backward feeds Adam directly (no gradient tensors at all)
-                fuse_adam = (self.fuse_adam and len(timesteps) == 1 and grad_sync is None and step_optimizer
-                             and isinstance(pc.optimizer, optim.FusedAdam))
+                fuse_adam = self.fuse_adam and fused_ok and len(timesteps) == 1 and reduce_compact is None
                 if fuse_adam:
                     adam = self._fused_adam_struct()
                     cfg = self._cfg()
@@ -223,6 +230,35 @@ class FastStepper:
                     total = torch.dot(b.terms, b.term_w)
                     radii0 = b.radii
                     break
+                if self.compact and fused_ok:
+                    first = k == 0
+                    if b.gc is None:
+                        b.gc = torch.empty((pc.num_points, 14), dtype=torch.float32, device=dev)
+                        b.gc_view = torch.empty_like(b.gc)
+                    tgt_gc = b.gc if first else b.gc_view
+                    m2 = b.means2D_grad if first else torch.empty_like(b.means2D_grad)
+                    cfg = self._cfg()
+                    _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
+                                                                _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
+                                                                _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
+                                                                _lib.ptr(tgt_gc), _lib.ptr(m2), _lib.ptr(b.bwd_scratch),
+                                                                b.bwd_scratch.numel(), stream),
+                               "fsgs_render_backward_compact")
+                    if not first:
+                        b.gc.add_(b.gc_view)
+                        pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
+                    loss_k = torch.dot(b.terms, b.term_w)
+                    total = loss_k if total is None else total + loss_k
+                    if first:
+                        radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
+                    if k == len(timesteps) - 1:
+                        if reduce_compact is not None:
+                            reduce_compact(b.gc)  # ONE all-reduce of 56 B / Gaussian
+                        adam = self._fused_adam_struct()
+                        _lib.check(lib.fsgs_adam_step_compact(pc.num_points, C.byref(args), _lib.ptr(b.gc),
+                                                              C.byref(adam), stream), "fsgs_adam_step_compact")
+                        step_optimizer = False  # done
+                    continue
                 # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
                 first = k == 0
                 tgt = []

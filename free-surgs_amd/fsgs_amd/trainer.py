@@ -214,6 +214,15 @@ class Runner:
         for _ in range(mapping_iter):
             self.iteration += 1
             ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
+            it = self.iteration
+            special = self.densify and ((it % 300 == 0 and it < 15000) or it % 3000 == 0)
+            if self.fast is not None and not special:
+                # nothing happens between backward and optimizer.step() on this iteration (train.py:266-272):
+                # the step driver may consume the gradient itself (Adam fused / compact gradient)
+                self.fast.pc = self.pc
+                self.fast.mapping_step(ts, step_optimizer=True)
+                pkg = None
+                continue
             if self.fast is not None:
                 self.fast.pc = self.pc
                 self.fast.mapping_step(ts, step_optimizer=False)

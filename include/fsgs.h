@@ -192,6 +192,20 @@ int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderA
                               const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
                               float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
 
+/* Compact gradient for steps that sum several views and / or several ranks: gcompact [P,14] =
+ * [d xyz (3) | gcol (3) | d opacity | d scaling (3) | d rotation (4)] where gcol is the clamped dL/dcolour.  The
+ * gradient of the 48 SH coefficients of a Gaussian is basis_k(direction) x gcol_c with a view-independent basis
+ * (world position, frame-0 camera centre; scene/gaussian_model.py:317-318), so sums over views and ranks only
+ * need gcol: 56 B per Gaussian cross xGMI instead of 236 B.  gs_grad = 1, param_grads = 1, cam_grad = 0. */
+int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                                 const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                                 const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
+                                 float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+/* Adam step of the six groups from the (summed / all-reduced) compact gradient: the SH outer products are formed
+ * on the fly.  Updates args->xyz ... args->rotation and the moments in place; args->w2c is not read. */
+int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,
+                           fsgs_stream_t stream);
+
 /* ---- simple-knn -------------------------------------------------------------- */
 
 /* Mean squared distance to the 3 nearest neighbours, exact (distCUDA2).

@@ -49,7 +49,7 @@ def _corners(H, W, dev):
     return (torch.randint(0, H - 128, (n,), generator=g).to(dev), torch.randint(0, W - 128, (n,), generator=g).to(dev))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
     from fsgs_amd import dist as fdist
@@ -61,12 +61,16 @@ def _worker(rank, world, port, out_dir):
     fdist.init_from_env(backend="gloo")
     pc, poses, frames, (H, W) = _world(dev)
     cr = _corners(H, W, dev)
-    bucket = fdist.GradBucket(pc)
     fs = FastStepper(pc, poses, frames)
+    if mode == "bucket":
+        bucket = fdist.GradBucket(pc)
     for step in range(2):
-        bucket.attach(pc, zero=False)  # the stepper overwrites every gradient element
-        loss = fs.mapping_step([rank], grad_sync=lambda p: fdist.sync_gradients(p, bucket), corners=cr)
-        assert all(pc.params[k].grad.data_ptr() == bucket.views[k].data_ptr() for k in PARAM_NAMES)
+        if mode == "bucket":  # legacy route: full [59 P] gradients, all-reduced in place, multi-tensor Adam
+            bucket.attach(pc, zero=False)  # the stepper overwrites every gradient element
+            loss = fs.mapping_step([rank], grad_sync=lambda p: fdist.sync_gradients(p, bucket), corners=cr)
+            assert all(pc.params[k].grad.data_ptr() == bucket.views[k].data_ptr() for k in PARAM_NAMES)
+        else:  # compact [P,14] gradient, one all-reduce, Adam from the compact form
+            loss = fs.mapping_step([rank], reduce_compact=fdist.all_reduce_compact, corners=cr)
     torch.cuda.synchronize()
     torch.save({k: pc.params[k].detach().cpu() for k in PARAM_NAMES} | {"loss": loss.detach().cpu()},
                os.path.join(out_dir, "rank%d.pt" % rank))
@@ -74,11 +78,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path):
+@pytest.mark.parametrize("mode", ["compact", "bucket"])
+def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
     from fsgs_amd.fast_step import FastStepper
     from fsgs_amd.model import PARAM_NAMES
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
     a = torch.load(os.path.join(tmp_path, "rank0.pt"))
     b = torch.load(os.path.join(tmp_path, "rank1.pt"))
     for k in PARAM_NAMES:
