@@ -18,6 +18,10 @@ def init_from_env(backend=None):
         return 0, 1, 0
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("FSGS_DIST_ONE_GPU") == "1":
+        # smoke-testing the N > 1 code path on a box with ONE GPU: every rank on device 0, gloo carries the tensors
+        # (RCCL refuses two ranks on one device).  Never set in production.
+        local, backend = 0, "gloo"
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
