@@ -112,6 +112,10 @@ def main():
                          "stepper (fast_step.FastStepper); same arithmetic, more host overhead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the extra tracking-iteration timing")
+    ap.add_argument("--ar-chunks", type=int, default=1,
+                    help="N > 1: > 1 splits the gradient all-reduce into row chunks pipelined with the Adam kernel "
+                         "(PipelinedCompactReducer); default one collective: at 16.8 MB the per-collective latency of "
+                         "several smaller ones eats the ~60 us of Adam they could hide")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     args = ap.parse_args()
@@ -149,11 +153,14 @@ def main():
 
         stepper = FastStepper(pc, poses, frames)
 
+    # N > 1: ONE all-reduce of the compact gradient (optionally chunked and pipelined with Adam, --ar-chunks)
+    reducer = fdist.PipelinedCompactReducer(args.ar_chunks) if args.ar_chunks > 1 else fdist.all_reduce_compact
+
     def one_step(it):
         ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
         if use_fast:
             # N > 1: ONE all-reduce of the compact [P,14] gradient (56 B / Gaussian), then Adam from it
-            red = fdist.all_reduce_compact if world > 1 else ((lambda t_: None) if args.dp_path else None)
+            red = reducer if world > 1 else ((lambda t_: None) if args.dp_path else None)
             return stepper.mapping_step([ts], reduce_compact=red), None
         if bucket is not None:
             bucket.attach(pc)

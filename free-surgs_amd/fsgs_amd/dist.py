@@ -71,6 +71,49 @@ def all_reduce_compact(gc):
         dist.all_reduce(gc, op=dist.ReduceOp.SUM)
 
 
+class PipelinedCompactReducer:
+    """all-reduce of the compact gradient in `nchunks` row ranges on a second stream, the Adam kernel of chunk i
+    running beside the all-reduce of chunk i+1:  t = AR + Adam / nchunks instead of AR + Adam.  Chunk boundaries are
+    multiples of 256 Gaussians (the Adam kernel's workgroup; keeps every 16-byte access aligned)."""
+
+    pipelined = True
+
+    def __init__(self, nchunks=4):
+        self.nchunks = max(1, int(nchunks))
+        self.side = None
+
+    def __call__(self, gc, adam_rows):
+        P = int(gc.shape[0])
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            adam_rows(0, P)
+            return
+        per = -(-P // self.nchunks)
+        per = max(256, -(-per // 256) * 256)
+        bounds = [(lo, min(P, lo + per)) for lo in range(0, P, per)]
+        if not gc.is_cuda:
+            for lo, hi in bounds:
+                dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)
+                adam_rows(lo, hi)
+            return
+        main = torch.cuda.current_stream(gc.device)
+        if self.side is None or self.side.device != gc.device:
+            self.side = torch.cuda.Stream(device=gc.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)
+        done = []
+        with torch.cuda.stream(self.side):
+            for lo, hi in bounds:
+                dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)
+                e = torch.cuda.Event()
+                e.record(self.side)
+                done.append(e)
+        gc.record_stream(self.side)
+        for (lo, hi), e in zip(bounds, done):
+            main.wait_event(e)
+            adam_rows(lo, hi)
+
+
 def sync_gradients(pc, bucket=None):
     """all-reduce(SUM) of the Gaussian gradients.  With a bucket attached before backward this is a
     single collective on one contiguous buffer; otherwise gradients are packed first."""

@@ -144,6 +144,27 @@ class FastStepper:
             adam.beta1, adam.beta2, adam.eps = float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
         return adam
 
+    @staticmethod
+    def _offset_structs(args, adam, lo):
+        """the same FsgsRenderArgs / FsgsFusedAdam with every per-Gaussian pointer advanced by `lo` Gaussians"""
+        if lo == 0:
+            return args, adam
+        rows = (3, 3, 45, 1, 3, 4)  # floats per Gaussian: xyz, f_dc, f_rest, opacity, scaling, rotation
+        a2 = _lib.FsgsRenderArgs()
+        C.memmove(C.byref(a2), C.byref(args), C.sizeof(a2))
+        rest_row = ((int(args.max_sh_degree) + 1) ** 2 - 1) * 3
+        for name, r in zip(("xyz", "features_dc", "features_rest", "opacity", "scaling", "rotation"),
+                           (3, 3, rest_row, 1, 3, 4)):
+            v = getattr(args, name)
+            setattr(a2, name, None if not v else v + 4 * r * lo)
+        ad2 = _lib.FsgsFusedAdam()
+        C.memmove(C.byref(ad2), C.byref(adam), C.sizeof(ad2))
+        for g, r in enumerate((3, 3, rest_row, 1, 3, 4)):
+            if adam.exp_avg[g]:
+                ad2.exp_avg[g] = adam.exp_avg[g] + 4 * r * lo
+                ad2.exp_avg_sq[g] = adam.exp_avg_sq[g] + 4 * r * lo
+        return a2, ad2
+
     def _side_stream(self, dev):
         st = getattr(self, "_side", None)
         if st is None or st.device != torch.device(dev):
@@ -252,11 +273,23 @@ class FastStepper:
                     if first:
                         radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
                     if k == len(timesteps) - 1:
-                        if reduce_compact is not None:
-                            reduce_compact(b.gc)  # ONE all-reduce of 56 B / Gaussian
                         adam = self._fused_adam_struct()
-                        _lib.check(lib.fsgs_adam_step_compact(pc.num_points, C.byref(args), _lib.ptr(b.gc),
-                                                              C.byref(adam), stream), "fsgs_adam_step_compact")
+
+                        def adam_rows(lo, hi, args=args, adam=adam):
+                            """Adam for Gaussians [lo, hi) from the (reduced) compact gradient"""
+                            a2, ad2 = self._offset_structs(args, adam, lo)
+                            with torch.cuda.device(dev):
+                                _lib.check(lib.fsgs_adam_step_compact(hi - lo, C.byref(a2), b.gc.data_ptr() + lo * 56,
+                                                                      C.byref(ad2), _lib.current_stream()),
+                                           "fsgs_adam_step_compact")
+
+                        if reduce_compact is None:
+                            adam_rows(0, pc.num_points)
+                        elif getattr(reduce_compact, "pipelined", False):
+                            reduce_compact(b.gc, adam_rows)  # chunked: all-reduce of chunk i+1 beside Adam of chunk i
+                        else:
+                            reduce_compact(b.gc)  # ONE all-reduce of 56 B / Gaussian
+                            adam_rows(0, pc.num_points)
                         step_optimizer = False  # done
                     continue
                 # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
