@@ -85,16 +85,22 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
     t0 = time.time()
     n = 0
     R = 0
+    t_fwd = t_bwd = 0.0
     while True:
         for c in (col, dcol):
+            ta = time.time()
             img, dep, radii, st = o.raster_forward(cam, sc["_xyz"], c, op.reshape(-1), s, r)
+            tb = time.time()
             o.raster_backward(st, dL)
+            t_fwd += tb - ta
+            t_bwd += time.time() - tb
             R = st.num_rendered
         n += 1
         if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
             break
     dt = (time.time() - t0) / n
     return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "raster_fwd_ms_per_pass": 1e3 * t_fwd / (2 * n), "raster_bwd_ms_per_pass": 1e3 * t_bwd / (2 * n),
             "sample": "%d full step(s) of the rasteriser part only (2 passes fwd+bwd, %dx%d, P=%d, R=%d), "
                       "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
 
