@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
 }
 
 constexpr int SORT_LDS_KEYS = 2048;  // 16 KB of LDS per workgroup; longer lists sort in global memory
+constexpr int SORT_RANK_KEYS = 256;  // up to here: rank sort (one key per thread); above: bitonic network
 
 // compare-exchange network over m (power of two) virtual elements, n real ones; every exchange puts the
 // smaller key at the lower index, so the +inf padding (indices >= n) never moves and is never touched.
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
                                                          unsigned long long *__restrict__ keys,
                                                          uint32_t *__restrict__ plist, int2 *__restrict__ ranges,
                                                          uint32_t cap_sub, uint32_t *__restrict__ overflow_need) {
-  __shared__ unsigned long long lds[SORT_LDS_KEYS];
+  __shared__ __attribute__((aligned(16))) unsigned long long lds[SORT_LDS_KEYS + 2];
   const int tile = blockIdx.x;
   // the eight segment fill counts (wave-uniform loads); a count above the capacity = dropped keys
   uint32_t cnt[BIN_SUBS], off[BIN_SUBS + 1], worst = 0;
@@ -298,8 +299,28 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
 #pragma unroll
     for (int s = 0; s < BIN_SUBS; s++)
       for (uint32_t i = threadIdx.x; i < cnt[s]; i += blockDim.x) lds[off[s] + i] = gk[(size_t)s * cap_sub + i];
-    bitonic_sort_ascending<true>(lds, n, m);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) plist[base + i] = (uint32_t)lds[i];
+    if (n <= SORT_RANK_KEYS) {
+      // Short lists (most tiles: mean 214 at C2): RANK sort.  Keys are unique (the Gaussian index sits in the low
+      // word), so a key's final position is the number of keys below it; thread t counts that for key t against
+      // the whole list, two list keys per broadcast ds_read_b128.  n^2 compares, but the only LDS traffic is
+      // broadcast reads -- the bitonic network moves every key through LDS 36 times and is LDS-bandwidth-bound.
+      // (Two keys per thread, n <= 512, was measured too: slower than the network from n ~ 300.)
+      if (threadIdx.x == 0) { lds[n] = ~0ull; lds[n + 1] = ~0ull; }  // +inf padding for the pairwise reads
+      __syncthreads();
+      const int t = threadIdx.x;
+      const bool mine = t < n;
+      const unsigned long long key = mine ? lds[t] : 0ull;
+      uint32_t rank = 0;
+      const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(lds);
+      for (int j = 0; j < (n + 1) >> 1; j++) {
+        const ulonglong2 ab = pairs[j];
+        rank += (ab.x < key) + (ab.y < key);
+      }
+      if (mine) plist[base + rank] = (uint32_t)key;
+    } else {
+      bitonic_sort_ascending<true>(lds, n, m);
+      for (int i = threadIdx.x; i < n; i += blockDim.x) plist[base + i] = (uint32_t)lds[i];
+    }
   } else {  // rare: a tile with more than 2048 Gaussians sorts in place in global memory (L2 resident)
     // close the gaps between the segments first: segment s moves down to off[s] (destination <= source; a chunk
     // is read by everybody before anybody writes it, chunks ascend)
