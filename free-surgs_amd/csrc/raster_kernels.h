@@ -460,6 +460,73 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
   }
 }
 
+// The default order (one band): the same job with the list lengths kept in registers (ntiles <= 8192), one
+// 1024-bin histogram and one bin per thread in the scan -- half the latency chain of the general kernel.
+__global__ __launch_bounds__(1024) void tile_order_lpt_kernel(int ntiles, const int2 *__restrict__ ranges,
+                                                              uint32_t *__restrict__ order,
+                                                              uint32_t *__restrict__ total_out,
+                                                              const uint32_t *__restrict__ overflow_need,
+                                                              uint32_t *host_word) {
+  __shared__ uint32_t hist[ORDER_BINS];
+  __shared__ uint32_t wave_tot[16], wave_len[16];
+  constexpr int PER = 8;
+  int len[PER];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) {  // strided ownership: coalesced loads
+    const int i = threadIdx.x + 1024 * q;
+    len[q] = 0;
+    if (i < ntiles) {
+      const int2 rg = ranges[i];
+      len[q] = rg.y - rg.x;
+    }
+    mine += (uint32_t)len[q];
+  }
+  hist[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    uint32_t s = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off, 64);
+    if (lane == 0) wave_len[wv] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; q++)
+    if (threadIdx.x + 1024 * q < ntiles) atomicAdd(&hist[ORDER_BINS - 1 - min(len[q], ORDER_BINS - 1)], 1u);  // bin 0 = longest
+  if (threadIdx.x == 0) {
+    uint32_t R = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) R += wave_len[w];
+    *total_out = R;
+    const uint32_t need = *overflow_need;
+    if (host_word)
+      __hip_atomic_store(host_word, need ? (0x80000000u | need) : R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  // exclusive scan of the 1024 bins, one per thread
+  const uint32_t c = hist[threadIdx.x];
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++)
+    if (w < wv) before += wave_tot[w];
+  hist[threadIdx.x] = before + incl - c;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int i = threadIdx.x + 1024 * q;
+    if (i < ntiles) order[atomicAdd(&hist[ORDER_BINS - 1 - min(len[q], ORDER_BINS - 1)], 1u)] = (uint32_t)i;
+  }
+}
+
 // Pixel ownership inside a 16x16 tile: four 8x8 quadrants, lane l owns pixel (l & 7, l >> 3) of each
 // quadrant k = 0..3 at offset (8*(k&1), 8*(k>>1)).  Whether a Gaussian can reach a quadrant at all is a
 // wave-uniform question answered once per pair by its owning lane (rect_touched, exact), carried as a
@@ -1047,9 +1114,13 @@ inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t m
     ProfScope ps(PROF_SORT_TILE, stream);
     hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
                        B.ranges, tk.cap_sub, B.total + 1);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
-                       (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order, B.total, B.total + 1,
-                       (uint32_t *)tk.slot);
+    if (!(cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) && ntiles <= 8 * 1024)
+      hipLaunchKernelGGL(tile_order_lpt_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.ranges, B.order, B.total,
+                         B.total + 1, (uint32_t *)tk.slot);
+    else
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
+                         (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order, B.total,
+                         B.total + 1, (uint32_t *)tk.slot);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
