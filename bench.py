@@ -205,7 +205,8 @@ def main():
     if launches:
         # blend_bwd algorithmic bytes per launch: R*(4 idx + 24 xy/conic/opacity + 4C colour) +
         # HW*(4C dL/dpixel + 8 final_T/n_contrib) + P*4*(6 + C) accumulated gradients
-        b_alg = R * (4 + 24 + 4 * C) + H * W * (4 * C + 8) + P * 4 * (6 + C)
+        cg = 4 if (use_fast and C == 6) else C  # planes of dL/dpixel actually read (rgb + depth)
+        b_alg = R * (4 + 24 + 4 * C) + H * W * (4 * cg + 8) + P * 4 * (6 + C)
         avg_s = ms_total / launches / 1e3
         ach = b_alg / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

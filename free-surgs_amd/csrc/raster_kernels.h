@@ -700,7 +700,9 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // the pose, the opacity gradient and the densification statistic are not used (SURVEY a1 note v).  8 slots per
 // Gaussian, so the transposing reduction of a Gaussian pair shrinks to 16 values, and only the RGB channels
 // carry a gradient.
-template <int C, bool SPLIT, bool POSE_ONLY = false>
+// CGRAD < C: only the first CGRAD channels carry dL/dpixel (the fused render's losses never touch the silhouette
+// and depth^2 planes: CGRAD = 4 drops their two FMAs in the colour dot product and their two dcolour sums).
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C>
 __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     float *__restrict__ dcolors) {
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   constexpr int REC4 = C > 4 ? 4 : 3;
-  constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : C;  // channels that carry dL/dpixel
+  constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : CGRAD;  // channels that carry dL/dpixel
   constexpr int GP = 2;                                // Gaussians per transposing reduction
   constexpr int SL = POSE_ONLY ? 8 : 16;               // slots per Gaussian
   constexpr int NV = GP * SL;                          // values per lane entering the reduction
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   // after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
   const int my_u = (lane / REP) / SL, my_c = (lane / REP) % SL;
   const bool c_used = !(lane & (REP - 1)) && (POSE_ONLY ? my_c < 5
-                                                : (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + C)));
+                                                : (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + CG)));
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -1154,11 +1156,11 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
-template <int C, bool SPLIT = false, bool POSE_ONLY = false>
+template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C>
 int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
                      colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
   return 0;
 }

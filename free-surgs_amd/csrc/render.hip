@@ -594,6 +594,12 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                                        (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
                                        dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+    else if (cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY)  // dL_ddepth_sil is [1,H,W]: planes 1, 2 carry no gradient
+      launch_blend_bwd<6, true, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+                                          (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
+                                          (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                          (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
+                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
     else
       launch_blend_bwd<6, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
                                 (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),

@@ -88,6 +88,9 @@ class FastStepper:
         key = (id(cam), cam.viewmatrix._version, cam.projmatrix._version, cam.bg._version)
         if self.cfg_key != key:
             self.cfg = rasterizer.make_cfg(cam, 6)
+            # this driver only ever hands the backward a gradient of the depth plane (Pearson losses): the silhouette and
+            # depth^2 planes of d_depth_sil stay zero, and the flag lets the backward blend drop their terms
+            self.cfg.flags |= _lib.FSGS_FLAG_DEPTH_GRAD_ONLY
             self.cfg_key = key
         return self.cfg
 

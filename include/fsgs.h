@@ -51,6 +51,10 @@ enum {
 /* dispatch the blend workgroups XCD-banded (each XCD's L2 sees one band of the image: less fabric traffic)
  * instead of plain longest-list-first over the whole image (default, ~10 % faster on MI355X) */
 #define FSGS_FLAG_XCD_BANDED_ORDER 1
+/* fsgs_render_backward*: dL_ddepth_sil is a [1,H,W] gradient of the DEPTH plane only -- the silhouette and depth^2
+ * planes get no gradient from any loss of the reference (train.py:166-272: rgb + Pearson(depth); the presence
+ * mask and the uncertainty are detached), and the backward blend drops their terms */
+#define FSGS_FLAG_DEPTH_GRAD_ONLY 2
 
 /* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
  * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
