@@ -216,7 +216,8 @@ def main():
         # gfx950 FETCH_SIZE x2 correction calibrated on the Adam kernel) for exactly this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "blend_bwd_kernel<%d; %s; false>" % (C, "true" if fused else "false")
+            key = "blend_bwd_kernel<%d; %s; false%s>" % (C, "true" if fused else "false",
+                                                         "; 4" if (use_fast and C == 6) else "")
             if pmc.get("config") == args.config and key in pmc["kernels"] and world == 1:
                 roofline["traffic"] = pmc["kernels"][key]["traffic_bytes"]
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
@@ -225,7 +226,7 @@ def main():
                     issue_s = wi * 4.0 / (256 * 4 * 2.4e9)
                     roofline["valu"] = {"wave_insts": wi, "issue_bound_ms": issue_s * 1e3,
                                         "frac_of_issue_bound": issue_s / avg_s,
-                                        "source": "SQ_INSTS_VALU, profiles/r01_v8_sq_counters.txt"}
+                                        "source": "SQ_INSTS_VALU, profiles/r01_v9_sq_counters.txt"}
         except Exception:
             pass
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
