@@ -118,6 +118,9 @@ def main():
                          "stepper (fast_step.FastStepper); same arithmetic, more host overhead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the extra tracking-iteration timing")
+    ap.add_argument("--no-stats", action="store_true",
+                    help="mapping iteration WITHOUT the densification statistics (the second half of global_run: "
+                         "iteration >= 15000); the default keeps them, as the first 15000 iterations do")
     ap.add_argument("--ar-chunks", type=int, default=1,
                     help="N > 1: > 1 splits the gradient all-reduce into row chunks pipelined with the Adam kernel "
                          "(PipelinedCompactReducer); default one collective: at 16.8 MB the per-collective latency of "
@@ -167,7 +170,7 @@ def main():
         if use_fast:
             # N > 1: ONE all-reduce of the compact [P,14] gradient (56 B / Gaussian), then Adam from it
             red = reducer if world > 1 else ((lambda t_: None) if args.dp_path else None)
-            return stepper.mapping_step([ts], reduce_compact=red), None
+            return stepper.mapping_step([ts], reduce_compact=red, collect_stats=not args.no_stats), None
         if bucket is not None:
             bucket.attach(pc)
         sync = (lambda pc_: fdist.sync_gradients(pc_, bucket)) if world > 1 else None

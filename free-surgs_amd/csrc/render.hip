@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
     }
   }
   if (i < P) {
-    out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f;
+    if (out.means2D) { out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f; }
     if (OUT != OUT_GRADS || out.xyz) {
       sink.put(0, 3 * (size_t)i, dxyz[0]);
       sink.put(0, 3 * (size_t)i + 1, dxyz[1]);
@@ -554,7 +554,8 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
   if (P == 0) return FSGS_OK;
-  if (!args_ok(args, P) || !radii || !scratch || !grads->means2D) return FSGS_ERR_INVALID;
+  if (!args_ok(args, P) || !radii || !scratch) return FSGS_ERR_INVALID;
+  if (!grads->means2D && !adam && !compact) return FSGS_ERR_INVALID;  // the autograd-facing form always has a holder
   if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
   if (!adam && !compact) {
     if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
@@ -594,6 +595,13 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                                        (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
                                        dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+    else if ((cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY) && !grads->means2D)
+      // nobody wants the densification statistic (means2D_grad == NULL): the RGB-only mean2D moments are dropped too
+      launch_blend_bwd<6, false, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+                                           (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
+                                           (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                           (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
+                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
     else if (cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY)  // dL_ddepth_sil is [1,H,W]: planes 1, 2 carry no gradient
       launch_blend_bwd<6, true, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                           (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
@@ -647,7 +655,7 @@ int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderA
                               const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                               const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
                               float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
-  if (!adam || !means2D_grad) return FSGS_ERR_INVALID;
+  if (!adam) return FSGS_ERR_INVALID;
   FsgsRenderGrads g;
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;
@@ -659,7 +667,7 @@ int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRend
                                  const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                                  const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
                                  float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
-  if (!gcompact || !means2D_grad) return FSGS_ERR_INVALID;
+  if (!gcompact) return FSGS_ERR_INVALID;
   FsgsRenderGrads g;
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;

@@ -193,12 +193,15 @@ class FastStepper:
         return g
 
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
-    def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None):
+    def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None,
+                     collect_stats=True):
         """One mapping iteration over `timesteps` (summed loss).  Gradient routes:
           * one view, no reduction, optimizer stepped here  -> Adam inside the render backward (no gradient tensors);
           * several views and / or `reduce_compact(tensor)` (the data-parallel all-reduce) -> the compact [P,14]
             gradient is summed / reduced and consumed by fsgs_adam_step_compact;
-          * step_optimizer=False or the legacy `grad_sync(pc)` -> full gradients in the parameters' .grad."""
+          * step_optimizer=False or the legacy `grad_sync(pc)` -> full gradients in the parameters' .grad.
+        collect_stats=False (only with the first two routes): the densification statistics are not accumulated --
+        for iterations past the last densification (train.py:305: `iteration < 15000`), where nothing reads them."""
         pc, lib = self.pc, self.lib
         dev = pc.params["_xyz"].device
         H, W = int(pc.cam.image_height), int(pc.cam.image_width)
@@ -248,7 +251,8 @@ class FastStepper:
                     _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                                              _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
                                                              _lib.ptr(b.d_depth_sil), C.byref(adam),
-                                                             _lib.ptr(b.means2D_grad), _lib.ptr(b.bwd_scratch),
+                                                             _lib.ptr(b.means2D_grad) if collect_stats else None,
+                                                             _lib.ptr(b.bwd_scratch),
                                                              b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
                     step_optimizer = False  # done
                     total = torch.dot(b.terms, b.term_w)
@@ -260,17 +264,19 @@ class FastStepper:
                         b.gc = torch.empty((pc.num_points, 14), dtype=torch.float32, device=dev)
                         b.gc_view = torch.empty_like(b.gc)
                     tgt_gc = b.gc if first else b.gc_view
-                    m2 = b.means2D_grad if first else torch.empty_like(b.means2D_grad)
+                    m2 = (b.means2D_grad if first else torch.empty_like(b.means2D_grad)) if collect_stats else None
                     cfg = self._cfg()
                     _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
                                                                 _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
                                                                 _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
-                                                                _lib.ptr(tgt_gc), _lib.ptr(m2), _lib.ptr(b.bwd_scratch),
+                                                                _lib.ptr(tgt_gc), None if m2 is None else _lib.ptr(m2),
+                                                                _lib.ptr(b.bwd_scratch),
                                                                 b.bwd_scratch.numel(), stream),
                                "fsgs_render_backward_compact")
                     if not first:
                         b.gc.add_(b.gc_view)
-                        pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
+                        if collect_stats:
+                            pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
                     loss_k = torch.dot(b.terms, b.term_w)
                     total = loss_k if total is None else total + loss_k
                     if first:
@@ -320,8 +326,9 @@ class FastStepper:
                     radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
             if grad_sync is not None:
                 grad_sync(pc)
-            optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
-                                pc.variables["xyz_gradient_accum"], pc.variables["denom"])
+            if collect_stats:
+                optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
+                                    pc.variables["xyz_gradient_accum"], pc.variables["denom"])
             self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil}
             if step_optimizer:
                 pc.optimizer.step()

@@ -220,7 +220,8 @@ class Runner:
                 # nothing happens between backward and optimizer.step() on this iteration (train.py:266-272):
                 # the step driver may consume the gradient itself (Adam fused / compact gradient)
                 self.fast.pc = self.pc
-                self.fast.mapping_step(ts, step_optimizer=True)
+                # the statistics feed densify_and_prune only, whose last call is at iteration 14 700 (train.py:305)
+                self.fast.mapping_step(ts, step_optimizer=True, collect_stats=self.densify and it < 15000)
                 pkg = None
                 continue
             if self.fast is not None:

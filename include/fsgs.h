@@ -183,7 +183,9 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
  * in place (args->xyz ... args->rotation are written!) together with its two moments.  Only valid when this is
  * the step's single contribution to the gradient (one view, one rank).  Arithmetic identical to
  * fsgs_render_backward + fsgs_adam_step.  Group order of the arrays: xyz, features_dc, features_rest, opacity,
- * scaling, rotation; step = the step count INCLUDING this step (>= 1).  means2D_grad [P,3] is still written. */
+ * scaling, rotation; step = the step count INCLUDING this step (>= 1).  means2D_grad [P,3] (the RGB pass's
+ * dL/dmeans2D for the densification statistic) is still written, unless it is NULL: then nobody wants the
+ * statistic (densification is over, iteration >= 15000 in train.py:305) and its per-pixel terms are skipped. */
 typedef struct FsgsFusedAdam {
   float *exp_avg[6];
   float *exp_avg_sq[6];

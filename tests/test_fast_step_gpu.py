@@ -120,3 +120,21 @@ def test_adam_fused_into_the_backward_equals_backward_then_adam():
             scale = sa[key].abs().max().item()
             assert ((sa[key] - sb[key]).abs() > 1e-4 * scale).float().mean().item() < 2e-3, (k, key)
     assert torch.equal(a[0].variables["denom"], b[0].variables["denom"])
+
+
+def test_mapping_step_without_statistics_is_the_same_update():
+    """collect_stats=False (iterations past the last densification) drops the RGB-only mean2D terms from the backward
+    blend and skips the statistics kernel; parameters and loss must not notice."""
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    a = _world()
+    b = _world()
+    fa, fb = FastStepper(a[0], a[1], a[2]), FastStepper(b[0], b[1], b[2])
+    for views in ([1], [2, 1]):
+        la = fa.mapping_step(views, corners=corners)
+        lb = fb.mapping_step(views, corners=corners, collect_stats=False)
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item())
+    for k in PARAM_NAMES:
+        pa, pb = a[0].params[k].detach(), b[0].params[k].detach()
+        assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
+    assert float(a[0].variables["denom"].sum()) > 0 and float(b[0].variables["denom"].sum()) == 0
