@@ -235,7 +235,11 @@ class Runner:
                 self.pc.optimizer.step()
                 self.pc.optimizer.zero_grad(set_to_none=True)
             pkg = _first if views == 1 else None
-        if pkg is None:  # the reference returns the LAST rendered view (cur_t)
+        if pkg is None and self.fast is not None and self.fast.last:
+            # the reference returns the render of the LAST view of the LAST iteration (cur_t), taken before that
+            # iteration's optimizer step (train.py:236-265, 291): exactly what the step driver still holds
+            pkg = {"render": self.fast.last["image"].clone(), "render_dep": self.fast.last["depth_sil"][0].clone()}
+        if pkg is None:
             with torch.no_grad():
                 pkg = (render if self.fused else render_two_pass)(self.poses, cur_t, self.pc, gs_grad=False, cam_grad=False)
         return pkg

@@ -33,3 +33,12 @@ tr = [m for t, m in marks if t.startswith("tracking")]; mp_ = [m for t, m in mar
 print("tracking/frame %.2f ms (%.3f ms/iter incl. per-frame setup), mapping/frame %.2f ms (%.3f ms/iter, 2 views), PSNR %.2f" % (
     np.mean(tr), np.mean(tr) / 50, np.mean(mp_), np.mean(mp_) / 30, run.validation() if len(run.frames.i_test) else float("nan")))
 print("pose metrics", run.eval_pose())
+if len(sys.argv) > 4:  # soak: global_run across densification boundaries
+    n_glob = int(sys.argv[4])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    P0 = run.pc.num_points
+    run.global_run(n_glob)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("global_run %d iterations: %.1f ms (%.3f ms/iter), P %d -> %d, iteration counter %d, PSNR %.2f" % (
+        n_glob, dt * 1e3, dt * 1e3 / n_glob, P0, run.pc.num_points, run.iteration, run.validation()))
+    assert all(torch.isfinite(v).all() for v in run.pc.params.values())
