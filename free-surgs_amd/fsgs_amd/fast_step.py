@@ -211,7 +211,8 @@ class FastStepper:
             b = self._buffers(pc.num_points, H, W, n_patches, dev)
             stream = _lib.current_stream()
             for k, ts in enumerate(timesteps):
-                w2c = self.poses.get_pose(ts).detach().contiguous()
+                w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
+                       else self.poses.get_pose(ts).detach().contiguous())
                 args, state, sbytes, cap, nr = self._render_forward(w2c, b)
                 gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
                 # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound, plus the
@@ -254,6 +255,7 @@ class FastStepper:
                                                              _lib.ptr(b.means2D_grad) if collect_stats else None,
                                                              _lib.ptr(b.bwd_scratch),
                                                              b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
+                    optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
                     step_optimizer = False  # done
                     total = torch.dot(b.terms, b.term_w)
                     radii0 = b.radii
@@ -299,6 +301,7 @@ class FastStepper:
                         else:
                             reduce_compact(b.gc)  # ONE all-reduce of 56 B / Gaussian
                             adam_rows(0, pc.num_points)
+                        optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
                         step_optimizer = False  # done
                     continue
                 # render backward straight into the parameters' .grad (view 0) or a scratch set that is added

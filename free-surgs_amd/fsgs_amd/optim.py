@@ -8,6 +8,13 @@ import torch
 from . import _lib
 
 
+def mark_updated(tensors):
+    """The HIP kernels write parameters behind autograd's back; bump the version counters like an in-place torch op
+    would (no kernel is launched), so version-keyed caches and autograd's saved-tensor checks stay truthful."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (betas, eps, no weight decay / amsgrad / maximize) with every group
     updated by ONE HIP kernel launch.  state[p] = {'step' (python int), 'exp_avg', 'exp_avg_sq'}."""
@@ -45,6 +52,7 @@ class FusedAdam(torch.optim.Optimizer):
                         arr[k].exp_avg, arr[k].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                         arr[k].n, arr[k].lr, arr[k].step = p.numel(), lr, st["step"]
                     _lib.check(lib.fsgs_adam_step(len(chunk), arr, b1, b2, eps, stream), "fsgs_adam_step")
+                mark_updated([it[0] for it in items])
         return None
 
 

@@ -57,6 +57,19 @@ class PoseTrack:
         self.pred_w2c[int(i)] = w2c.detach()
         return w2c
 
+    def get_pose_detached(self, i):
+        """w2c of frame i for callers that do not differentiate through the pose (mapping): cached until r / t change
+        (in-place updates bump the tensors' version counters), so a mapping iteration does not relaunch the kernel."""
+        key = (int(i), self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr())
+        hit = getattr(self, "_w2c_cache", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w2c = self.get_pose(i).detach().contiguous()
+            # the fused optimizer kernels write r / t behind autograd's back only in the TRACKING step, which bumps
+            # the versions through optimizer.step(); mapping never touches them
+            self._w2c_cache = hit = (key, w2c)
+        return hit[1]
+
     def initialize_tracking_optimizer(self, tracking_iter=50):
         """Adam(lr .01, eps 1e-15) + MultiStepLR(milestones 0,16,32,48; gamma .5)
         (scene/pose_optimizer.py:489-496)."""
