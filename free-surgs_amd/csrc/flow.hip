@@ -296,6 +296,98 @@ __global__ __launch_bounds__(256) void sampson_mask_kernel(int H, int W, int npa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Flow targets of a tracked frame: the pose-INDEPENDENT half of projection_flow_loss, once per frame
+// (get_pointcloud + the duplicate rejection, scene/pose_optimizer.py:42-73,171-181).  A valid pixel (depth * rigid
+// > 0) is back-projected with K, moved to the world with inverse(w2c_prev), and dropped when |round(world, 4)|
+// equals that of another point or the origin.  Three launches around a sort of 64-bit hashes of the rounded
+// triples (the sort itself and the scan of the keep flags are the caller's: torch.sort / cumsum = rocPRIM):
+//   keys   : world point + rounded triple + hash per pixel (invalid pixels get the all-ones key and sort last)
+//   flag   : in sorted order, a point is a duplicate when a neighbour carries the same hash AND the same triple
+//            (a colliding hash between two copies of a duplicate would hide it: probability ~ M / 2^64)
+//   gather : the kept points in pixel order -> pts [M,3], pix_vu [M,2] = (v, u)
+// torch.round(x, decimals=4) = nearbyint(x * 1e4f) / 1e4f in fp32, reproduced here; the world point itself comes
+// from an fp32 FMA chain instead of torch's 4x4 GEMM, so a coordinate within an ulp of a rounding boundary may
+// round the other way (tests allow <= 1e-5 of the points to differ in the keep decision).
+// ---------------------------------------------------------------------------------------------------
+struct Mat16 {
+  float m[16];
+};
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL; x ^= x >> 27; x *= 0x94d049bb133111ebULL; x ^= x >> 31;
+  return x;
+}
+__global__ __launch_bounds__(256) void flow_targets_keys_kernel(int H, int W, FlowCam c, Mat16 c2w,
+                                                                const float *__restrict__ depth,
+                                                                const uint8_t *__restrict__ rigid,
+                                                                float *__restrict__ world, float *__restrict__ rounded,
+                                                                long long *__restrict__ keys) {
+  const size_t HW = (size_t)H * W;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float z = depth[p];
+  const float dm = rigid ? z * (rigid[p] ? 1.0f : 0.0f) : z;
+  if (!(dm > 0.f)) {
+    keys[p] = -1;  // sorts after every valid key in an UNSIGNED view, first in a signed one: flagged by value either way
+    return;
+  }
+  const int v = (int)(p / W), u = (int)(p - (size_t)v * W);
+  const float xx = ((float)u - c.K[2]) / c.K[0], yy = ((float)v - c.K[5]) / c.K[4];
+  const float cx = xx * z, cy = yy * z;
+  const float *m = c2w.m;
+  float r[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float wk = m[4 * k] * cx + m[4 * k + 1] * cy + m[4 * k + 2] * z + m[4 * k + 3];
+    world[3 * p + k] = wk;
+    r[k] = fabsf(nearbyintf(wk * 10000.0f) / 10000.0f);
+    rounded[3 * p + k] = r[k];
+  }
+  unsigned long long h = mix64(((unsigned long long)__float_as_uint(r[0]) << 32) | __float_as_uint(r[1]));
+  h = mix64(h ^ (0x9e3779b97f4a7c15ULL + __float_as_uint(r[2])));
+  if (h == ~0ull) h = 0x1234567ULL;  // the all-ones pattern is reserved for invalid pixels
+  keys[p] = (long long)h;
+}
+// sorted_keys / sorted_idx: the keys in ascending (signed) order with their pixel indices
+__global__ __launch_bounds__(256) void flow_targets_flag_kernel(size_t HW, const long long *__restrict__ sorted_keys,
+                                                                const long long *__restrict__ sorted_idx,
+                                                                const float *__restrict__ rounded,
+                                                                int32_t *__restrict__ keep) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= HW) return;
+  const long long key = sorted_keys[s];
+  const size_t p = (size_t)sorted_idx[s];
+  if (key == -1) {
+    keep[p] = 0;
+    return;
+  }
+  const float a0 = rounded[3 * p], a1 = rounded[3 * p + 1], a2 = rounded[3 * p + 2];
+  bool dup = (a0 == 0.f && a1 == 0.f && a2 == 0.f);  // the extra all-zero row of the reference's unique()
+#pragma unroll
+  for (int d = -1; d <= 1; d += 2) {
+    const long long q = (long long)s + d;
+    if (q < 0 || q >= (long long)HW) continue;
+    if (sorted_keys[q] != key) continue;
+    const size_t pq = (size_t)sorted_idx[q];
+    dup = dup || (rounded[3 * pq] == a0 && rounded[3 * pq + 1] == a1 && rounded[3 * pq + 2] == a2);
+  }
+  keep[p] = dup ? 0 : 1;
+}
+// incl = inclusive prefix sum of keep (pixel order)
+__global__ __launch_bounds__(256) void flow_targets_gather_kernel(int H, int W, const int32_t *__restrict__ keep,
+                                                                  const int32_t *__restrict__ incl,
+                                                                  const float *__restrict__ world,
+                                                                  float *__restrict__ pts,
+                                                                  long long *__restrict__ pix_vu) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (size_t)H * W || !keep[p]) return;
+  const size_t j = (size_t)incl[p] - 1;
+  pts[3 * j] = world[3 * p]; pts[3 * j + 1] = world[3 * p + 1]; pts[3 * j + 2] = world[3 * p + 2];
+  const long long v = (long long)(p / W);
+  pix_vu[2 * j] = v;
+  pix_vu[2 * j + 1] = (long long)p - v * W;
+}
+
 // every workgroup ends with a handful of same-address atomics, which serialise (tens of ns each): with 1024
 // workgroups that chain was longer than the streaming pass itself, so the grid is capped at one workgroup per CU
 int flow_blocks(size_t M) {
@@ -313,6 +405,42 @@ FlowCam make_flow_cam(const float *K9, int W, int H, float edge) {
 }  // namespace
 
 extern "C" {
+
+int fsgs_flow_targets_keys(int H, int W, const float *depth_prev, const uint8_t *rigid, const float *K9_host,
+                           const float *c2w16_host, float *world, float *rounded, int64_t *keys,
+                           fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (H <= 0 || W <= 0 || !depth_prev || !K9_host || !c2w16_host || !world || !rounded || !keys) return FSGS_ERR_INVALID;
+  FlowCam c = make_flow_cam(K9_host, W, H, 0.f);
+  Mat16 m;
+  for (int i = 0; i < 16; i++) m.m[i] = c2w16_host[i];
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(flow_targets_keys_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream, H, W, c, m,
+                     depth_prev, rigid, world, rounded, (long long *)keys);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_flow_targets_flag(int64_t HW, const int64_t *sorted_keys, const int64_t *sorted_idx, const float *rounded,
+                           int32_t *keep, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (HW <= 0 || !sorted_keys || !sorted_idx || !rounded || !keep) return FSGS_ERR_INVALID;
+  hipLaunchKernelGGL(flow_targets_flag_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream, (size_t)HW,
+                     (const long long *)sorted_keys, (const long long *)sorted_idx, rounded, keep);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_flow_targets_gather(int H, int W, const int32_t *keep, const int32_t *incl, const float *world, float *pts,
+                             int64_t *pix_vu, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (H <= 0 || W <= 0 || !keep || !incl || !world || !pts || !pix_vu) return FSGS_ERR_INVALID;
+  const size_t HW = (size_t)H * W;
+  hipLaunchKernelGGL(flow_targets_gather_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, stream, H, W, keep,
+                     incl, world, pts, (long long *)pix_vu);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
 
 int fsgs_flow_pose_loss_forward(int64_t M, const float *pts_world, const int64_t *pix_vu, const float *w2c,
                                 const float *K9_host, const float *flow_fw, int W, int H, float edge, double *acc3,

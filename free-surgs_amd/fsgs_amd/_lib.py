@@ -139,6 +139,9 @@ _PROTOTYPES = {
     "fsgs_flow_scratch_bytes": (_sz, [_i64]),
     "fsgs_flow_pose_loss_fused": (_i, [_i64, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, C.c_float,
                                        C.c_float, _vp, _vp, _vp, _vp]),
+    "fsgs_flow_targets_keys": (_i, [_i, _i, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _vp, _vp]),
+    "fsgs_flow_targets_flag": (_i, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "fsgs_flow_targets_gather": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_sampson_scratch_bytes": (_sz, [_i, _i]),
     "fsgs_sampson_rigid_mask": (_i, [_i, _i, _vp, C.POINTER(C.c_float), C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pose_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -35,6 +35,48 @@ def backproject_previous(depth_prev, K, w2c_prev, rigid_mask=None):
     return pts[keep], idx[keep]
 
 
+def backproject_previous_hip(depth_prev, K, w2c_prev, rigid_mask=None):
+    """product path of backproject_previous (csrc/flow.hip flow_targets_*): three launches around one sort of 64-bit
+    hashes and one scan, instead of torch.unique(dim=0)'s lexicographic row sort; one host read (M)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    depth = depth_prev.detach().float().contiguous()
+    if not depth.is_cuda:
+        raise RuntimeError("fsgs flow targets need CUDA/HIP tensors; there is no CPU fallback")
+    dev = depth.device
+    H, W = int(depth.shape[-2]), int(depth.shape[-1])
+    HW = H * W
+    w2c = torch.as_tensor(np.asarray(w2c_prev), dtype=torch.float32, device=dev) if not torch.is_tensor(w2c_prev) \
+        else w2c_prev.detach().float().to(dev)
+    c2w = torch.inverse(w2c).cpu().numpy().astype(np.float32).reshape(16)  # the reference inverts on the device too
+    Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32).reshape(9)
+    K9 = (C.c_float * 9)(*[float(v) for v in Kn])
+    M16 = (C.c_float * 16)(*[float(v) for v in c2w])
+    rig = None if rigid_mask is None else rigid_mask.detach().to(torch.uint8).contiguous()
+    world = torch.empty((HW, 3), dtype=torch.float32, device=dev)
+    rounded = torch.empty((HW, 3), dtype=torch.float32, device=dev)
+    keys = torch.empty((HW,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream()
+        _lib.check(lib.fsgs_flow_targets_keys(H, W, _lib.ptr(depth), _lib.ptr(rig), K9, M16, _lib.ptr(world),
+                                              _lib.ptr(rounded), _lib.ptr(keys), stream), "fsgs_flow_targets_keys")
+        skeys, sidx = torch.sort(keys)
+        keep = torch.empty((HW,), dtype=torch.int32, device=dev)
+        _lib.check(lib.fsgs_flow_targets_flag(HW, _lib.ptr(skeys), _lib.ptr(sidx), _lib.ptr(rounded), _lib.ptr(keep),
+                                              stream), "fsgs_flow_targets_flag")
+        incl = torch.cumsum(keep, dim=0, dtype=torch.int32)
+        M = int(incl[-1].item())  # the one host read: the outputs' size
+        pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        vu = torch.empty((M, 2), dtype=torch.int64, device=dev)
+        if M > 0:
+            _lib.check(lib.fsgs_flow_targets_gather(H, W, _lib.ptr(keep), _lib.ptr(incl), _lib.ptr(world), _lib.ptr(pts),
+                                                    _lib.ptr(vu), stream), "fsgs_flow_targets_gather")
+    return pts, vu
+
+
 def flow_pose_loss_torch(pts_world, pix_vu, w2c_cur, K, flow_fw, width, height, edge=20):
     """transform by the current (differentiable) pose, project with K, keep the border-safe points in
     front of the camera, L1 between (projection - pixel) and the forward flow
@@ -75,7 +117,10 @@ class FlowTargets:
 
     def __init__(self, depth_prev, w2c_prev, K, flow_fw, rigid_mask=None):
         self.H, self.W = int(depth_prev.shape[1]), int(depth_prev.shape[2])
-        pts, vu = backproject_previous(depth_prev, K, w2c_prev, rigid_mask)
+        if depth_prev.is_cuda:
+            pts, vu = backproject_previous_hip(depth_prev, K, w2c_prev, rigid_mask)
+        else:
+            pts, vu = backproject_previous(depth_prev, K, w2c_prev, rigid_mask)  # CPU: the torch statement
         self.pts = pts.detach().contiguous().float()
         self.vu = vu.detach().contiguous().to(torch.int64)
         self.flow = flow_fw.detach().contiguous().float()

@@ -265,6 +265,23 @@ int fsgs_flow_pose_loss_backward(int64_t M, const float *pts_world, const int64_
                                  const float *K9_host, const float *flow_fw, int W, int H, float edge,
                                  const double *acc3, const float *upstream, float *dw2c, fsgs_stream_t stream);
 
+/* Flow targets of a tracked frame, once per frame (get_pointcloud + duplicate rejection,
+ * scene/pose_optimizer.py:42-73,171-181), in three launches around a caller-side sort and scan:
+ *  keys   : depth_prev [H,W], rigid uint8 [H,W] or NULL, K9 / c2w16 = inverse(w2c_prev) row-major on the HOST ->
+ *           world [HW,3], rounded [HW,3] = |round(world, 4)|, keys int64 [HW] (hash of the rounded triple; -1 for
+ *           pixels with depth * rigid <= 0);
+ *  (caller: sort keys ascending carrying the pixel indices)
+ *  flag   : keep int32 [HW] = 1 for valid points whose rounded triple is unique and not the origin;
+ *  (caller: incl = inclusive prefix sum of keep; M = incl[HW-1])
+ *  gather : pts [M,3], pix_vu int64 [M,2] = (v, u), in pixel order like the reference's boolean indexing. */
+int fsgs_flow_targets_keys(int H, int W, const float *depth_prev, const uint8_t *rigid, const float *K9_host,
+                           const float *c2w16_host, float *world, float *rounded, int64_t *keys,
+                           fsgs_stream_t stream);
+int fsgs_flow_targets_flag(int64_t HW, const int64_t *sorted_keys, const int64_t *sorted_idx, const float *rounded,
+                           int32_t *keep, fsgs_stream_t stream);
+int fsgs_flow_targets_gather(int H, int W, const int32_t *keep, const int32_t *incl, const float *world, float *pts,
+                             int64_t *pix_vu, fsgs_stream_t stream);
+
 /* Forward and backward in one streaming pass (the autograd-free tracking step): out2 = {loss, #valid} and
  * dw2c[4,4] = accumulate * dw2c + upstream * dloss/dw2c (accumulate = 0 overwrites without reading dw2c, so the
  * caller can fold the weighted sum with the rasteriser's pose gradient into this call).  upstream / accumulate

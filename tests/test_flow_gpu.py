@@ -173,3 +173,39 @@ def test_sampson_rigid_mask_matches_torch_statement_and_flags_the_moving_block()
     fl0 = _two_view_flow(H, W, K, w1, w2, depth)
     _, d0, _ = epipolar.rigid_mask(fl0, F, 2.0)
     assert d0.max().item() < 1e-3
+
+
+def test_flow_targets_kernels_match_the_torch_statement():
+    """csrc/flow.hip flow_targets_* (hash sort + neighbour test) against backproject_previous (torch.unique(dim=0) of
+    the reference): same kept set and order.  Constructed duplicates are decided identically by both; a coordinate
+    within an ulp of a 1e-4 rounding boundary may go either way (FMA chain vs 4x4 GEMM), so <= 1e-5 of the points
+    may differ."""
+    from fsgs_amd import synth
+
+    H, W = 256, 320
+    K = synth.intrinsics(W, H).copy()
+    K[0, 2], K[1, 2] = 160.0, 128.0   # integer principal point: pixel u mirrors 320 - u exactly
+    u = torch.arange(W, device=DEV).float()[None] / W
+    v = torch.arange(H, device=DEV).float()[:, None] / H
+    depth = (1.0 + 0.3 * torch.sin(6.28 * u) * torch.cos(6.28 * v)).reshape(1, H, W).contiguous()
+    depth[0, :7, :9] = 0.0            # invalid pixels
+    depth[0, 100:104, :] = 1.0        # a fronto-parallel strip: x <-> -x mirror pairs collide in |round(., 4)|
+    rigid = torch.rand(H, W, device=DEV) > 0.1
+    for w_prev in (np.eye(4, dtype=np.float32),
+                   synth.pose_matrix((1, 0.01, -0.02, 0.005), (0.01, 0.02, -0.01)).astype(np.float32)):
+        for rm in (rigid, None):
+            pa, va = flow.backproject_previous(depth, K, w_prev, rm)
+            pb, vb = flow.backproject_previous_hip(depth, K, w_prev, rm)
+            ka = (va[:, 0] * W + va[:, 1]).cpu().numpy()
+            kb = (vb[:, 0] * W + vb[:, 1]).cpu().numpy()
+            assert np.all(np.diff(kb) > 0)  # pixel order, like boolean indexing
+            sym = np.setxor1d(ka, kb)
+            assert len(sym) <= max(2, int(1e-5 * len(ka))), (len(sym), len(ka))
+            both = np.intersect1d(ka, kb)
+            ia, ib = np.searchsorted(ka, both), np.searchsorted(kb, both)
+            np.testing.assert_allclose(pb[ib].cpu().numpy(), pa[ia].cpu().numpy(), rtol=1e-5, atol=1e-6)
+            if np.allclose(w_prev, np.eye(4)):
+                assert len(ka) < int((depth[0] * (rm if rm is not None else 1) > 0).sum())  # duplicates were dropped
+    # nothing valid
+    pts, vu = flow.backproject_previous_hip(torch.zeros(1, H, W, device=DEV), K, np.eye(4, dtype=np.float32), None)
+    assert pts.shape == (0, 3) and vu.shape == (0, 2)
