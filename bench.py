@@ -255,6 +255,24 @@ def main():
         tracking = {"iters_per_sec": nt / (time.perf_counter() - t1), "ms_per_iter": (time.perf_counter() - t1) / nt * 1e3,
                     "what": "render(gs_grad=False, cam_grad=True) + masked rgb loss + flow loss + pose Adam"}
 
+    # ---- extra (N > 1): the step's one collective on its own, so the scaling numbers can be read ----
+    comm = None
+    if world > 1:
+        nfloat = P * (14 if use_fast else 59)
+        buf = torch.zeros((nfloat,), dtype=torch.float32, device=device)
+        for _ in range(3):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        tc = time.perf_counter()
+        for _ in range(10):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        comm_ms = (time.perf_counter() - tc) / 10 * 1e3
+        comm = {"what": "all-reduce(SUM) of the %s gradient, alone" % ("compact [P,14]" if use_fast else "[59 P]"),
+                "bytes": nfloat * 4, "ms": comm_ms,
+                "algbw_GBps": nfloat * 4 / (comm_ms * 1e-3) / 1e9}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sc, cam, pc.active_sh_degree)
@@ -274,7 +292,7 @@ def main():
                               if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step, from the all-reduced compact [P,14] gradient (fsgs_adam_step_compact)"
                               if use_fast else "FusedAdam / torch path"),
                 "parallelism": "dp%d" % world, "loss": float(loss)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking, "comm": comm,
         }
         print(json.dumps(out))
     if world > 1:
