@@ -73,3 +73,35 @@ def test_two_ranks_stay_in_lockstep(tmp_path, use_bucket):
     b = torch.load(os.path.join(tmp_path, "rank1.pt"))
     for k in PARAM_NAMES:
         assert torch.equal(a[k], b[k]), k  # replicas must be bit-identical after synchronised steps
+
+
+def _compact_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fsgs_amd import dist as fdist
+
+    fdist.init_from_env(backend="gloo")
+    P = 1000
+    base = torch.arange(P * 14, dtype=torch.float32).reshape(P, 14)
+    # one collective
+    gc = base * (rank + 1)
+    fdist.all_reduce_compact(gc)
+    assert torch.equal(gc, base * 3)
+    # chunked + pipelined: every row is reduced exactly once BEFORE its Adam chunk runs, chunk bounds are multiples of 256
+    gc = base * (rank + 1)
+    seen = []
+
+    def adam_rows(lo, hi):
+        assert lo % 256 == 0 and (hi % 256 == 0 or hi == P)
+        assert torch.equal(gc[lo:hi], base[lo:hi] * 3)
+        seen.append((lo, hi))
+
+    fdist.PipelinedCompactReducer(3)(gc, adam_rows)
+    assert seen[0][0] == 0 and seen[-1][1] == P and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_gradient_reducers():
+    """all_reduce_compact / PipelinedCompactReducer (fsgs_amd/dist.py): the [P,14] gradient of the HIP step driver."""
+    mp.spawn(_compact_worker, args=(2, _free_port(), ""), nprocs=2, join=True)
