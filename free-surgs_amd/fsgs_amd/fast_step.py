@@ -1,12 +1,14 @@
 """Autograd-free mapping / tracking iterations: the same arithmetic as trainer.mapping_step /
 tracking_step (train.py:166-200,236-272), but every stage is ONE C-ABI call into libfsgs_hip.so and the
-chain rule between stages is written out by hand, so a step costs ~15 kernel launches and no autograd
-graph (the torch-autograd path spends ~0.5 ms/step of pure host time in ~100 tiny kernels).
+chain rule between stages is written out by hand, so a step costs ~21 kernel launches on two streams and no
+autograd graph (the torch-autograd path spends ~0.5 ms/step of pure host time in ~100 tiny kernels).
 
-    mapping :  render fwd -> rgb loss fwd -> pearson(global + patches) fwd
-               -> rgb bwd (x5) -> pearson bwd (x0.05, x0.15/n) -> render bwd -> densify stats -> Adam
-    tracking:  render fwd -> masked rgb loss fwd -> flow loss fwd -> their bwd -> render bwd (pose only)
-               -> quaternion/translation chain (12 floats, torch) -> Adam
+    mapping :  render fwd -> [rgb loss fwd, bwd (x5)  ||  patch draws, pearson(global + patches) fwd, bwd (x0.05, x0.15/n)]
+               -> render bwd feeding Adam directly (1 view, 1 rank)
+                  or render bwd -> compact [P,14] gradient (summed over views, all-reduced over ranks) -> Adam from it
+               -> densification statistics
+    tracking:  [flow loss fwd+bwd (one pass)  ||  render fwd] -> masked rgb loss fwd, bwd -> render bwd (pose only)
+               -> quaternion/translation chain (12 floats) -> Adam
 
 Equivalence with the autograd path is asserted in tests/test_fast_step_gpu.py.
 """
@@ -266,7 +268,8 @@ class FastStepper:
                         b.gc = torch.empty((pc.num_points, 14), dtype=torch.float32, device=dev)
                         b.gc_view = torch.empty_like(b.gc)
                     tgt_gc = b.gc if first else b.gc_view
-                    m2 = (b.means2D_grad if first else torch.empty_like(b.means2D_grad)) if collect_stats else None
+                    # the densification statistic comes from view 0 only (train.py:260-263): later views skip its terms
+                    m2 = b.means2D_grad if (first and collect_stats) else None
                     cfg = self._cfg()
                     _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
                                                                 _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
