@@ -9,6 +9,6 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_o
 python bench.py --steps 10 --warmup 3 --profile-all --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_profile_all.json
 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.json
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/rocprof.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-tracking > gpurun_out/rocprof.log 2>&1
 find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/ \;
 ls -la gpurun_out
