@@ -222,6 +222,13 @@ class FastStepper:
                 side = self._side_stream(dev)
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
+                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, 0.2,
+                                                             _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
+                                                             stream), "fsgs_photometric_loss_forward")
+                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None,
+                                                              _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
+                                                              _lib.ptr(b.d_image), stream),
+                           "fsgs_photometric_loss_backward")
                 side.wait_event(fwd_done)
                 with torch.cuda.stream(side):
                     sstream = _lib.current_stream()
@@ -237,13 +244,6 @@ class FastStepper:
                     side_done.record()
                     for t_ in cr:  # drawn on the side stream, last used there
                         t_.record_stream(side)
-                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, 0.2,
-                                                             _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
-                                                             stream), "fsgs_photometric_loss_forward")
-                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None,
-                                                              _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
-                                                              _lib.ptr(b.d_image), stream),
-                           "fsgs_photometric_loss_backward")
                 torch.cuda.current_stream().wait_event(side_done)
                 fused_ok = step_optimizer and grad_sync is None and isinstance(pc.optimizer, optim.FusedAdam)
                 # single view, single rank: the backward feeds Adam directly (no gradient tensors at all)
