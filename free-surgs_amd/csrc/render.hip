@@ -582,7 +582,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   const char *sb = (const char *)state;
   float *grad_acc = (float *)scratch;
   float *dcolors6 = grad_acc + (size_t)P * kAccStride;
-  FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
+  if (!(cfg->flags & FSGS_FLAG_SCRATCH_ZEROED)) FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
   if (cam_grad) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
   if (num_rendered > 0 && (dL_dimage || dL_ddepth_sil)) {
     ProfScope ps(PROF_BLEND_BWD, stream);

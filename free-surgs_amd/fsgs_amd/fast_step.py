@@ -96,6 +96,17 @@ class FastStepper:
             self.cfg_key = key
         return self.cfg
 
+    def _cfg_zeroed(self):
+        """the same configuration with FSGS_FLAG_SCRATCH_ZEROED: for backward calls whose scratch this driver has
+        cleared itself on the side stream"""
+        base = self._cfg()
+        if getattr(self, "_cfgz_of", None) is not base:
+            z = _lib.FsgsRasterCfg()
+            C.memmove(C.byref(z), C.byref(base), C.sizeof(z))
+            z.flags |= _lib.FSGS_FLAG_SCRATCH_ZEROED
+            self._cfgz, self._cfgz_of = z, base
+        return self._cfgz
+
     def _render_forward(self, w2c, b):
         pc, lib = self.pc, self.lib
         p = pc.params
@@ -177,8 +188,8 @@ class FastStepper:
         return st
 
     def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
-                         param_grads):
-        cfg = self._cfg()
+                         param_grads, zeroed=False):
+        cfg = self._cfg_zeroed() if zeroed else self._cfg()
         rc = self.lib.fsgs_render_backward(C.byref(cfg), self.pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                            _lib.ptr(state), sbytes, cap, nr, _lib.ptr(d_image), _lib.ptr(d_depth_sil),
                                            int(gs_grad), int(cam_grad), int(param_grads), C.byref(grads),
@@ -240,6 +251,7 @@ class FastStepper:
                     _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
                                                          _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
                                                          0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
+                    b.bwd_scratch.zero_()  # the backward's accumulators, cleared here instead of in front of the blend
                     side_done = torch.cuda.Event()
                     side_done.record()
                     for t_ in cr:  # drawn on the side stream, last used there
@@ -250,7 +262,7 @@ class FastStepper:
                 fuse_adam = self.fuse_adam and fused_ok and len(timesteps) == 1 and reduce_compact is None
                 if fuse_adam:
                     adam = self._fused_adam_struct()
-                    cfg = self._cfg()
+                    cfg = self._cfg_zeroed()
                     _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                                              _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
                                                              _lib.ptr(b.d_depth_sil), C.byref(adam),
@@ -270,7 +282,7 @@ class FastStepper:
                     tgt_gc = b.gc if first else b.gc_view
                     # the densification statistic comes from view 0 only (train.py:260-263): later views skip its terms
                     m2 = b.means2D_grad if (first and collect_stats) else None
-                    cfg = self._cfg()
+                    cfg = self._cfg_zeroed()
                     _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
                                                                 _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
                                                                 _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
@@ -369,6 +381,7 @@ class FastStepper:
                                                              _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
                                                              _lib.ptr(b.d_flow), _lib.current_stream()),
                                "fsgs_flow_pose_loss_fused")
+                    b.bwd_scratch.zero_()  # the backward's accumulators (previous iteration's readers are behind pose_ready)
                     flow_done = torch.cuda.Event()
                     flow_done.record()
                     wd.record_stream(side)
@@ -386,8 +399,9 @@ class FastStepper:
                            "fsgs_photometric_loss_backward")
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
                 grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)
-                self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False)
                 torch.cuda.current_stream().wait_event(flow_done)
+                self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False,
+                                      zeroed=True)
                 # d_total = w_rgb * dL_rgb/dw2c + w_flow * dL_flow/dw2c
                 if float(LOSS_W_TRACKING["rgb"]) != 1.0:
                     d_total.mul_(float(LOSS_W_TRACKING["rgb"]))

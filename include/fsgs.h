@@ -55,6 +55,9 @@ enum {
  * planes get no gradient from any loss of the reference (train.py:166-272: rgb + Pearson(depth); the presence
  * mask and the uncertainty are detached), and the backward blend drops their terms */
 #define FSGS_FLAG_DEPTH_GRAD_ONLY 2
+/* fsgs_render_backward*: the caller has already zeroed the first P * 56 bytes of `scratch` (e.g. on another stream,
+ * beside the loss kernels); the call does not enqueue its own fill in front of the backward blend */
+#define FSGS_FLAG_SCRATCH_ZEROED 4
 
 /* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
  * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
