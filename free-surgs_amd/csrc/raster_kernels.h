@@ -708,8 +708,10 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
     const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
-    float *__restrict__ dcolors) {
+    float *__restrict__ dcolors, float *__restrict__ clear16) {
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
+  // 16 floats the NEXT kernel accumulates into with atomics (dL/dw2c): cleared here instead of by a separate fill
+  if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) clear16[threadIdx.x] = 0.f;
   constexpr int REC4 = C > 4 ? 4 : 3;
   constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : CGRAD;  // channels that carry dL/dpixel
   constexpr int GP = 2;                                // Gaussians per transposing reduction
@@ -1159,9 +1161,10 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C>
 int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
                      const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
-                     const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s) {
+                     const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
+                     float *clear16 = nullptr) {
   hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
-                     colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors);
+                     colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
   return 0;
 }
 

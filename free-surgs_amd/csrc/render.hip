@@ -583,8 +583,12 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   float *grad_acc = (float *)scratch;
   float *dcolors6 = grad_acc + (size_t)P * kAccStride;
   if (!(cfg->flags & FSGS_FLAG_SCRATCH_ZEROED)) FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
-  if (cam_grad) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
-  if (num_rendered > 0 && (dL_dimage || dL_ddepth_sil)) {
+  const bool blend = num_rendered > 0 && (dL_dimage || dL_ddepth_sil);
+  const bool pose_only_path = blend && cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
+  // dL/dw2c is accumulated with atomics by the preprocess backward: cleared by the blend kernel in front of it
+  // (tracking), by a fill otherwise
+  if (cam_grad && !pose_only_path) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
+  if (blend) {
     ProfScope ps(PROF_BLEND_BWD, stream);
     const uint32_t *order = ntiles <= ORDER_MAX_TILES ? (const uint32_t *)(sb + SL.order) : nullptr;
     // tracking (pose gradient only, rgb loss only): the lean variant -- see blend_bwd_kernel
@@ -594,7 +598,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                                        (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
                                        (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c);
     else if ((cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY) && !grads->means2D)
       // nobody wants the densification statistic (means2D_grad == NULL): the RGB-only mean2D moments are dropped too
       launch_blend_bwd<6, false, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
