@@ -244,11 +244,11 @@ def main():
         depth_prev = frames.monodeps[0].reshape(1, H, W)
         flow_fw = torch.zeros((2, H, W), device=device)
         targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), cam["K"], flow_fw, rigid)
-        for _ in range(3):
+        for _ in range(10):
             stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nt = 20
+        nt = 40
         for _ in range(nt):
             stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
         torch.cuda.synchronize()
