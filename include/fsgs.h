@@ -4,7 +4,9 @@
  *
  * Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
  * unless marked [host].  Nothing is allocated, freed or kept between calls by the
- * library; all calls are asynchronous on `stream` except where noted and are
+ * library -- with one exception: a 16 KB pinned host "mailbox" (256 slots) created on
+ * first use, through which the forward learns the pair count without synchronising the
+ * stream.  All calls are asynchronous on `stream` except where noted and are
  * re-entrant (two Python threads -- trainer and viewer -- may interleave,
  * train.py:150,166-200,227-231).  Return value: 0 on success, negative FSGS_ERR_*.
  *
@@ -24,7 +26,12 @@
  *   fsgs_pearson_*                    <- utils/loss_utils.py:98-127
  *   fsgs_flow_pose_loss_*             <- scene/pose_optimizer.py:164-218
  *   fsgs_sampson_rigid_mask           <- train.py:157-165, scene/pose_optimizer.py:700-746
+ *   fsgs_flow_targets_*               <- get_pointcloud + duplicate rejection, scene/pose_optimizer.py:42-73,171-181
  *   fsgs_adam_step                    <- torch.optim.Adam steps of train.py:194,272
+ *   fsgs_render_backward_adam         <- loss.backward() + optimizer.step() of one single-view mapping iteration
+ *                                        (train.py:265-272) in one pass
+ *   fsgs_render_backward_compact /
+ *   fsgs_adam_step_compact            <- the same for multi-view / multi-rank steps (summed 56 B/Gaussian gradient)
  *   fsgs_densify_plan / _apply        <- GaussianModel.densify_and_prune, scene/gaussian_model.py:523-676
  */
 #ifndef FSGS_H
@@ -42,7 +49,7 @@ typedef void *fsgs_stream_t; /* hipStream_t */
 enum {
   FSGS_OK = 0,
   FSGS_ERR_INVALID = -1,   /* bad argument (null pointer, channel count, size) */
-  FSGS_ERR_CAPACITY = -2,  /* state/scratch buffer too small; *num_rendered holds the need */
+  FSGS_ERR_CAPACITY = -2,  /* state/scratch buffer too small; *num_rendered holds a max_pairs that suffices */
   FSGS_ERR_HIP = -3,       /* a HIP runtime call or kernel launch failed */
   FSGS_ERR_STATE = -4      /* state buffer does not belong to a completed forward */
 };
@@ -112,10 +119,13 @@ int fsgs_raster_state_layout(int P, int width, int height, int64_t max_pairs, si
 /* Forward: kernels R1-R6 of SURVEY.md s2.1.
  *  means3D[P,3] colors[P,C] opacities[P] scales[P,3] rotations[P,4] (r,x,y,z), fp32 row-major.
  *  out_color[C,H,W] planar, out_depth[H,W] (depth-fork third output), radii[P] int32.
+ *  max_pairs: capacity for (tile, Gaussian) pairs, split evenly over (tiles x 8) fixed-capacity list segments
+ *  (single-pass binning: no count pass, no scan; a segment holds max_pairs / (8 tiles) keys).
  *  num_rendered [host]: receives R = number of (tile, Gaussian) pairs.  The host learns R from a pinned
- *  mailbox word the scan kernel writes (no stream synchronisation; the call returns while the blend is still
- *  queued); if R > max_pairs the call returns FSGS_ERR_CAPACITY, nothing is rendered (the binning kernels
- *  refuse on the device) and the caller retries with bigger buffers. */
+ *  mailbox word the last binning kernel writes (no stream synchronisation; the call returns while the blend is
+ *  still queued).  If a segment overflowed the call returns FSGS_ERR_CAPACITY, *num_rendered holds a max_pairs
+ *  that would have sufficed, the outputs are garbage (the blend ran on truncated, in-bounds lists) and the caller
+ *  retries with bigger buffers. */
 int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P,
                         const float *means3D, const float *colors, const float *opacities,
                         const float *scales, const float *rotations,
@@ -125,7 +135,7 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P,
 
 /* Backward: kernels R7-R9.  dL_dcolor[C,H,W].  Outputs are overwritten:
  *  dmeans2D[P,3] (NDC-scaled screen gradient, z = 0), dcolors[P,C], dopacities[P],
- *  dmeans3D[P,3], dscales[P,3], drotations[P,4].  `scratch` >= P*16 bytes. */
+ *  dmeans3D[P,3], dscales[P,3], drotations[P,4].  `scratch` >= P*32 bytes (fsgs_raster_sizes covers it). */
 int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P,
                          const float *means3D, const float *colors,
                          const float *scales, const float *rotations, const int32_t *radii,
