@@ -317,6 +317,40 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
         rank += (ab.x < key) + (ab.y < key);
       }
       if (mine) plist[base + rank] = (uint32_t)key;
+    } else if (n <= 2 * SORT_RANK_KEYS) {
+      // 257..512 keys: two rank-sorted halves A = keys [0,256), B = keys [256,n), merged by rank: a key's final
+      // position = its rank in its own half + the number of keys of the OTHER half below it (binary search in the
+      // sorted other half).  ~n/2 broadcast reads + 9 probes per key instead of 45 network steps through LDS.
+      __shared__ __attribute__((aligned(16))) unsigned long long half_sorted[2 * SORT_RANK_KEYS + 2];
+      const int nB = n - SORT_RANK_KEYS;
+      if (threadIdx.x == 0) { lds[n] = ~0ull; lds[n + 1] = ~0ull; }
+      __syncthreads();
+      const int t = threadIdx.x;
+      const bool hasB = t < nB;
+      const unsigned long long kA = lds[t], kB = hasB ? lds[SORT_RANK_KEYS + t] : 0ull;
+      uint32_t rA = 0, rB = 0;
+      const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(lds);
+      for (int j = 0; j < SORT_RANK_KEYS / 2; j++) {  // A: exactly 256 keys
+        const ulonglong2 ab = pairs[j];
+        rA += (ab.x < kA) + (ab.y < kA);
+      }
+      for (int j = SORT_RANK_KEYS / 2; j < (n + 1) >> 1; j++) {  // B (+inf padded)
+        const ulonglong2 ab = pairs[j];
+        rB += (ab.x < kB) + (ab.y < kB);
+      }
+      half_sorted[rA] = kA;
+      if (hasB) half_sorted[SORT_RANK_KEYS + rB] = kB;
+      __syncthreads();
+      // number of keys of a sorted array below `key` (keys are unique across the halves too)
+      auto below = [&](const unsigned long long *arr, int len, unsigned long long key) {
+        int lo = 0;
+#pragma unroll
+        for (int step = 256; step > 0; step >>= 1)
+          if (lo + step <= len && arr[lo + step - 1] < key) lo += step;
+        return lo;
+      };
+      plist[base + rA + below(half_sorted + SORT_RANK_KEYS, nB, kA)] = (uint32_t)kA;
+      if (hasB) plist[base + rB + below(half_sorted, SORT_RANK_KEYS, kB)] = (uint32_t)kB;
     } else {
       bitonic_sort_ascending<true>(lds, n, m);
       for (int i = threadIdx.x; i < n; i += blockDim.x) plist[base + i] = (uint32_t)lds[i];

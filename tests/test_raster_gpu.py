@@ -164,14 +164,15 @@ def test_full_size_properties_c2():
     assert int((radii > 0).sum()) > P // 2
 
 
-def test_binning_is_upstream_order_minus_unreachable_pairs(oracle32):
+@pytest.mark.parametrize("P", [6000, 24000])  # tile lists up to ~200 keys (rank sort) / ~500 keys (two halves + merge)
+def test_binning_is_upstream_order_minus_unreachable_pairs(oracle32, P):
     """The HIP binning keeps UPSTREAM's (tile, depth, index) order and drops only (tile, Gaussian) pairs
     that no pixel of the tile can reach (alpha < 1/255 everywhere): per tile the HIP list must be a
     subsequence of the oracle's rect-based list, and every dropped pair must be unreachable."""
     from fsgs_amd import rasterizer
     from fsgs_amd.trainer import settings_from_cam
 
-    W, H, P = 320, 256, 6000
+    W, H = 320, 256
     cam = synth.make_camera(W, H)
     sc = synth.trained_like_scene(W, H, P, seed=3, base_ratio=0.02)
     s, r, o = synth.activate(sc)
@@ -182,6 +183,8 @@ def test_binning_is_upstream_order_minus_unreachable_pairs(oracle32):
     v = {k: t.cpu().numpy() for k, t in rasterizer.state_views(st).items()}
     oi, od, orad, ost = oracle32.raster_forward(cam, sc["_xyz"], col, o.reshape(-1), s, r)
     assert st.num_rendered < ost.num_rendered  # something was culled
+    lens = v["ranges"][:, 1] - v["ranges"][:, 0]
+    assert (lens.max() <= 256) if P == 6000 else (256 < lens.max() <= 512 and (lens > 256).mean() > 0.1), (lens.max(), (lens > 256).mean())
     o_ranges, o_list = ost.ranges(), ost.point_list().astype(np.int64)
     xy, co = ost.xy().astype(np.float64), ost.conic_opacity().astype(np.float64)
     gx = (W + 15) // 16
