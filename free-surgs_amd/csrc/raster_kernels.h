@@ -654,13 +654,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       if (C > 4) rec[lane * REC4 + 3] = make_float4(c6[4], c6[5], c6[6], c6[7]);
     }
     __syncthreads();
-    float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = C > 4 ? rec[3] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < n; j++) {
-      const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-      if (j + 1 < n) {  // software prefetch of the next record (wave-uniform address)
-        n0 = rec[(j + 1) * REC4 + 0]; n1 = rec[(j + 1) * REC4 + 1]; n2 = rec[(j + 1) * REC4 + 2];
-        if (C > 4) n3 = rec[(j + 1) * REC4 + 3];
-      }
+      // broadcast reads of record j (same LDS address in every lane); the other waves of the SIMD hide the latency
+      const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
+      const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t bm = readlane(gmask, j) & alive;  // scalar
       if (bm == 0) continue;
       const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
