@@ -102,38 +102,43 @@ __device__ __forceinline__ Activated activate(const RenderDev &a, int i) {
 // (one contiguous 46 KB run) through LDS with coalesced accesses; the per-thread stride of 45 floats
 // is odd, so the LDS side is bank-conflict free.
 constexpr int SH_REST_MAX = 45;  // (16 - 1) * 3
+// Gaussians (= threads) per workgroup of the per-Gaussian kernels below: LDS holds RB x 45 floats of SH
+// coefficients (46 KB at 256).  Measured at C2: 64 / 128 / 256 are within 3 % of each other for the mapping
+// backward (LDS bytes per resident wave are the same), and 256 has the fewest dL/dw2c atomics in tracking.
+constexpr int RB = 256;
+
 __device__ __forceinline__ void stage_in(float *lds, const float *src, size_t first, size_t count) {
   // count floats starting at src[first]; first*4 is 16-byte aligned for 256-Gaussian blocks when the row
   // length is a multiple of 4 bytes x 4 -- fall back to scalar copies otherwise
   if (((first & 3) == 0) && ((((uintptr_t)src) & 15) == 0)) {
     const float4 *s4 = (const float4 *)(src + first);
     size_t n4 = count >> 2;
-    for (size_t i = threadIdx.x; i < n4; i += 256) ((float4 *)lds)[i] = s4[i];
-    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) lds[i] = src[first + i];
+    for (size_t i = threadIdx.x; i < n4; i += RB) ((float4 *)lds)[i] = s4[i];
+    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += RB) lds[i] = src[first + i];
   } else {
-    for (size_t i = threadIdx.x; i < count; i += 256) lds[i] = src[first + i];
+    for (size_t i = threadIdx.x; i < count; i += RB) lds[i] = src[first + i];
   }
 }
 __device__ __forceinline__ void stage_out(float *dst, const float *lds, size_t first, size_t count) {
   if (((first & 3) == 0) && ((((uintptr_t)dst) & 15) == 0)) {
     float4 *d4 = (float4 *)(dst + first);
     size_t n4 = count >> 2;
-    for (size_t i = threadIdx.x; i < n4; i += 256) d4[i] = ((const float4 *)lds)[i];
-    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) dst[first + i] = lds[i];
+    for (size_t i = threadIdx.x; i < n4; i += RB) d4[i] = ((const float4 *)lds)[i];
+    for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += RB) dst[first + i] = lds[i];
   } else {
-    for (size_t i = threadIdx.x; i < count; i += 256) dst[first + i] = lds[i];
+    for (size_t i = threadIdx.x; i < count; i += RB) dst[first + i] = lds[i];
   }
 }
 
-__global__ __launch_bounds__(256) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
+__global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
                                                              float *__restrict__ colors6,
                                                              uint32_t *__restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];
+  __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
   const int b0 = blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;  // floats of f_rest per Gaussian
   if (a.deg > 0) {
-    size_t cnt = (size_t)min(256, P - b0) * row;
+    size_t cnt = (size_t)min(RB, P - b0) * row;
     stage_in(s_rest, a.f_rest, (size_t)b0 * row, cnt);
     __syncthreads();
   }
@@ -241,16 +246,16 @@ __device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const Ada
   const bool vec = ((first & 3) == 0) && (((((uintptr_t)pp) | ((uintptr_t)mp) | ((uintptr_t)vp)) & 15) == 0);
   const size_t n4 = vec ? (stage_cnt >> 2) : 0;
   constexpr int U = 4;
-  for (size_t q0 = threadIdx.x; q0 < n4; q0 += 256 * U) {
+  for (size_t q0 = threadIdx.x; q0 < n4; q0 += RB * U) {
     float4 p4[U], m4[U], v4[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const size_t q = q0 + (size_t)u * 256;
+      const size_t q = q0 + (size_t)u * RB;
       if (q < n4) { p4[u] = ((float4 *)pp)[q]; m4[u] = ((float4 *)mp)[q]; v4[u] = ((float4 *)vp)[q]; }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const size_t q = q0 + (size_t)u * 256;
+      const size_t q = q0 + (size_t)u * RB;
       if (q >= n4) break;
       const float4 g4 = ((const float4 *)s_rest)[q];
       adam_one(p4[u].x, g4.x, m4[u].x, v4[u].x, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
@@ -260,7 +265,7 @@ __device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const Ada
       ((float4 *)pp)[q] = p4[u]; ((float4 *)mp)[q] = m4[u]; ((float4 *)vp)[q] = v4[u];
     }
   }
-  for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += 256) {
+  for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += RB) {
     float pv = pp[e], mv = mp[e], vv = vp[e];
     adam_one(pv, s_rest[e], mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
     pp[e] = pv; mp[e] = mv; vp[e] = vv;
@@ -268,7 +273,7 @@ __device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const Ada
 }
 
 template <int OUT>
-__global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
+__global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
                                                              const float4 *__restrict__ conic_op,
                                                              const float *__restrict__ grad_acc,
@@ -277,13 +282,13 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
                                                              RenderGradsDev out, AdamDev ad) {
   const GradSink<OUT> sink{out, a, ad};
   constexpr bool ADAM = OUT == OUT_ADAM;
-  __shared__ float red[12][4];
-  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];  // coefficients in, their gradients out
+  __shared__ float red[12][RB / 64];
+  __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];  // coefficients in, their gradients out
   const int b0 = blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;
   const bool stage = (mode & MODE_PARAM_GRAD) && row > 0;
-  const size_t stage_cnt = (size_t)min(256, P - b0) * row;
+  const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
   if (stage) {
     if (a.deg > 0) stage_in(s_rest, a.f_rest, (size_t)b0 * row, stage_cnt);
     __syncthreads();
@@ -406,7 +411,9 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
       }
     __syncthreads();
     if (threadIdx.x < 12) {
-      float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < RB / 64; w++) t += red[threadIdx.x][w];
       if (t != 0.f) atomicAdd(out.w2c + threadIdx.x, t);
     }
   }
@@ -415,14 +422,14 @@ __global__ __launch_bounds__(256) void render_pre_bwd_kernel(int P, CamParams ca
 // Adam step of all six groups from the compact per-Gaussian gradient (see OUT_COMPACT): the SH gradients
 // basis_k x gcol_c are formed here, in LDS, and never exist in HBM.  The basis uses the position BEFORE this
 // step's update, i.e. the one the forward pass saw.
-__global__ __launch_bounds__(256) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc, AdamDev ad) {
-  __shared__ __attribute__((aligned(16))) float s_rest[256 * SH_REST_MAX];
+__global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc, AdamDev ad) {
+  __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
   const RenderGradsDev none{};
   const GradSink<OUT_ADAM> sink{none, a, ad};
   const int b0 = blockIdx.x * blockDim.x;
   const int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;
-  const size_t stage_cnt = (size_t)min(256, P - b0) * row;
+  const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
   if (i < P) {
     const float *g = gc + (size_t)i * COMPACT_ROW;
     const float vx = a.xyz[3 * i] - a.cam_center[0], vy = a.xyz[3 * i + 1] - a.cam_center[1],
@@ -504,7 +511,7 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
     GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};
-    hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, to_dev(args), g,
+    hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args), g,
                        B.colors, B.flags);
   }
   FSGS_HIP(hipGetLastError());
@@ -626,15 +633,15 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     if (adam)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad);
     else if (compact)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad);
     else
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad);
   }
@@ -693,7 +700,7 @@ int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcomp
   if (fill_adam(adam, args->max_sh_degree, ad) != FSGS_OK) return FSGS_ERR_INVALID;
   {
     ProfScope ps(PROF_ADAM, stream);
-    hipLaunchKernelGGL(adam_compact_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, to_dev(args), gcompact, ad);
+    hipLaunchKernelGGL(adam_compact_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, to_dev(args), gcompact, ad);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
