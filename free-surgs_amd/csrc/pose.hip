@@ -6,7 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <math.h>
+
 #include "../../include/fsgs.h"
+#include "fsgs_device.h"
 #include "fsgs_host.h"
 
 namespace {
@@ -66,9 +69,83 @@ __global__ void pose_bwd_kernel(const float *r, int N, int id, const float *dW, 
   dt[0 * N + id] = dW[3]; dt[1 * N + id] = dW[7]; dt[2 * N + id] = dW[11];
 }
 
+// One launch for the tail of a tracking iteration (train.py:186-195): dW = w_a dW_a + dW_b, the adjoint of
+// LearnPose.forward for camera `id`, torch.optim.Adam over ALL of r [1,4,N] and t [3,N] (zero gradient outside
+// column id, exactly what autograd would hand the optimizer), and the new w2c of camera id for the next
+// iteration.  Replaces: add, pose backward, Adam, pose forward (4-6 launches of ~5 us each).
+__global__ __launch_bounds__(256) void pose_adam_kernel(float *r, float *t, int N, int id, const float *dWa, float wa,
+                                                        const float *dWb, float *m_r, float *v_r, float *m_t,
+                                                        float *v_t, float ss_r, float ib_r, float ss_t, float ib_t,
+                                                        float omb1, float b2, float omb2, float eps, float *w2c) {
+  __shared__ float g7[7];
+  if (threadIdx.x == 0) {
+    float dW[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) dW[k] = wa * dWa[k] + (dWb ? dWb[k] : 0.f);
+    PoseQ p = pose_quat(r, N, id);
+    const float qr = p.q2[0], x = p.q2[1], y = p.q2[2], z = p.q2[3];
+    const float d0 = dW[0], d1 = dW[1], d2 = dW[2], d3 = dW[4], d4 = dW[5], d5 = dW[6], d6 = dW[8], d7 = dW[9],
+                d8 = dW[10];
+    float g[4];
+    g[0] = 2.f * (-z * d1 + y * d2 + z * d3 - x * d5 - y * d6 + x * d7);
+    g[1] = 2.f * (y * d1 + z * d2 + y * d3 - 2.f * x * d4 - qr * d5 + z * d6 + qr * d7 - 2.f * x * d8);
+    g[2] = 2.f * (-2.f * y * d0 + x * d1 + qr * d2 + x * d3 + z * d5 - qr * d6 + z * d7 - 2.f * y * d8);
+    g[3] = 2.f * (-2.f * z * d0 - qr * d1 + x * d2 + qr * d3 - 2.f * z * d4 + y * d5 + x * d6 + y * d7);
+    float dot = p.q2[0] * g[0] + p.q2[1] * g[1] + p.q2[2] * g[2] + p.q2[3] * g[3];
+    float h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = (g[k] - p.q2[k] * dot) / p.n1;
+    dot = p.q1[0] * h[0] + p.q1[1] * h[1] + p.q1[2] * h[2] + p.q1[3] * h[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) g7[k] = (h[k] - p.q1[k] * dot) / p.n0;
+    g7[4] = dW[3]; g7[5] = dW[7]; g7[6] = dW[11];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 7 * N; e += blockDim.x) {
+    const bool is_r = e < 4 * N;
+    const int le = is_r ? e : e - 4 * N;
+    const int row = le / N, col = le - row * N;
+    const float g = col == id ? g7[is_r ? row : 4 + row] : 0.f;
+    float *pp = is_r ? r + le : t + le, *mp = is_r ? m_r + le : m_t + le, *vp = is_r ? v_r + le : v_t + le;
+    float pv = *pp, mv = *mp, vv = *vp;
+    fsgs::adam_one(pv, g, mv, vv, omb1, b2, omb2, eps, is_r ? ss_r : ss_t, is_r ? ib_r : ib_t);
+    *pp = pv; *mp = mv; *vp = vv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && w2c) {
+    PoseQ p = pose_quat(r, N, id);  // the updated quaternion
+    const float qr = p.q2[0], x = p.q2[1], y = p.q2[2], z = p.q2[3];
+    w2c[0] = 1.f - 2.f * (y * y + z * z); w2c[1] = 2.f * (x * y - qr * z);       w2c[2] = 2.f * (x * z + qr * y);
+    w2c[4] = 2.f * (x * y + qr * z);       w2c[5] = 1.f - 2.f * (x * x + z * z); w2c[6] = 2.f * (y * z - qr * x);
+    w2c[8] = 2.f * (x * z - qr * y);       w2c[9] = 2.f * (y * z + qr * x);       w2c[10] = 1.f - 2.f * (x * x + y * y);
+    w2c[3] = t[0 * N + id]; w2c[7] = t[1 * N + id]; w2c[11] = t[2 * N + id];
+    w2c[12] = 0.f; w2c[13] = 0.f; w2c[14] = 0.f; w2c[15] = 1.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fsgs_pose_adam_step(float *r, float *t, int num_cams, int cam_id, const float *dw2c_a, float weight_a,
+                        const float *dw2c_b, float *exp_avg_r, float *exp_avg_sq_r, float *exp_avg_t,
+                        float *exp_avg_sq_t, float lr_r, float lr_t, int step_r, int step_t, double beta1, double beta2,
+                        double eps, float *w2c_next, fsgs_stream_t stream) {
+  if (!r || !t || !dw2c_a || !exp_avg_r || !exp_avg_sq_r || !exp_avg_t || !exp_avg_sq_t || num_cams <= 0 ||
+      cam_id < 0 || cam_id >= num_cams || step_r < 1 || step_t < 1)
+    return FSGS_ERR_INVALID;
+  // the host arithmetic of fsgs_adam_step
+  const float ss_r = (float)((double)lr_r / (1.0 - pow(beta1, (double)step_r)));
+  const float ib_r = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step_r)));
+  const float ss_t = (float)((double)lr_t / (1.0 - pow(beta1, (double)step_t)));
+  const float ib_t = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step_t)));
+  hipLaunchKernelGGL(pose_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, r, t, num_cams, cam_id, dw2c_a,
+                     weight_a, dw2c_b, exp_avg_r, exp_avg_sq_r, exp_avg_t, exp_avg_sq_t, ss_r, ib_r, ss_t, ib_t,
+                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, w2c_next);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
 
 int fsgs_pose_forward(const float *r, const float *t, int num_cams, int cam_id, float *w2c, fsgs_stream_t stream) {
   if (!r || !t || !w2c || num_cams <= 0 || cam_id < 0 || cam_id >= num_cams) return FSGS_ERR_INVALID;

@@ -77,6 +77,7 @@ class FastStepper:
         self.last = {}
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
+        self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
 
     # ---- helpers -----------------------------------------------------------------------------------------
     def _buffers(self, P, H, W, n_patches, dev):
@@ -354,12 +355,17 @@ class FastStepper:
         return total
 
     # ---- tracking (train.py:166-200) -----------------------------------------------------------------------
-    def tracking_step(self, t, targets, rigid_mask):
+    def tracking_step(self, t, targets, rigid_mask, want_losses=True):
+        """One pose-tracking iteration of frame t.  want_losses=False skips the two launches that only form the weighted
+        loss values for logging (returns (None, None, None)); the update itself is unaffected."""
         pc, lib, poses = self.pc, self.lib, self.poses
         dev = pc.params["_xyz"].device
         H, W = int(pc.cam.image_height), int(pc.cam.image_width)
         with torch.cuda.device(dev):
-            w2c = poses.get_pose(t)  # keeps the tiny quaternion -> matrix graph for the 12-float chain rule
+            fused_pose = self.fuse_pose and hasattr(poses, "fused_step") and isinstance(poses.optimizer, optim.FusedAdam)
+            # fused: the pose the previous iteration's update kernel already produced (no launch); otherwise the
+            # tiny quaternion -> matrix autograd graph for the 12-float chain rule
+            w2c = poses.get_pose_detached(t) if fused_pose else poses.get_pose(t)
             with torch.no_grad():
                 b = self._buffers(pc.num_points, H, W, int(P_CORR * (H // BOX) * (W // BOX)), dev)
                 stream = _lib.current_stream()
@@ -402,13 +408,21 @@ class FastStepper:
                 torch.cuda.current_stream().wait_event(flow_done)
                 self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False,
                                       zeroed=True)
+                total = rgb = flow = None
+                if want_losses:
+                    weighted = b.terms * b.trk_w  # [w_rgb * rgb, ., ., ., ., w_flow * flow, ., .]
+                    rgb, flow = weighted[0], weighted[5]
+                    total = torch.dot(b.terms, b.trk_w)
+                if fused_pose:
+                    # scheduler first, as train.py:189,194; then ONE launch: w_rgb dW_rgb + dW_flow -> pose adjoint ->
+                    # Adam -> the next iteration's w2c
+                    poses.scheduler.step()
+                    poses.fused_step(t, d_total, float(LOSS_W_TRACKING["rgb"]), b.d_flow)
+                    return total, rgb, flow
                 # d_total = w_rgb * dL_rgb/dw2c + w_flow * dL_flow/dw2c
                 if float(LOSS_W_TRACKING["rgb"]) != 1.0:
                     d_total.mul_(float(LOSS_W_TRACKING["rgb"]))
                 d_total.add_(b.d_flow)
-                weighted = b.terms * b.trk_w  # [w_rgb * rgb, ., ., ., ., w_flow * flow, ., .]
-                rgb, flow = weighted[0], weighted[5]
-                total = torch.dot(b.terms, b.trk_w)
             w2c.backward(d_total)  # LearnPose.forward's backward: normalize + q2rot, 12 floats
             poses.scheduler.step()
             with torch.no_grad():

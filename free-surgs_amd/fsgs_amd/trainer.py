@@ -81,6 +81,42 @@ class PoseTrack:
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=list(range(0, int(tracking_iter), step)), gamma=0.5)
 
+    def fused_step(self, i, dw2c_a, weight_a, dw2c_b):
+        """scheduler-independent tail of a tracking iteration in one launch (csrc/pose.hip pose_adam_kernel):
+        dW = weight_a * dw2c_a + dw2c_b -> LearnPose adjoint -> Adam on r, t -> the new w2c of frame i (cached for the
+        next get_pose_detached).  Call scheduler.step() first, as train.py:189,194 does."""
+        import ctypes as C
+
+        from . import _lib
+        from .optim import FusedAdam, mark_updated
+
+        opt = self.optimizer
+        if not isinstance(opt, FusedAdam) or not self.r.is_cuda:
+            raise RuntimeError("fused pose step needs the HIP FusedAdam on device tensors; there is no CPU fallback")
+        gr, gt_ = opt.param_groups[0], opt.param_groups[1]
+        sts = []
+        for p in (self.r, self.t):
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] = int(st["step"]) + 1
+            sts.append(st)
+        w2c_next = torch.empty((4, 4), dtype=torch.float32, device=self.r.device)
+        N = int(self.r.shape[-1])
+        with torch.cuda.device(self.r.device):
+            rc = _lib.load().fsgs_pose_adam_step(
+                _lib.ptr(self.r), _lib.ptr(self.t), N, int(i), _lib.ptr(dw2c_a), float(weight_a), _lib.ptr(dw2c_b),
+                _lib.ptr(sts[0]["exp_avg"]), _lib.ptr(sts[0]["exp_avg_sq"]), _lib.ptr(sts[1]["exp_avg"]),
+                _lib.ptr(sts[1]["exp_avg_sq"]), float(gr["lr"]), float(gt_["lr"]), int(sts[0]["step"]),
+                int(sts[1]["step"]), float(gr["betas"][0]), float(gr["betas"][1]), float(gr["eps"]),
+                _lib.ptr(w2c_next), _lib.current_stream())
+        _lib.check(rc, "fsgs_pose_adam_step")
+        mark_updated([self.r, self.t])
+        self.pred_w2c[int(i)] = w2c_next
+        self._w2c_cache = ((int(i), self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr()), w2c_next)
+
     def initialize_pose(self, i):
         """constant-velocity prediction for i >= 2 (scene/pose_optimizer.py:498-516)."""
         with torch.no_grad():
@@ -276,9 +312,12 @@ class Runner:
         depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
         targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
         out = None
-        for _ in range(self.tracking_iter):
+        for it_ in range(self.tracking_iter):
             if self.fast is not None:
-                out = self.fast.tracking_step(t, targets, None if all_rigid else rigid) + (None,)
+                # the loss values are only logged once per frame (the reference prints them every iteration through
+                # .item(), i.e. a host sync per iteration)
+                out = self.fast.tracking_step(t, targets, None if all_rigid else rigid,
+                                              want_losses=it_ == self.tracking_iter - 1) + (None,)
             else:
                 out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
         return out

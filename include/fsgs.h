@@ -321,6 +321,15 @@ int fsgs_pose_forward(const float *r, const float *t, int num_cams, int cam_id, 
 /* dw2c [4,4] -> dr [1,4,N], dt [3,N] (overwritten; zero except column cam_id). */
 int fsgs_pose_backward(const float *r, int num_cams, int cam_id, const float *dw2c, float *dr, float *dt,
                        fsgs_stream_t stream);
+/* The tail of a tracking iteration in ONE launch (train.py:186-195): dW = weight_a * dw2c_a + dw2c_b (dw2c_b may be
+ * NULL), the adjoint of LearnPose.forward for cam_id, torch.optim.Adam over all of r [1,4,N] and t [3,N] (the
+ * gradient is zero outside column cam_id, as autograd would report it) with the moments of the two tensors, and
+ * the updated pose of cam_id written to w2c_next [4,4] (may be NULL).  step_* = the step counts INCLUDING this
+ * step; lr_* = the scheduled learning rates. */
+int fsgs_pose_adam_step(float *r, float *t, int num_cams, int cam_id, const float *dw2c_a, float weight_a,
+                        const float *dw2c_b, float *exp_avg_r, float *exp_avg_sq_r, float *exp_avg_t,
+                        float *exp_avg_sq_t, float lr_r, float lr_t, int step_r, int step_t, double beta1, double beta2,
+                        double eps, float *w2c_next, fsgs_stream_t stream);
 
 /* ---- optimiser step and densification statistics -------------------------------------------------- */
 

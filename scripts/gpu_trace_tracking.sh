@@ -11,7 +11,7 @@ python - "$f" <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "pose_bwd_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "pose_adam_kernel" in r["Kernel_Name"]]
 a, b = idx[-3], idx[-2]
 seg = rows[a + 1:b + 1]
 t0 = int(seg[0]["Start_Timestamp"]); t1 = int(seg[-1]["End_Timestamp"])
@@ -19,7 +19,7 @@ busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
 out = open("gpurun_out/trace_tracking.txt", "w")
 def P(*a):
     s = " ".join(str(x) for x in a); print(s); out.write(s + "\n")
-P("one tracking iteration (pose_bwd to pose_bwd): wall %.1f us, kernels %d, busy %.1f us" % ((t1 - t0) / 1e3, len(seg), busy / 1e3))
+P("one tracking iteration (pose update to pose update): wall %.1f us, kernels %d, busy %.1f us" % ((t1 - t0) / 1e3, len(seg), busy / 1e3))
 prev_end = t0
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
