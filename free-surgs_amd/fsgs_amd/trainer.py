@@ -60,14 +60,17 @@ class PoseTrack:
     def get_pose_detached(self, i):
         """w2c of frame i for callers that do not differentiate through the pose (mapping): cached until r / t change
         (in-place updates bump the tensors' version counters), so a mapping iteration does not relaunch the kernel."""
-        key = (int(i), self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr())
-        hit = getattr(self, "_w2c_cache", None)
+        key = (self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr())
+        cache = self.__dict__.setdefault("_w2c_cache", {})
+        hit = cache.get(int(i))
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 w2c = self.get_pose(i).detach().contiguous()
-            # the fused optimizer kernels write r / t behind autograd's back only in the TRACKING step, which bumps
-            # the versions through optimizer.step(); mapping never touches them
-            self._w2c_cache = hit = (key, w2c)
+            # the fused optimizer kernels write r / t behind autograd's back and bump the versions themselves
+            # (optim.mark_updated); mapping never touches the poses, so its frames stay cached
+            if len(cache) > 4096:
+                cache.clear()
+            cache[int(i)] = hit = (key, w2c)
         return hit[1]
 
     def initialize_tracking_optimizer(self, tracking_iter=50):
@@ -115,7 +118,8 @@ class PoseTrack:
         _lib.check(rc, "fsgs_pose_adam_step")
         mark_updated([self.r, self.t])
         self.pred_w2c[int(i)] = w2c_next
-        self._w2c_cache = ((int(i), self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr()), w2c_next)
+        self.__dict__.setdefault("_w2c_cache", {})[int(i)] = (
+            (self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr()), w2c_next)
 
     def initialize_pose(self, i):
         """constant-velocity prediction for i >= 2 (scene/pose_optimizer.py:498-516)."""
