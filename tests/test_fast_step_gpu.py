@@ -138,3 +138,38 @@ def test_mapping_step_without_statistics_is_the_same_update():
         pa, pb = a[0].params[k].detach(), b[0].params[k].detach()
         assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
     assert float(a[0].variables["denom"].sum()) > 0 and float(b[0].variables["denom"].sum()) == 0
+
+
+def test_full_size_c2_gradient_routes_agree():
+    """BASELINE.json's C2 (1280x1024, 300 000 Gaussians): the three gradient routes of the step driver -- Adam inside the
+    backward, the compact [P,14] gradient, full gradients + multi-tensor Adam -- must produce the same update at full
+    size (size-dependent indexing: 300k x 45 SH floats, 5120 tiles, ~1.1 M pairs)."""
+    import bench
+
+    outs = []
+    for route in ("fused", "compact", "full"):
+        torch.manual_seed(0)
+        pc, poses, frames, cam, sc = bench.build_problem("C2", DEV, 0, 1, n_frames=2)
+        fs = FastStepper(pc, poses, frames)
+        H, W = 1024, 1280
+        g = torch.Generator().manual_seed(3)
+        n = int(0.5 * (H // 128) * (W // 128))
+        corners = (torch.randint(0, H - 128, (n,), generator=g).to(DEV), torch.randint(0, W - 128, (n,), generator=g).to(DEV))
+        if route == "compact":
+            fs.fuse_adam = False
+        if route == "full":
+            fs.fuse_adam = fs.compact = False
+        loss = fs.mapping_step([1], corners=corners)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss)
+        outs.append(({k: pc.params[k].detach().clone() for k in PARAM_NAMES}, loss.item(),
+                     pc.variables["denom"].sum().item()))
+        del pc, fs
+    ref = outs[0]
+    for other in outs[1:]:
+        assert abs(other[1] - ref[1]) <= 1e-5 * abs(ref[1]) and other[2] == ref[2]
+        for k in PARAM_NAMES:
+            a, b = ref[0][k], other[0][k]
+            assert torch.isfinite(b).all()
+            # one Adam step of size lr: elements whose gradient is atomics-order noise may differ by ~lr
+            assert ((a - b).abs() > 1e-5 * a.abs().max()).float().mean().item() < 2e-3, k
