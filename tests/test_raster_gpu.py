@@ -134,14 +134,14 @@ def test_thresholds_alpha_clamp_and_termination(oracle32):
     _compare(oracle32, cam, xyz, col, op, s, rot)
 
 
-def test_full_size_properties_c2():
-    """1280x1024 / 300k Gaussians (too slow for the scalar oracle in CI): size-independent
+@pytest.mark.parametrize("W,H,P", [(1280, 1024, 300_000), (1920, 1080, 1_000_000)])  # BASELINE.json C2, C4
+def test_full_size_properties(W, H, P):
+    """full benchmark sizes (too slow for the scalar oracle in CI): size-independent
     properties instead -- silhouette identity (bg = 1: sum(alpha T) + T_final = 1), linearity of
     the image in the colours, and the gradient of a constant-one silhouette plane being zero."""
     from diff_gaussian_rasterization import GaussianRasterizer
     from simple_knn._C import distCUDA2
 
-    W, H, P = 1280, 1024, 300_000
     cam = synth.make_camera(W, H)
     knn = lambda pts: distCUDA2(torch.tensor(pts, device=DEV)).cpu().numpy()
     sc = synth.trained_like_scene(W, H, P, seed=0, knn_fn=knn)
