@@ -162,6 +162,22 @@ def test_full_size_properties(W, H, P):
                     rotations=r_t)
     assert float((i3 - (0.25 * i1 + 0.75 * i2)).abs().max()) < 2e-5
     assert int((radii > 0).sum()) > P // 2
+    # the backward is linear in dL/dpixel: grad(a dL1 + b dL2) = a grad(dL1) + b grad(dL2) for every input
+    def grads(dL):
+        leaves = [x.detach().clone().requires_grad_(True) for x in (m3, c1, o_t, sc_t, r_t)]
+        img, _, _ = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], colors_precomp=leaves[1], scales=leaves[3],
+                         rotations=leaves[4])
+        (img * dL).sum().backward()
+        return [x.grad for x in leaves]
+
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    dL1 = (torch.rand((3, H, W), device=DEV, generator=gen) - 0.5) / (H * W)
+    dL2 = (torch.rand((3, H, W), device=DEV, generator=gen) - 0.5) / (H * W)
+    g1, g2, g3 = grads(dL1), grads(dL2), grads(0.3 * dL1 - 1.7 * dL2)
+    for a, b, c, name in zip(g1, g2, g3, ("means3D", "colors", "opacities", "scales", "rotations")):
+        want = 0.3 * a - 1.7 * b
+        scale = max(float(want.abs().max()), 1e-12)
+        assert float((c - want).abs().max()) <= 2e-4 * scale, name  # atomics order + fp32 cancellation
 
 
 @pytest.mark.parametrize("P", [6000, 24000])  # tile lists up to ~200 keys (rank sort) / ~500 keys (two halves + merge)
