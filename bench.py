@@ -66,6 +66,25 @@ def build_problem(cfg_name, device, rank, world, n_frames=8):
     return pc, poses, frames, cam, sc
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose
+    256 logical CPUs under a 16-core quota; 256 OpenMP threads there run 5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(float(quota) / float(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // pr)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
     """The oracle (kind "port": the reference has no CPU path and its rasteriser source is absent) timed on
     the host cores: rasteriser fwd + bwd of the RGB pass and of the depth/silhouette pass = the
@@ -74,8 +93,8 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
     from oracle.fsgs_oracle import Oracle
 
     o = Oracle(np.float32)
-    o.set_threads(0)
-    cores = o.max_threads()
+    cores = min(usable_cores(), o.max_threads())
+    o.set_threads(cores)
     s, r, op = synth.activate(sc)
     col = np.clip(sc["_features_dc"][:, 0, :] * synth.SH_C0 + 0.5, 0, None).astype(np.float32)
     z = sc["_xyz"][:, 2:3]
