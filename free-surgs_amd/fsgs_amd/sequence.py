@@ -112,3 +112,20 @@ def learner_from_first_frame(frames, cam, ratio=0.1, device="cuda", seed=0):
     pc.cam = settings_from_cam(cam, device)
     pc.training_setup()
     return pc
+
+
+def write_frames(root, frames, scene="1", data="5"):
+    """Lay a synthetic sequence down in the reference's on-disk layout (dataset.write_sequence):
+    8-bit PNG colours, mono-depth as disparity (the reader inverts and re-normalises to [0.5,1.5]), forward flows,
+    zero backward flows, the ground-truth poses and the intrinsics referred back to 1280x1024."""
+    from . import dataset
+
+    H, W = frames.colors[0].shape[-2:]
+    u8 = [(c.detach().clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy() for c in frames.colors]
+    disp = [(1.0 / m.detach()).cpu().numpy() for m in frames.monodeps]
+    fw = [f.detach().cpu().numpy() for f in frames.flows_fw]
+    KL = np.array(frames.K, dtype=np.float64)
+    KL[0, :] *= dataset.REF_W / W
+    KL[1, :] *= dataset.REF_H / H
+    return dataset.write_sequence(root, u8, disp, fw, [np.zeros_like(f) for f in fw], frames.gt_w2c, KL,
+                                  scene=scene, data=data)

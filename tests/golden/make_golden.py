@@ -318,6 +318,119 @@ def main():
         out["r_opacity"] = npy(gm.params["_opacity"])
         out["r_m_opacity"] = npy(gm.optimizer.state[gm.params["_opacity"]]["exp_avg"])
         np.savez_compressed(os.path.join(OUT, "densify.npz"), **out)
+
+        # ---------------- on-disk sequence layout -> record_data (scene/pose_optimizer.py:355-460) ----------------
+        # inputs are laid down by the BUILD's writer (fsgs_amd.dataset.write_sequence), read by the reference's
+        # PoseModel.__init__; the fixture keeps the raw arrays (inputs) and what the reference made of them (outputs)
+        import argparse
+        import contextlib
+        import io
+        import tempfile
+
+        sys.path.insert(0, os.path.join(os.path.dirname(OUT), "..", "free-surgs_amd"))
+        from fsgs_amd import checkpoint as ckpt  # noqa: E402
+        from fsgs_amd import dataset as fds  # noqa: E402
+
+        rng = np.random.default_rng(21)
+        n, H, W = 11, 20, 36
+        colors_u8 = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        disparity = rng.uniform(0.2, 3.0, (n, H, W)).astype(np.float32)
+        flows_fw = rng.normal(0, 2.0, (n - 1, 2, H, W)).astype(np.float32)
+        flows_bw = rng.normal(0, 2.0, (n - 1, 2, H, W)).astype(np.float32)
+        cam_poses = np.tile(np.eye(4), (n, 1, 1))
+        cam_poses[:, :3, 3] = rng.normal(0, 0.1, (n, 3))
+        KL = np.array([[1035.3, 0.0, 596.5], [0.0, 1035.1, 520.4], [0.0, 0.0, 1.0]])
+        runs = ["5"] * 7 + ["6"] * 4
+        with tempfile.TemporaryDirectory() as tmp:
+            fds.write_sequence(tmp, colors_u8, disparity, flows_fw, flows_bw, cam_poses, KL, scene="1", data=runs)
+            out = {"colors_u8": colors_u8, "disparity": disparity, "flows_fw_in": flows_fw, "flows_bw_in": flows_bw,
+                   "cam_poses": cam_poses, "KL": KL, "runs": np.array(runs)}
+            for tag, (fs, fe) in (("all", (0, -1)), ("slice", (2, 9))):
+                a = argparse.Namespace(source_path=tmp, data_type="scared", frame_start=fs, frame_end=fe)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    pm = pose_optimizer.PoseModel(a, device="cpu")
+                rd = pm.record_data
+                out.update({tag + "_colors": npy(rd["colors"]), tag + "_flows_fw": npy(rd["flows_fw"]),
+                            tag + "_flows_bw": npy(rd["flows_bw"]), tag + "_monodeps": npy(rd["monodeps"]),
+                            tag + "_intrinsic": np.asarray(rd["intrinsic"]), tag + "_data_ind": np.asarray(rd["data_ind"]),
+                            tag + "_weights": np.asarray(rd["weights"]), tag + "_i_test": np.asarray(pm.i_test),
+                            tag + "_i_train": np.asarray(pm.i_train), tag + "_fov": np.array([pm.FovX, pm.FovY]),
+                            tag + "_proj": npy(pm.projection_matrix), tag + "_num_cams": pm.num_cams})
+                for k, v in rd["gt_poses"].items():
+                    out["%s_gt_%s" % (tag, k)] = npy(v)
+            np.savez_compressed(os.path.join(OUT, "dataset.npz"), **out)
+
+            # ---------------- checkpoints (scene/gaussian_model.py:86-116, scene/pose_optimizer.py:472-487) -----------
+            # a chkpnt / poses pair WRITTEN BY THE REFERENCE classes (tensors + Adam state_dicts: data only) ...
+            seed_all(23)
+            P = 53
+            gm = GM.__new__(GM)
+            gm.setup_functions()
+            gm.max_sh_degree, gm.active_sh_degree, gm.spatial_lr_scale = 3, 2, 5.0
+            gm.params = {"_xyz": torch.randn(P, 3), "_features_dc": torch.randn(P, 1, 3),
+                         "_features_rest": torch.randn(P, 15, 3), "_opacity": torch.randn(P, 1),
+                         "_scaling": torch.randn(P, 3) - 4.0, "_rotation": torch.randn(P, 4)}
+            gm.params = {k: torch.nn.Parameter(v) for k, v in gm.params.items()}
+            gm.variables = {"max_radii2D": torch.rand(P) * 30, "xyz_gradient_accum": torch.rand(P, 1),
+                            "denom": torch.randint(0, 5, (P, 1)).float()}
+            targs = argparse.Namespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                                       position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025,
+                                       opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+            gm.training_setup(targs)
+            gm.variables["xyz_gradient_accum"] = torch.rand(P, 1)
+            gm.variables["denom"] = torch.randint(1, 5, (P, 1)).float()
+            for it in range(3):
+                for k in gm.params:
+                    gm.params[k].grad = torch.randn_like(gm.params[k]) * 1e-2
+                gm.optimizer.step()
+            a = argparse.Namespace(source_path=tmp, data_type="scared", frame_start=0, frame_end=-1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                pm = pose_optimizer.PoseModel(a, device="cpu")
+            with torch.no_grad():
+                pm.pose_param_net.r.add_(0.05 * torch.randn_like(pm.pose_param_net.r))
+                pm.pose_param_net.t.add_(0.05 * torch.randn_like(pm.pose_param_net.t))
+            pm.initialize_tracking_optimizer(50)
+            for it in range(2):
+                pm.pose_param_net.r.grad = torch.randn_like(pm.pose_param_net.r) * 1e-2
+                pm.pose_param_net.t.grad = torch.randn_like(pm.pose_param_net.t) * 1e-2
+                pm.optimizer.step()
+            for i in range(0, pm.num_cams, 2):
+                pm.record_data["pred_w2c"][i] = npy(pm.pose_param_net(i))
+            torch.save((gm.capture(), 7), os.path.join(OUT, "ref_chkpnt7.pth"))
+            torch.save((pm.capture(), 7), os.path.join(OUT, "ref_poses7.pth"))
+
+            # ... and the other direction checked right here, where the reference can run: a pair written by the
+            # build (fsgs_amd.checkpoint.save) restores into the reference's classes and its Adam keeps stepping
+            from fsgs_amd.model import GaussianCloud  # noqa: E402
+            from fsgs_amd.trainer import PoseTrack  # noqa: E402
+
+            pc = GaussianCloud({k: npy(v) for k, v in gm.params.items()}, sh_degree=3, device="cpu")
+            pc.training_setup(fused=False)
+            for k in pc.params:
+                pc.params[k].grad = torch.randn_like(pc.params[k]) * 1e-2
+            pc.optimizer.step()
+            pt = PoseTrack(pm.num_cams, device="cpu")
+            pt.optimizer = torch.optim.Adam([{"params": pt.r, "lr": 0.01}, {"params": pt.t, "lr": 0.01}], lr=0.001,
+                                            eps=1e-15)
+            pt.r.grad, pt.t.grad = torch.randn_like(pt.r), torch.randn_like(pt.t)
+            pt.optimizer.step()
+            with torch.no_grad():
+                pt.get_pose(3)
+            ckpt.save(tmp, 9, pc, pt, np.eye(3))
+            mp, it9 = torch.load(os.path.join(tmp, "chkpnt9.pth"), weights_only=False)
+            g2 = GM.__new__(GM)
+            g2.setup_functions()
+            g2.params, g2.variables = {}, {}
+            g2.restore(mp, targs)
+            assert it9 == 9 and all(torch.equal(g2.params[k], pc.params[k]) for k in pc.params)
+            for k in g2.params:
+                g2.params[k].grad = torch.ones_like(g2.params[k])
+            g2.optimizer.step()  # torch's Adam accepts the state the build wrote
+            assert float(g2.optimizer.state[g2.params["_xyz"]]["step"]) == 2.0
+            pp, _ = torch.load(os.path.join(tmp, "poses9.pth"), weights_only=False)
+            pm.restore(pp)
+            assert torch.equal(pm.pose_param_net.r, pt.r) and torch.equal(pm.pose_param_net.t, pt.t)
+            assert np.allclose(pm.record_data["pred_w2c"][3], npy(pt.pred_w2c[3])) and not pm.record_data["pred_w2c"][4].any()
     print("golden fixtures written to", OUT)
 
 

@@ -214,3 +214,143 @@ def test_fundamental_matrix_and_sampson_statement_known_answers():
     thr = dist.mean().item() + 2.0 * dist.std().item()
     m = epipolar.rigid_mask_torch(dist, 2.0)
     assert thr > 1.5 and m.tolist() == [[True, True, True, False, False, False]]
+
+
+def _write_golden_dataset(root, d):
+    from fsgs_amd import dataset
+
+    dataset.write_sequence(root, d["colors_u8"], d["disparity"], d["flows_fw_in"], d["flows_bw_in"], d["cam_poses"],
+                           d["KL"], scene="1", data=[str(r) for r in d["runs"]])
+
+
+@pytest.mark.parametrize("tag,fs,fe", [("all", 0, -1), ("slice", 2, 9)])
+def test_sequence_reader_matches_reference_record_data(tmp_path, tag, fs, fe):
+    """the on-disk layout: what PoseModel.__init__ made of the same files (scene/pose_optimizer.py:355-460)."""
+    from fsgs_amd import dataset
+
+    d = _load("dataset.npz")
+    _write_golden_dataset(str(tmp_path), d)
+    fr = dataset.read_sequence(str(tmp_path), frame_start=fs, frame_end=fe, device="cpu")
+    n = int(d[tag + "_num_cams"])
+    assert len(fr.colors) == n == len(fr.monodeps) and len(fr.flows_fw) == n - 1
+    np.testing.assert_array_equal(torch.stack(fr.colors).numpy(), d[tag + "_colors"])       # u8 / 255 in fp32
+    np.testing.assert_array_equal(torch.stack(fr.flows_fw).numpy(), d[tag + "_flows_fw"])
+    np.testing.assert_array_equal(torch.stack(fr.flows_bw).numpy(), d[tag + "_flows_bw"])
+    np.testing.assert_array_equal(torch.stack(fr.monodeps).numpy(), d[tag + "_monodeps"])   # float64 maths, then fp32
+    np.testing.assert_allclose(fr.K, d[tag + "_intrinsic"], rtol=1e-7)
+    np.testing.assert_array_equal(fr.i_test, d[tag + "_i_test"])
+    np.testing.assert_array_equal(fr.i_train, d[tag + "_i_train"])
+    np.testing.assert_array_equal(fr.data_ind, d[tag + "_data_ind"])
+    np.testing.assert_allclose(fr.weights, d[tag + "_weights"])
+    for k, v in fr.gt_poses.items():
+        np.testing.assert_array_equal(v, d["%s_gt_%s" % (tag, k)])
+    cam = dataset.camera_from_frames(fr)
+    fov = d[tag + "_fov"]
+    np.testing.assert_allclose([cam["tanfovx"], cam["tanfovy"]], np.tan(fov * 0.5), rtol=1e-6)
+    assert fr.monodeps[0].min() == 0.5 and fr.monodeps[0].max() == 1.5
+
+
+def test_sequence_reader_errors(tmp_path):
+    from fsgs_amd import dataset
+
+    with pytest.raises(FileNotFoundError):
+        dataset.read_sequence(str(tmp_path), device="cpu")
+    os.makedirs(tmp_path / "input")
+    (tmp_path / "input" / "badname.png").write_bytes(b"")
+    with pytest.raises(ValueError):
+        dataset.read_sequence(str(tmp_path), device="cpu")
+
+
+def test_checkpoints_written_by_the_reference_restore(tmp_path):
+    """chkpnt7.pth / poses7.pth as GaussianModel.capture() / PoseModel.capture() wrote them (train.py:371-376)."""
+    import shutil
+
+    from fsgs_amd import checkpoint
+    from fsgs_amd.trainer import PoseTrack
+
+    for f in ("ref_chkpnt7.pth", "ref_poses7.pth"):
+        shutil.copy(os.path.join(G, f), tmp_path / f.replace("ref_", ""))
+    ref, it = torch.load(tmp_path / "chkpnt7.pth", weights_only=False)
+    P = ref[1].shape[0]
+    pc = model.GaussianCloud({k: np.zeros((1,) + s, np.float32) for k, s in
+                              (("_xyz", (3,)), ("_features_dc", (1, 3)), ("_features_rest", (15, 3)), ("_opacity", (1,)),
+                               ("_scaling", (3,)), ("_rotation", (4,)))}, device="cpu")
+    poses = PoseTrack(2, device="cpu")
+    it2, intrinsic = checkpoint.load(str(tmp_path / "chkpnt7.pth"), pc, poses, fused=False)
+    assert it == it2 == 7 and pc.num_points == P and pc.active_sh_degree == 2 and pc.spatial_lr_scale == 5.0
+    order = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    for k, t in zip(order, ref[1:7]):
+        assert torch.equal(pc.params[k], t.detach()) and pc.params[k].requires_grad and pc.params[k].is_leaf
+    assert torch.equal(pc.variables["max_radii2D"], ref[7])
+    assert not pc.variables["denom"].any() and not pc.variables["xyz_gradient_accum"].any()  # upstream's restore quirk
+    sd = ref[10]
+    for gi, g in enumerate(pc.optimizer.param_groups):
+        assert g["name"] == sd["param_groups"][gi]["name"] and g["lr"] == pytest.approx(sd["param_groups"][gi]["lr"])
+        st = pc.optimizer.state[g["params"][0]]
+        assert int(st["step"]) == 3
+        assert torch.equal(st["exp_avg"], sd["state"][gi]["exp_avg"])
+        assert torch.equal(st["exp_avg_sq"], sd["state"][gi]["exp_avg_sq"])
+    # poses: 11 cameras, every second pred_w2c filled by LearnPose.forward
+    pref, _ = torch.load(tmp_path / "poses7.pth", weights_only=False)
+    assert torch.equal(poses.r, pref[1].detach()) and torch.equal(poses.t, pref[2].detach())
+    assert poses.optimizer is None and intrinsic.shape == (3, 3)
+    for i in range(poses.r.shape[-1]):
+        if i % 2 == 0:
+            np.testing.assert_allclose(poses.pred_w2c[i].numpy(), pref[3][i], rtol=1e-6)
+            np.testing.assert_allclose(pose.pose_to_w2c(poses.r, poses.t, i).detach().numpy(), pref[3][i], atol=1e-6)
+        else:
+            assert poses.pred_w2c[i] is None
+    # and the step after a restore continues the reference's Adam trajectory
+    torch.manual_seed(0)
+    grads = {k: torch.randn_like(pc.params[k]) * 1e-2 for k in order}
+    ref_opt = torch.optim.Adam([{"params": [ref[1 + order.index(g["name"])].detach().clone().requires_grad_(True)],
+                                 "lr": g["lr"], "name": g["name"]} for g in sd["param_groups"]], lr=0.0, eps=1e-15)
+    ref_opt.load_state_dict(sd)
+    for g in ref_opt.param_groups:
+        g["params"][0].grad = grads[g["name"]].clone()
+    ref_opt.step()
+    for k in order:
+        pc.params[k].grad = grads[k].clone()
+    pc.optimizer.step()
+    for g in ref_opt.param_groups:
+        assert torch.equal(pc.params[g["name"]], g["params"][0])
+
+
+def test_checkpoint_round_trip_and_bad_tuples(tmp_path):
+    from fsgs_amd import checkpoint
+    from fsgs_amd.trainer import PoseTrack
+
+    torch.manual_seed(3)
+    P = 17
+    mk = lambda: model.GaussianCloud({"_xyz": torch.randn(P, 3), "_features_dc": torch.randn(P, 1, 3),
+                                      "_features_rest": torch.randn(P, 15, 3), "_opacity": torch.randn(P, 1),
+                                      "_scaling": torch.randn(P, 3), "_rotation": torch.randn(P, 4)}, device="cpu")
+    pc = mk()
+    with pytest.raises(RuntimeError):
+        checkpoint.capture_gaussians(pc)
+    pc.training_setup(fused=False)
+    pc.active_sh_degree = 1
+    for k in pc.params:
+        pc.params[k].grad = torch.randn_like(pc.params[k])
+    pc.optimizer.step()
+    # a FusedAdam-style python-int step must come out as the tensor torch's Adam expects
+    pc.optimizer.state[pc.params["_xyz"]]["step"] = 1
+    poses = PoseTrack(4, device="cpu")
+    poses.set_pose(2, [0.9, 0.1, -0.2, 0.05], [0.1, 0.2, 0.3])
+    with torch.no_grad():
+        poses.get_pose(2)
+    checkpoint.save(str(tmp_path), 42, pc, poses, np.eye(3) * 2)
+    sd = torch.load(tmp_path / "chkpnt42.pth", weights_only=False)[0][10]
+    assert all(torch.is_tensor(s["step"]) and s["step"].dtype == torch.float32 for s in sd["state"].values())
+    pc2, poses2 = mk(), PoseTrack(1, device="cpu")
+    it, K = checkpoint.load(str(tmp_path / "chkpnt42.pth"), pc2, poses2, fused=False)
+    assert it == 42 and np.array_equal(K, np.eye(3) * 2) and pc2.active_sh_degree == 1
+    for k in pc.params:
+        assert torch.equal(pc.params[k], pc2.params[k])
+        assert torch.equal(pc.optimizer.state[pc.params[k]]["exp_avg"], pc2.optimizer.state[pc2.params[k]]["exp_avg"])
+    assert torch.equal(poses.r, poses2.r) and torch.equal(poses2.pred_w2c[2], poses.pred_w2c[2])
+    assert poses2.pred_w2c[0] is None
+    with pytest.raises(ValueError):
+        checkpoint.restore_gaussians(pc2, (1, 2, 3))
+    with pytest.raises(ValueError):
+        checkpoint.restore_poses(poses2, (None, torch.zeros(4, 3), torch.zeros(3, 3), np.zeros((3, 4, 4)), np.eye(3)))

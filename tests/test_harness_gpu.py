@@ -65,3 +65,57 @@ def test_reference_faithful_mode_runs_with_the_row0_depth_quirk():
     m = run.eval_pose()
     assert np.isfinite(m).all()
     assert len(run.log) == n - 1 and all(np.isfinite(l[2]) for l in run.log)
+
+
+def test_run_from_an_on_disk_sequence_then_resume_from_a_checkpoint(tmp_path):
+    """The caller-side data formats: a sequence in the reference's directory layout feeds the
+    harness, and a chkpnt/poses pair in the reference's tuple layout resumes it (train.py:107-111,371-376)."""
+    from fsgs_amd import checkpoint, dataset
+    from fsgs_amd.optim import FusedAdam
+    from fsgs_amd.sequence import learner_from_first_frame, make_sequence, write_frames
+    from fsgs_amd.trainer import PoseTrack, Runner
+
+    torch.manual_seed(0)
+    W, H, n = 320, 256, 5
+    synth_frames, _ = make_sequence(W, H, n, P=40000, seed=3)
+    root = str(tmp_path / "scared_demo")
+    write_frames(root, synth_frames)
+    frames = dataset.read_sequence(root, device="cuda")
+    assert len(frames.colors) == n and frames.colors[0].shape == (3, H, W) and frames.colors[0].is_cuda
+    assert (torch.stack(frames.colors) - torch.stack(synth_frames.colors).clamp(0, 1)).abs().max() <= 0.5 / 255 + 1e-6
+    assert torch.allclose(torch.stack(frames.monodeps), torch.stack(synth_frames.monodeps), atol=1e-5)
+    assert torch.equal(torch.stack(frames.flows_fw), torch.stack(synth_frames.flows_fw))
+    np.testing.assert_allclose(frames.K, synth_frames.K, rtol=1e-6)
+    cam = dataset.camera_from_frames(frames)
+
+    pc = learner_from_first_frame(frames, cam, ratio=0.25)
+    poses = PoseTrack(n, "cuda")
+    run = Runner(pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, row0_depth_quirk=False)
+    run.progressive_run()
+    rpe_t, rpe_r, ate = run.eval_pose()
+    gt = np.stack(frames.gt_w2c)
+    step = np.mean([np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(n - 1)])
+    assert rpe_t < 0.25 * step and ate < 0.25 * step, (rpe_t, ate, step)
+
+    checkpoint.save(str(tmp_path / "out"), run.iteration, pc, poses, frames.K)
+    pc2 = learner_from_first_frame(frames, cam, ratio=0.05)  # a different cloud: restore must replace all of it
+    poses2 = PoseTrack(n, "cuda")
+    it, K = checkpoint.load(str(tmp_path / "out" / ("chkpnt%d.pth" % run.iteration)), pc2, poses2)
+    assert it == run.iteration and isinstance(pc2.optimizer, FusedAdam) and pc2.num_points == pc.num_points
+    np.testing.assert_array_equal(K, frames.K)
+    for k in pc.params:
+        assert torch.equal(pc.params[k], pc2.params[k]) and pc2.params[k].is_cuda
+        s1, s2 = pc.optimizer.state[pc.params[k]], pc2.optimizer.state[pc2.params[k]]
+        assert int(s1["step"]) == int(s2["step"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
+    assert torch.equal(poses.r, poses2.r) and torch.equal(poses.t, poses2.t)
+    # both copies take the same two 2-view mapping iterations: the restored Adam state continues the trajectory
+    run2 = Runner(pc2, poses2, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, row0_depth_quirk=False)
+    run2.iteration, run2.keyframes = run.iteration, list(run.keyframes)
+    run.rng.seed(5)
+    run2.rng.seed(5)
+    for r in (run, run2):
+        torch.manual_seed(9)
+        r.mapping(n - 1, 2, progressive=True)
+    for k in pc.params:
+        a, b = pc.params[k], pc2.params[k]
+        assert (a - b).abs().max() <= 1e-4 * a.abs().max() + 1e-7, k
