@@ -89,12 +89,12 @@ void prof_record(int id, hipStream_t s, bool begin) {
     r.id = id;
     r.closed = false;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_prof_recs.push_back(r);
   } else {
     for (size_t i = g_prof_recs.size(); i-- > 0;)
       if (g_prof_recs[i].id == id && !g_prof_recs[i].closed) {
-        hipEventRecord(g_prof_recs[i].b, s);
+        (void)hipEventRecord(g_prof_recs[i].b, s);
         g_prof_recs[i].closed = true;
         break;
       }
@@ -109,8 +109,8 @@ static void prof_drain() {
         g_prof_n[r.id] += 1;
       }
     }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   g_prof_recs.clear();
 }
