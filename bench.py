@@ -33,6 +33,7 @@ CONFIGS = {
     "C1": (640, 512, 20_000, "init"),
     "C2": (1280, 1024, 300_000, "trained"),
     "C4": (1920, 1080, 1_000_000, "trained"),
+    "C4x4": (1920, 1080, 4_000_000, "trained"),  # size stress only (tests); not a BASELINE.json configuration
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 

@@ -173,3 +173,37 @@ def test_full_size_c2_gradient_routes_agree():
             assert torch.isfinite(b).all()
             # one Adam step of size lr: elements whose gradient is atomics-order noise may differ by ~lr
             assert ((a - b).abs() > 1e-5 * a.abs().max()).float().mean().item() < 2e-3, k
+
+
+def test_four_million_gaussians_step_and_track():
+    """4x the cloud of BASELINE.json's largest configuration (C4: 1920x1080, 1 M): every size-dependent index of the
+    step -- 4 M x 45 SH floats, 8160 tiles x 8 sub-lists, the compact gradient, the fixed-capacity pair segments and
+    their overflow retry -- in one mapping and one tracking iteration; finite results, every visible Gaussian updated,
+    and the dense Adam moved the invisible ones' moments too."""
+    import bench
+    from fsgs_amd.flow import FlowTargets
+
+    torch.manual_seed(0)
+    pc, poses, frames, cam, sc = bench.build_problem("C4x4", DEV, 0, 1, n_frames=2)
+    assert pc.num_points == 4_000_000
+    fs = FastStepper(pc, poses, frames)
+    before = {k: pc.params[k].detach().clone() for k in PARAM_NAMES}
+    loss = fs.mapping_step([1])
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    vis = fs.last["radii"] > 0
+    assert int(vis.sum()) > 2_000_000
+    for k in PARAM_NAMES:
+        assert torch.isfinite(pc.params[k]).all(), k
+    moved = (pc.params["_opacity"].detach() != before["_opacity"]).reshape(-1)
+    assert float(moved[vis].float().mean()) > 0.95  # (a visible Gaussian behind opaque ones may get an exact-zero gradient)
+    assert int(pc.optimizer.state[pc.params["_xyz"]]["step"]) == 1
+    # tracking on the same cloud
+    H, W = 1080, 1920
+    poses.initialize_tracking_optimizer(50)
+    targets = FlowTargets(frames.monodeps[0].reshape(1, H, W), np.eye(4, dtype=np.float32), cam["K"],
+                          torch.zeros((2, H, W), device=DEV), torch.ones((H, W), dtype=torch.bool, device=DEV))
+    r0 = poses.r.detach().clone()
+    total, rgb, flow = fs.tracking_step(1, targets, None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(total) and torch.isfinite(poses.r).all() and not torch.equal(poses.r, r0)
