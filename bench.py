@@ -147,6 +147,9 @@ def main():
                          "several smaller ones eats the ~60 us of Adam they could hide")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
+    ap.add_argument("--profile-stride", type=int, default=3,
+                    help="HIP-event time every n-th launch of the dominant kernels inside the timed region (each timed "
+                         "launch costs two event packets of dispatch gap); 1 = every launch.  Keep it coprime with the 8-frame cycle")
     args = ap.parse_args()
 
     from fsgs_amd import _lib, dist as fdist
@@ -205,7 +208,7 @@ def main():
         one_step(it)
     barrier()
     dominant = "blend_bwd"
-    _lib.profile_enable(None if args.profile_all else [dominant, "blend_fwd"])
+    _lib.profile_enable(None if args.profile_all else [dominant, "blend_fwd"], stride=max(1, args.profile_stride))
     t0 = time.perf_counter()
     for it in range(args.steps):
         loss, pkg = one_step(args.warmup + it)

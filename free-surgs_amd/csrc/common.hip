@@ -77,11 +77,18 @@ struct ProfRec {
 };
 static std::mutex g_prof_mu;
 static uint64_t g_prof_mask = 0;
+static int g_prof_stride = 1;            // time every g_prof_stride-th scope of an enabled id
+static long long g_prof_seen[PROF_COUNT];
 static std::vector<ProfRec> g_prof_recs;
 static double g_prof_ms[PROF_COUNT];
 static long long g_prof_n[PROF_COUNT];
 
-bool prof_enabled(int id) { return (g_prof_mask >> id) & 1ull; }
+bool prof_enabled(int id) {
+  if (!((g_prof_mask >> id) & 1ull)) return false;
+  if (g_prof_stride <= 1) return true;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  return (g_prof_seen[id]++ % g_prof_stride) == 0;
+}
 void prof_record(int id, hipStream_t s, bool begin) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (begin) {
@@ -157,8 +164,13 @@ int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stre
 int fsgs_profile_enable(uint64_t mask) {
   std::lock_guard<std::mutex> lk(fsgs::g_prof_mu);
   fsgs::prof_drain();
-  for (int i = 0; i < fsgs::PROF_COUNT; i++) { fsgs::g_prof_ms[i] = 0; fsgs::g_prof_n[i] = 0; }
+  for (int i = 0; i < fsgs::PROF_COUNT; i++) { fsgs::g_prof_ms[i] = 0; fsgs::g_prof_n[i] = 0; fsgs::g_prof_seen[i] = 0; }
   fsgs::g_prof_mask = mask;
+  return FSGS_OK;
+}
+int fsgs_profile_stride(int stride) {
+  std::lock_guard<std::mutex> lk(fsgs::g_prof_mu);
+  fsgs::g_prof_stride = stride < 1 ? 1 : stride;
   return FSGS_OK;
 }
 int fsgs_profile_count(void) { return fsgs::PROF_COUNT; }

@@ -89,6 +89,7 @@ _PROTOTYPES = {
     "fsgs_selftest_transpose_reduce": (_i, [_vp, _vp, _vp]),
     "fsgs_selftest_transpose_reduce_n": (_i, [_vp, _vp, _i, _vp]),
     "fsgs_profile_enable": (_i, [C.c_uint64]),
+    "fsgs_profile_stride": (_i, [C.c_int]),
     "fsgs_profile_count": (_i, []),
     "fsgs_profile_name": (C.c_char_p, [_i]),
     "fsgs_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -204,9 +205,10 @@ def current_stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def profile_enable(names=None):
-    """Enable HIP-event timing for the named kernels (None = all, [] = off)."""
+def profile_enable(names=None, stride=1):
+    """Enable HIP-event timing for the named kernels (None = all, [] = off); stride n times every n-th launch."""
     lib = load()
+    lib.fsgs_profile_stride(int(stride))
     n = lib.fsgs_profile_count()
     all_names = [lib.fsgs_profile_name(i).decode() for i in range(n)]
     mask = 0

@@ -98,6 +98,10 @@ int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int wid
  * mask: bit i enables kernel id i (ids: fsgs_profile_name); 0 disables.  Enabling resets totals.
  * fsgs_profile_read synchronises the pending events of that id and returns the running totals. */
 int fsgs_profile_enable(uint64_t mask);
+/* Time only every stride-th launch of an enabled kernel (default 1 = every launch): each timed launch puts two
+ * event packets into the stream, ~2-5 us of dispatch gap apiece, which a throughput measurement should not pay on
+ * every step.  Set before fsgs_profile_enable. */
+int fsgs_profile_stride(int stride);
 int fsgs_profile_count(void);
 const char *fsgs_profile_name(int id);
 int fsgs_profile_read(int id, double *total_ms, int64_t *launches);
