@@ -201,7 +201,10 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            if torch.distributed.get_backend() == "nccl":
+                torch.distributed.barrier(device_ids=[local])  # name the device: no rank -> GPU guessing inside RCCL
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for it in range(args.warmup):
@@ -285,8 +288,7 @@ def main():
         buf = torch.zeros((nfloat,), dtype=torch.float32, device=device)
         for _ in range(3):
             torch.distributed.all_reduce(buf)
-        torch.cuda.synchronize()
-        torch.distributed.barrier()
+        barrier()
         tc = time.perf_counter()
         for _ in range(10):
             torch.distributed.all_reduce(buf)
