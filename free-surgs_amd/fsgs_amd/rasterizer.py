@@ -29,20 +29,22 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # ---- host copies of the tiny camera tensors, cached so a render does not sync on them ----------
+# Keyed by the tensor OBJECT (held alive by the entry, so neither its id nor its address can be recycled while it is
+# cached) and its version counter.  A key made of (data_ptr, version, shape) alone is wrong: the caching allocator
+# hands the address of a freed camera matrix to the next one, which starts at version 0 again.
 _host_cache = {}
 
 
 def _host_floats(t, n):
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
-    hit = _host_cache.get(key)
-    if hit is None:
-        if len(_host_cache) > 256:
+    hit = _host_cache.get(id(t))
+    if hit is None or hit[0] is not t or hit[1] != t._version:
+        if len(_host_cache) > 64:
             _host_cache.clear()
-        hit = [float(x) for x in t.detach().reshape(-1).to("cpu", torch.float32).tolist()]
-        _host_cache[key] = hit
-    if len(hit) < n:
-        raise ValueError("camera tensor has %d elements, expected >= %d" % (len(hit), n))
-    return hit
+        vals = [float(x) for x in t.detach().reshape(-1).to("cpu", torch.float32).tolist()]
+        hit = _host_cache[id(t)] = (t, t._version, vals)
+    if len(hit[2]) < n:
+        raise ValueError("camera tensor has %d elements, expected >= %d" % (len(hit[2]), n))
+    return hit[2]
 
 
 def make_cfg(settings, channels):

@@ -301,3 +301,31 @@ def test_pair_capacity_overflow_is_reported_and_retried(oracle32):
         assert rasterizer._capacity[key] >= R
     finally:
         rasterizer._capacity.pop(key, None)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_small_scenes_match_oracle(oracle32, seed):
+    """A seeded sweep over what the fixed cases do not vary together: image sizes that are not multiples of the tile
+    (down to less than one tile), cloud sizes from 1 up, footprints from sub-pixel to screen-filling, needle-shaped
+    Gaussians, a posed raster camera, opacities at both extremes (below 1/255: never visible; 1.0: clamped to 0.99),
+    points on and behind the near plane, 3 or 6 channels."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(5, 150)), int(rng.integers(5, 120))
+    P = int(rng.choice([1, 2, 7, 64, 65, 300, 1500]))
+    w2c = None
+    if seed % 3 == 1:
+        w2c = synth.pose_matrix(np.array([1.0, 0, 0, 0]) + 0.05 * rng.standard_normal(4), 0.05 * rng.standard_normal(3))
+    cam = synth.make_camera(W, H, w2c=w2c)
+    lo, hi = [(0.05, 0.8), (1.5, 6.0), (4.0, 40.0), (0.3, 120.0)][seed % 4]
+    ch = 6 if seed % 2 else 3
+    xyz, col, op, s, r = synth.random_small_scene(P, cam, seed=seed, zmin=0.25, zmax=2.0, scale_px=(lo, hi), channels=ch)
+    if w2c is not None:  # random_small_scene places points in the camera frame: move them to the world
+        xyz = (np.linalg.inv(w2c) @ np.concatenate([xyz, np.ones((P, 1))], 1).T).T[:, :3]
+    s[rng.random(P) < 0.2, 0] *= 12.0      # needles
+    op[rng.random(P) < 0.1] = 0.003        # < 1/255: can never contribute
+    op[rng.random(P) < 0.1] = 1.0          # clamped to 0.99 in the blend
+    xyz[rng.random(P) < 0.05, 2] = 0.2     # exactly on the near-plane cull (z <= 0.2 is culled)
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    # (the sweep also creates and drops a camera per case: the allocator hands the old matrices' addresses to the new
+    # ones, which is how a pointer-keyed host cache of the camera matrices was caught serving stale values)
+    _compare(oracle32, cam, f(xyz), f(col), f(op), f(s), f(r), seed=seed)
