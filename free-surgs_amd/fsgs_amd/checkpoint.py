@@ -40,8 +40,11 @@ def restore_gaussians(pc, model_args, opt=OptimizationParams, eps=1e-15, fused=T
     if len(model_args) != 12:
         raise ValueError("expected the 12-tuple of GaussianModel.capture(), got %d entries" % len(model_args))
     dev = pc.params["_xyz"].device
-    leaf = lambda t: torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).contiguous().requires_grad_(True)
-    plain = lambda t: torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).contiguous()
+    # always a COPY: a tuple captured from a live model (not read from disk) must not end up sharing parameter or
+    # moment storage with the model it is restored into
+    plain = lambda t: torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).clone(
+        memory_format=torch.contiguous_format)
+    leaf = lambda t: plain(t).requires_grad_(True)
     pc.active_sh_degree = int(model_args[0])
     for k, t in zip(_CAPTURE_ORDER, model_args[1:7]):
         pc.params[k] = leaf(t)
@@ -56,7 +59,11 @@ def restore_gaussians(pc, model_args, opt=OptimizationParams, eps=1e-15, fused=T
     pc.variables["denom"] = torch.zeros_like(plain(model_args[9]))
     pc.spatial_lr_scale = float(model_args[11])
     pc.training_setup(opt, eps=eps, fused=fused)
-    pc.optimizer.load_state_dict(model_args[10])
+    sd = model_args[10]
+    pc.optimizer.load_state_dict({
+        "param_groups": sd["param_groups"],
+        "state": {k: {n: (v.detach().clone() if torch.is_tensor(v) else v) for n, v in st.items()}
+                  for k, st in sd["state"].items()}})
     return pc
 
 
@@ -80,8 +87,8 @@ def restore_poses(poses, model_args):
         raise ValueError("expected the 5-tuple of PoseModel.capture(), got %d entries" % len(model_args))
     _, r, t, pred, intrinsic = model_args
     dev = poses.r.device
-    r = torch.as_tensor(r).detach().to(device=dev, dtype=torch.float32)
-    t = torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32)
+    r = torch.as_tensor(r).detach().to(device=dev, dtype=torch.float32).clone()
+    t = torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).clone()
     if tuple(r.shape[:2]) != (1, 4) or tuple(t.shape[:1]) != (3,) or r.shape[-1] != t.shape[-1]:
         raise ValueError("pose tensors must be r[1,4,N] and t[3,N]")
     poses.r = r.contiguous().requires_grad_(True)

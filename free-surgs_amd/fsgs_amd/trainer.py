@@ -203,7 +203,10 @@ def tracking_step(pc, poses, frames, t, targets, rigid_mask, fused=True):
 
     rend = render if fused else render_two_pass
     pkg = rend(poses, t, pc, gs_grad=False, cam_grad=True)
-    mask = ((pkg["render_dep"] > 0) * rigid_mask).unsqueeze(0)
+    mask = pkg["render_dep"] > 0
+    if rigid_mask is not None:  # None = every pixel rigid (frame 1 has no Sampson mask, train.py:158-162)
+        mask = mask * rigid_mask
+    mask = mask.unsqueeze(0)
     rgb = LOSS_W_TRACKING["rgb"] * losses.rgb_loss_func(pkg["render"], frames.colors[t], mask=mask)
     flow = LOSS_W_TRACKING["flow"] * flow_pose_loss(pkg["render_w2c"], targets)
     loss = flow + rgb

@@ -207,3 +207,112 @@ def test_four_million_gaussians_step_and_track():
     total, rgb, flow = fs.tracking_step(1, targets, None)
     torch.cuda.synchronize()
     assert torch.isfinite(total) and torch.isfinite(poses.r).all() and not torch.equal(poses.r, r0)
+
+
+def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
+    """ONE FastStepper (and one set of cached buffers, capacities and streams) driven through a seeded schedule of
+    everything the harness does to it -- 1- and 2-view mapping iterations, tracking iterations with and without a
+    rigid mask, densify + prune (P changes, up and down), opacity reset, SH degree steps -- each event replayed from
+    the SAME state on the torch-autograd path.  Catches state carried from one call shape to the next."""
+    from fsgs_amd import checkpoint, optim, trainer
+    from fsgs_amd.flow import FlowTargets
+
+    H, W = 256, 320
+    a, b = _world(seed=5, P=5000), _world(seed=5, P=5000)
+    for w in (a, b):
+        w[0].active_sh_degree = 0
+    fs = FastStepper(b[0], b[1], b[2])
+    rng = np.random.default_rng(7)
+
+    def copy_state():  # b := a (parameters, Adam moments and step counts, statistics, SH degree, poses)
+        checkpoint.restore_gaussians(b[0], checkpoint.capture_gaussians(a[0]))
+        for k in ("max_radii2D", "xyz_gradient_accum", "denom"):
+            b[0].variables[k] = a[0].variables[k].clone()
+        for ga, gb in zip(a[0].optimizer.param_groups, b[0].optimizer.param_groups):
+            gb["lr"] = ga["lr"]
+        with torch.no_grad():
+            b[1].r.copy_(a[1].r)
+            b[1].t.copy_(a[1].t)
+        optim.mark_updated([b[1].r, b[1].t])
+
+    def close(pa, pb, name, frac=2e-3):
+        if pa.numel() == 0:  # the schedule may prune the whole cloud away; the step must still run
+            assert pb.numel() == 0, name
+            return
+        diff = (pa - pb).abs()
+        assert (diff > 1e-5 * pa.abs().max() + 1e-12).float().mean().item() < frac, name
+
+    log = []
+    for step in range(28):
+        ev = rng.choice(["M1", "M2", "T", "Tm", "D", "R", "S"], p=[0.3, 0.25, 0.1, 0.1, 0.15, 0.05, 0.05])
+        copy_state()
+        P = a[0].num_points
+        log.append((ev, P))
+        if ev in ("M1", "M2"):
+            views = [int(rng.integers(0, 3))] if ev == "M1" else [int(rng.integers(0, 3)), int(rng.integers(0, 3))]
+            corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+            loss, first = 0, None
+            for ts in views:
+                pkg = trainer.render(a[1], ts, a[0], gs_grad=True, cam_grad=False)
+                loss = loss + trainer.mapping_loss(pkg, a[2].colors[ts], a[2].monodeps[ts], corners)
+                first = first or pkg
+            loss.backward()
+            optim.densify_stats(first["radii"], first["viewspace_points"].grad, a[0].variables["max_radii2D"],
+                                a[0].variables["xyz_gradient_accum"], a[0].variables["denom"])
+            a[0].optimizer.step()
+            a[0].optimizer.zero_grad(set_to_none=True)
+            lb = fs.mapping_step(views, corners=corners)
+            assert abs(loss.item() - lb.item()) <= 1e-5 * abs(loss.item()), (step, ev, log)
+            for k in PARAM_NAMES:
+                close(a[0].params[k].detach(), b[0].params[k].detach(), (step, ev, k, log))
+            assert torch.equal(a[0].variables["denom"], b[0].variables["denom"]), (step, ev, log)
+            assert torch.equal(a[0].variables["max_radii2D"], b[0].variables["max_radii2D"]), (step, ev, log)
+        elif ev in ("T", "Tm"):
+            rigid = (torch.rand(H, W, device=DEV) > 0.15) if ev == "Tm" else None
+            depth_prev = torch.rand(1, H, W, device=DEV) + 0.5
+            t = int(rng.integers(1, 3))
+            res = []
+            for w, fast in ((a, False), (b, True)):
+                w[1].initialize_tracking_optimizer(50)
+                targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), w[2].K, w[2].flows_fw[0],
+                                      rigid if rigid is not None else torch.ones(H, W, dtype=torch.bool, device=DEV))
+                for _ in range(2):
+                    l = fs.tracking_step(t, targets, rigid) if fast else tracking_step(w[0], w[1], w[2], t, targets, rigid)
+                res.append(l[0].item())
+            assert abs(res[0] - res[1]) <= 1e-4 * abs(res[0]), (step, ev, log)
+            assert torch.allclose(a[1].r, b[1].r, rtol=0, atol=2e-4) and torch.allclose(a[1].t, b[1].t, rtol=0, atol=2e-4)
+        elif ev == "D":
+            # make the statistics select something: ~10 % above the gradient threshold, a few huge / transparent ones
+            with torch.no_grad():
+                sel = torch.rand(P, 1, device=DEV) < 0.1
+                a[0].variables["denom"] = torch.ones(P, 1, device=DEV)
+                a[0].variables["xyz_gradient_accum"] = torch.where(sel, torch.full_like(sel, 1e-3, dtype=torch.float32),
+                                                                   torch.zeros(P, 1, device=DEV))
+                a[0].params["_opacity"][torch.rand(P, 1, device=DEV) < 0.03] = -6.0
+                a[0].variables["max_radii2D"] = torch.rand(P, device=DEV) * 24.0  # ~1/6 above the screen-size limit
+            copy_state()
+            torch.manual_seed(100 + step)
+            a[0].densify_and_prune(2e-4, 0.05, 20 if step % 2 else None)
+            torch.manual_seed(100 + step)
+            b[0].densify_and_prune_device(2e-4, 0.05, 20 if step % 2 else None)
+            assert a[0].num_points == b[0].num_points and a[0].num_points != P, (step, log)
+            for k in PARAM_NAMES:
+                if k == "_xyz":  # the children's positions: batched GEMM there, FMAs here (tests/test_optim_gpu.py)
+                    assert a[0].num_points == 0 or (
+                        (a[0].params[k] - b[0].params[k]).abs().max() <= 1e-6 * a[0].params[k].abs().max()), (step, log)
+                else:
+                    assert torch.equal(a[0].params[k], b[0].params[k]), (step, k, log)
+                sa, sb = a[0].optimizer.state[a[0].params[k]], b[0].optimizer.state[b[0].params[k]]
+                assert ("exp_avg" in sa) == ("exp_avg" in sb)
+                if "exp_avg" in sa:  # (no Adam state yet when the schedule densifies before the first step)
+                    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        elif ev == "R":
+            a[0].reset_opacity()
+            b[0].reset_opacity()
+            assert torch.equal(a[0].params["_opacity"], b[0].params["_opacity"])
+        else:
+            a[0].oneupSHdegree()
+            b[0].oneupSHdegree()
+    kinds = {e for e, _ in log}
+    print("schedule:", " ".join("%s@%d" % (e, p) for e, p in log))
+    assert {"M1", "M2", "D"} <= kinds and len({p for _, p in log}) >= 3, log  # the schedule did change P

@@ -350,6 +350,12 @@ def test_checkpoint_round_trip_and_bad_tuples(tmp_path):
         assert torch.equal(pc.optimizer.state[pc.params[k]]["exp_avg"], pc2.optimizer.state[pc2.params[k]]["exp_avg"])
     assert torch.equal(poses.r, poses2.r) and torch.equal(poses2.pred_w2c[2], poses.pred_w2c[2])
     assert poses2.pred_w2c[0] is None
+    # an in-memory capture restored into another model is a snapshot, not a view of the live tensors
+    pc3 = mk()
+    checkpoint.restore_gaussians(pc3, checkpoint.capture_gaussians(pc), fused=False)
+    assert pc3.params["_xyz"].data_ptr() != pc.params["_xyz"].data_ptr()
+    m1, m3 = pc.optimizer.state[pc.params["_xyz"]]["exp_avg"], pc3.optimizer.state[pc3.params["_xyz"]]["exp_avg"]
+    assert m1.data_ptr() != m3.data_ptr() and torch.equal(m1, m3)
     with pytest.raises(ValueError):
         checkpoint.restore_gaussians(pc2, (1, 2, 3))
     with pytest.raises(ValueError):
