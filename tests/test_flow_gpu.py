@@ -209,3 +209,40 @@ def test_flow_targets_kernels_match_the_torch_statement():
     # nothing valid
     pts, vu = flow.backproject_previous_hip(torch.zeros(1, H, W, device=DEV), K, np.eye(4, dtype=np.float32), None)
     assert pts.shape == (0, 3) and vu.shape == (0, 2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_flow_loss_sizes_masks_and_poses(seed):
+    """image sizes down to the 20-pixel border the loss discards (nothing survives -> exactly zero), holes in the depth,
+    sparse and empty rigid masks, poses that push part of the points behind the camera; the plain and the fused
+    (forward + pose gradient in one pass) entry points against the torch statement."""
+    from fsgs_amd import synth
+
+    rng = np.random.default_rng(400 + seed)
+    H, W = int(rng.integers(30, 200)), int(rng.integers(30, 260))
+    if seed == 0:
+        H, W = 40, 41  # the border band (20 < u < W - 20) leaves no pixel
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    K = synth.intrinsics(W, H)
+    depth = (0.5 + torch.rand((1, H, W), device=DEV, generator=g)).contiguous()
+    depth[0][torch.rand((H, W), device=DEV, generator=g) < 0.2] = 0.0
+    fl = 3.0 * torch.randn((2, H, W), device=DEV, generator=g)
+    keep = float(rng.choice([0.0, 0.02, 0.5, 1.0]))
+    rigid = torch.rand((H, W), device=DEV, generator=g) < keep if keep < 1.0 else None
+    w_prev = synth.pose_matrix(np.array([1.0, 0, 0, 0]) + 0.01 * rng.standard_normal(4), 0.02 * rng.standard_normal(3))
+    w_prev = w_prev.astype(np.float32)
+    q = np.array([1.0, 0, 0, 0]) + float(rng.choice([0.01, 0.3])) * rng.standard_normal(4)
+    t = float(rng.choice([0.02, 0.6])) * rng.standard_normal(3)
+    w_cur = torch.tensor(synth.pose_matrix(q, t).astype(np.float32), device=DEV)
+    targets = flow.FlowTargets(depth, w_prev, K, fl, rigid)
+    a = w_cur.clone().requires_grad_(True)
+    la = flow.flow_pose_loss(a, targets)
+    (la + 0.0 * a.sum()).backward()  # an empty selection returns a constant 0 (scene/pose_optimizer.py:182-183,217)
+    b = w_cur.clone().requires_grad_(True)
+    lb = flow.projection_flow_loss_torch(depth, w_prev, b, K, fl, rigid)
+    (lb + 0.0 * b.sum()).backward()
+    assert abs(la.item() - lb.item()) <= 3e-5 * abs(lb.item()) + 1e-7, (H, W, keep)
+    scale = max(b.grad[:3].abs().max().item(), 1e-12)
+    assert (a.grad[:3] - b.grad[:3]).abs().max().item() <= 1e-3 * scale, (H, W, keep)
+    if lb.item() == 0.0:
+        assert la.item() == 0.0 and not bool(a.grad.abs().sum())

@@ -51,3 +51,28 @@ def test_full_size_idempotence_and_permutation_invariance():
     b = _hip(pts[perm])
     np.testing.assert_array_equal(a[perm], b)
     assert np.all(a > 0) and np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_randomised_clouds_with_degenerate_geometry(oracle32, seed):
+    """cloud sizes around the Morton-box and workgroup boundaries; anisotropic, planar, collinear and clustered point
+    sets; exact duplicates (distance 0) mixed in; wide dynamic range of coordinates."""
+    oracle32.set_threads(0)
+    rng = np.random.default_rng(300 + seed)
+    P = int(rng.choice([4, 6, 63, 64, 65, 127, 129, 511, 513, 1023, 1025, 3000, 5000]))
+    kind = seed % 5
+    pts = rng.standard_normal((P, 3))
+    if kind == 1:
+        pts[:, 2] = 0.0                                   # planar
+    elif kind == 2:
+        pts = np.outer(rng.standard_normal(P), [1.0, 2.0, -0.5])  # collinear
+    elif kind == 3:
+        pts = pts * np.array([1e3, 1.0, 1e-3])            # very anisotropic extent
+    elif kind == 4:
+        centres = rng.standard_normal((5, 3)) * 50
+        pts = centres[rng.integers(0, 5, P)] + 0.01 * pts  # tight clusters far apart
+    dup = rng.random(P) < 0.15
+    pts[dup] = pts[rng.integers(0, P, int(dup.sum()))]   # exact duplicates
+    pts = (pts * float(rng.choice([1e-3, 1.0, 1e3])) + rng.standard_normal(3) * 10).astype(np.float32)
+    got, want = _hip(pts), oracle32.knn_meandist2(pts)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=0, err_msg=str((P, kind)))

@@ -107,3 +107,54 @@ def test_full_size_properties():
     assert abs(l1.item() - l2.item()) < 2e-5
     l1.backward()
     assert abs(dep.grad.sum().item()) < 1e-6 * dep.grad.abs().sum().item()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_shapes_rgb_loss(seed):
+    """image shapes around every edge of the tiling: narrower / shorter than the 11-tap window, one row, one column,
+    one pixel, sizes straddling the 32-pixel tile and the 64-wide streaming segment; with and without a mask; the
+    kernels' scratch is reused from call to call."""
+    rng = np.random.default_rng(50 + seed)
+    H = int(rng.choice([1, 2, 5, 10, 11, 12, 31, 32, 33, 63, 64, 65, 97, 130]))
+    W = int(rng.choice([1, 3, 6, 11, 16, 31, 32, 33, 63, 64, 65, 127, 129, 200]))
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    gt = torch.rand((3, H, W), device=DEV, generator=g)
+    img = (gt + 0.2 * torch.randn((3, H, W), device=DEV, generator=g)).clamp(0, 1)
+    mask = torch.rand((1, H, W), device=DEV, generator=g) > 0.3
+    for m in (None, mask):
+        a = img.clone().requires_grad_(True)
+        b = img.clone().requires_grad_(True)
+        la = losses.rgb_loss_func(a, gt, mask=m)
+        lb = losses.rgb_loss_torch(b, gt, mask=m)
+        la.backward()
+        lb.backward()
+        assert abs(la.item() - lb.item()) <= 2e-5 * abs(lb.item()) + 1e-7, (H, W, m is not None)
+        scale = b.grad.abs().max().item()
+        assert (a.grad - b.grad).abs().max().item() <= 2e-4 * scale + 1e-12, (H, W, m is not None)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_shapes_pearson(seed):
+    """global + local Pearson at random sizes (patches clipped to the image, 1..12 patches incl. duplicates and
+    patches flush with the border), constant-offset / scaled inputs."""
+    rng = np.random.default_rng(80 + seed)
+    box = int(rng.choice([8, 32, 128]))
+    H, W = int(rng.integers(box + 1, box + 200)), int(rng.integers(box + 1, box + 260))
+    n = int(rng.integers(1, 13))
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    mono = torch.rand((H, W), device=DEV, generator=g) * float(rng.uniform(0.1, 5.0)) + float(rng.uniform(-2, 2))
+    dep = (mono * 0.7 + torch.rand((H, W), device=DEV, generator=g)).contiguous()
+    x0 = torch.tensor(rng.integers(0, H - box, n), device=DEV)
+    y0 = torch.tensor(rng.integers(0, W - box, n), device=DEV)
+    if n > 2:
+        x0[1], y0[1] = x0[0], y0[0]              # the same patch twice
+        x0[2], y0[2] = H - box - 1, W - box - 1  # the last corner randint can return
+    a = dep.clone().requires_grad_(True)
+    b = dep.clone().requires_grad_(True)
+    la = 0.05 * losses.pearson_depth_loss(mono, a) + 0.15 * losses.local_pearson_loss(mono, a, box, 0.5, (x0, y0))
+    lb = 0.05 * losses.pearson_torch(mono, b) + 0.15 * losses.local_pearson_torch(mono, b, box, 0.5, (x0, y0))
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-4 * abs(lb.item()) + 1e-7, (H, W, box, n)
+    scale = b.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() <= 2e-4 * scale, (H, W, box, n)
