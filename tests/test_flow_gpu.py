@@ -246,3 +246,29 @@ def test_randomised_flow_loss_sizes_masks_and_poses(seed):
     assert (a.grad[:3] - b.grad[:3]).abs().max().item() <= 1e-3 * scale, (H, W, keep)
     if lb.item() == 0.0:
         assert la.item() == 0.0 and not bool(a.grad.abs().sum())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_sampson_mask_sizes(seed):
+    """pixel counts below, at and across the 4096-pixel chunks of the two-pass statistics; random relative poses and
+    threshold factors; the `dist < (dist <= mean + factor std)` quirk of the reference decides the mask."""
+    from fsgs_amd import epipolar, synth
+
+    rng = np.random.default_rng(700 + seed)
+    H, W = [(1, 1), (3, 5), (64, 64), (64, 65), (17, 241), (100, 123), (128, 160), (211, 97)][seed]
+    K = synth.intrinsics(max(W, 8), max(H, 8))
+    w1 = synth.pose_matrix(np.array([1.0, 0, 0, 0]) + 0.01 * rng.standard_normal(4), 0.02 * rng.standard_normal(3))
+    w2 = synth.pose_matrix(np.array([1.0, 0, 0, 0]) + 0.02 * rng.standard_normal(4), 0.05 * rng.standard_normal(3))
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    fl = 2.0 * torch.randn((2, H, W), device=DEV, generator=g)
+    F = epipolar.fundamental_from_w2c(w1, w2, K)
+    factor = float(rng.choice([0.5, 2.0, 3.0]))
+    rigid, dist, stats = epipolar.rigid_mask(fl, F, factor)
+    want = epipolar.sampson_distance_torch(fl, F)
+    scale = max(want.abs().max().item(), 1e-30)
+    assert (dist - want).abs().max().item() <= 2e-4 * scale
+    np.testing.assert_allclose(stats[0].item(), want.mean().item(), rtol=2e-4)
+    if H * W > 1:
+        np.testing.assert_allclose(stats[1].item(), want.std().item(), rtol=2e-4)
+    wm = epipolar.rigid_mask_torch(want, factor)
+    assert (rigid != wm).float().mean().item() <= max(1e-4, 1.01 / (H * W)) if H * W > 1 else True
