@@ -72,7 +72,8 @@ enum {
 typedef struct FsgsRasterCfg {
   int32_t image_height;
   int32_t image_width;
-  int32_t channels;        /* colour channels of colors_precomp: 1..FSGS_MAX_CHANNELS (reference: 3) */
+  int32_t channels;        /* colour channels of colors_precomp: 1, 3 (the reference) or 6 (both passes fused);
+                            * any other count is FSGS_ERR_INVALID */
   int32_t flags;           /* FSGS_FLAG_* bits, 0 = defaults */
   float tanfovx;
   float tanfovy;

@@ -308,7 +308,7 @@ def test_randomised_small_scenes_match_oracle(oracle32, seed):
     """A seeded sweep over what the fixed cases do not vary together: image sizes that are not multiples of the tile
     (down to less than one tile), cloud sizes from 1 up, footprints from sub-pixel to screen-filling, needle-shaped
     Gaussians, a posed raster camera, opacities at both extremes (below 1/255: never visible; 1.0: clamped to 0.99),
-    points on and behind the near plane, 3 or 6 channels."""
+    points on and behind the near plane, 1, 3 or 6 channels."""
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.integers(5, 150)), int(rng.integers(5, 120))
     P = int(rng.choice([1, 2, 7, 64, 65, 300, 1500]))
@@ -317,7 +317,7 @@ def test_randomised_small_scenes_match_oracle(oracle32, seed):
         w2c = synth.pose_matrix(np.array([1.0, 0, 0, 0]) + 0.05 * rng.standard_normal(4), 0.05 * rng.standard_normal(3))
     cam = synth.make_camera(W, H, w2c=w2c)
     lo, hi = [(0.05, 0.8), (1.5, 6.0), (4.0, 40.0), (0.3, 120.0)][seed % 4]
-    ch = 6 if seed % 2 else 3
+    ch = (3, 6, 1)[seed % 3 if seed % 5 else 2]
     xyz, col, op, s, r = synth.random_small_scene(P, cam, seed=seed, zmin=0.25, zmax=2.0, scale_px=(lo, hi), channels=ch)
     if w2c is not None:  # random_small_scene places points in the camera frame: move them to the world
         xyz = (np.linalg.inv(w2c) @ np.concatenate([xyz, np.ones((P, 1))], 1).T).T[:, :3]
@@ -329,3 +329,15 @@ def test_randomised_small_scenes_match_oracle(oracle32, seed):
     # (the sweep also creates and drops a camera per case: the allocator hands the old matrices' addresses to the new
     # ones, which is how a pointer-keyed host cache of the camera matrices was caught serving stale values)
     _compare(oracle32, cam, f(xyz), f(col), f(op), f(s), f(r), seed=seed)
+
+
+def test_unsupported_channel_count_is_an_error_not_a_wrong_image():
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    cam = synth.make_camera(48, 32)
+    xyz, col, op, s, r = synth.random_small_scene(20, cam, seed=0, channels=4)
+    T = lambda a: torch.tensor(np.asarray(a, np.float32), device=DEV)
+    with pytest.raises(Exception):
+        GaussianRasterizer(raster_settings=_settings(cam))(
+            means3D=T(xyz), means2D=torch.zeros(20, 3, device=DEV), opacities=T(op).reshape(-1, 1),
+            colors_precomp=T(col), scales=T(s), rotations=T(r))
