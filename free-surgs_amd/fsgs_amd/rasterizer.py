@@ -207,8 +207,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (gaussian_renderer/__init__.py:68-70)
         m3, col, sc, rot, radii = ctx.saved_tensors
         gc = _f32c(grad_color)
+        # the forward state is read-only here and stays with ctx: a retained graph can be backpropagated again, and
+        # without retain_graph autograd frees ctx (and with it the state) as soon as this node is done
         dm2, dcol, dop, dm3, dsc, drot = raster_backward(ctx.st, m3, col, sc, rot, radii, gc)
-        ctx.st = None
         return dm3, dm2, None, dcol, dop, dsc, drot, None, None
 
 

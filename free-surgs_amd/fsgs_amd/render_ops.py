@@ -97,7 +97,7 @@ class _FusedRender(torch.autograd.Function):
             _lib.check(rc, "fsgs_render_backward")
         elif d_w2c is not None:
             d_w2c.zero_()
-        ctx.misc = None
+        # (ctx.misc stays: the forward state is read-only, so a retained graph can be backpropagated again)
         return (d_xyz, d[0], d[1], d[2], d[3], d[4], d_w2c, d_m2, None, None, None, None, None, None, None)
 
 

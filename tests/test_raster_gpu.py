@@ -341,3 +341,75 @@ def test_unsupported_channel_count_is_an_error_not_a_wrong_image():
         GaussianRasterizer(raster_settings=_settings(cam))(
             means3D=T(xyz), means2D=torch.zeros(20, 3, device=DEV), opacities=T(op).reshape(-1, 1),
             colors_precomp=T(col), scales=T(s), rotations=T(r))
+
+
+def _scene_tensors(cam, P, seed, channels=3):
+    xyz, col, op, s, r = synth.random_small_scene(P, cam, seed=seed, channels=channels)
+    T = lambda a: torch.tensor(np.asarray(a, np.float32), device=DEV)
+    return T(xyz), T(col), T(op).reshape(-1, 1), T(s), T(r)
+
+
+def _fwd_bwd(rast, tens, dL, leaves=None):
+    leaves = leaves or [t.detach().clone().requires_grad_(True) for t in tens]
+    m3, c, o, s, r = leaves
+    img, radii, depth = rast(means3D=m3, means2D=torch.zeros_like(m3), opacities=o, colors_precomp=c, scales=s, rotations=r)
+    (img * dL).sum().backward()
+    return img.detach(), [x.grad.clone() for x in leaves]
+
+
+def test_interleaved_live_states_and_repeated_backward():
+    """the mapping iteration keeps several forward states alive before any backward runs (2 views x 2 passes,
+    train.py:236-265): forward A, forward B, backward B, backward A must equal the isolated runs; and a retained graph
+    can be backpropagated twice (the saved state is read-only)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    camA, camB = synth.make_camera(96, 64), synth.make_camera(50, 70, w2c=synth.pose_matrix((1, .02, -.01, .03), (.02, 0, .01)))
+    rA, rB = GaussianRasterizer(raster_settings=_settings(camA)), GaussianRasterizer(raster_settings=_settings(camB))
+    tA, tB = _scene_tensors(camA, 700, 1), _scene_tensors(camB, 300, 2)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    dA = torch.rand((3, 64, 96), device=DEV, generator=g) - 0.5
+    dB = torch.rand((3, 70, 50), device=DEV, generator=g) - 0.5
+    imgA, gA = _fwd_bwd(rA, tA, dA)
+    imgB, gB = _fwd_bwd(rB, tB, dB)
+    lA = [t.detach().clone().requires_grad_(True) for t in tA]
+    lB = [t.detach().clone().requires_grad_(True) for t in tB]
+    iA, _, _ = rA(means3D=lA[0], means2D=torch.zeros_like(lA[0]), opacities=lA[2], colors_precomp=lA[1], scales=lA[3], rotations=lA[4])
+    iB, _, _ = rB(means3D=lB[0], means2D=torch.zeros_like(lB[0]), opacities=lB[2], colors_precomp=lB[1], scales=lB[3], rotations=lB[4])
+    (iB * dB).sum().backward(retain_graph=True)
+    (iA * dA).sum().backward()
+    assert torch.equal(iA.detach(), imgA) and torch.equal(iB.detach(), imgB)
+    for got, want in zip([x.grad for x in lA] + [x.grad for x in lB], gA + gB):
+        assert (got - want).abs().max() <= 1e-5 * want.abs().max() + 1e-12  # atomics order only
+    first = [x.grad.clone() for x in lB]
+    (iB * dB).sum().backward()  # second pass over the retained graph: gradients accumulate to exactly twice
+    for x, f in zip(lB, first):
+        assert (x.grad - 2 * f).abs().max() <= 2e-5 * f.abs().max() + 1e-12
+
+
+def test_non_contiguous_inputs_and_a_side_stream():
+    """views into larger tensors (the reference slices and transposes freely) and a call issued on a non-default
+    stream give the results of the contiguous default-stream call; gradients come back in the views' shapes."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    cam = synth.make_camera(80, 48)
+    rast = GaussianRasterizer(raster_settings=_settings(cam))
+    tens = _scene_tensors(cam, 500, 3)
+    dL = torch.rand((3, 48, 80), device=DEV) - 0.5
+    img0, g0 = _fwd_bwd(rast, tens, dL)
+    P = tens[0].shape[0]
+    big = torch.zeros((P, 7), device=DEV)
+    big[:, 1:4] = tens[0]
+    m3 = big[:, 1:4].detach().requires_grad_(True)                      # row stride 7
+    col = tens[1].t().contiguous().t().detach().requires_grad_(True)     # column-major
+    sc = tens[3][:, [2, 0, 1]][:, [1, 2, 0]].detach().requires_grad_(True)
+    rot = torch.cat([tens[4], tens[4]], 1)[:, :4].detach().requires_grad_(True)
+    op = tens[2].expand(P, 1).detach().requires_grad_(True)
+    assert not m3.is_contiguous() and not col.is_contiguous() and not rot.is_contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        img1, g1 = _fwd_bwd(rast, None, dL, leaves=[m3, col, op, sc, rot])
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(img1, img0)
+    for a, b in zip(g1, g0):
+        assert a.shape == b.shape and (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12

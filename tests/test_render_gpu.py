@@ -206,3 +206,21 @@ def test_randomised_fused_render_equals_two_pass(seed):
         for k in PARAM_NAMES + ("viewspace",):
             assert_close_flip_aware(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1), k, floor=floor, rows=P,
                                     max_frac=2e-3)
+
+
+def test_fused_render_retained_graph_backpropagates_twice():
+    """autograd lets a retained graph run backward again; the op's saved forward state must survive the first pass."""
+    W, H, P = 96, 80, 900
+    pc, poses = _setup(W, H, P, 2, seed=4)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV)
+    wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV)
+    pkg = render(poses, 1, pc, gs_grad=True, cam_grad=True)
+    loss = (pkg["render"] * wi).sum() + (pkg["render_dep"] * wd).sum()
+    loss.backward(retain_graph=True)
+    first = {k: pc.params[k].grad.clone() for k in PARAM_NAMES}
+    r1 = poses.r.grad.clone()
+    loss.backward()
+    for k in PARAM_NAMES:
+        assert (pc.params[k].grad - 2 * first[k]).abs().max() <= 2e-5 * first[k].abs().max() + 1e-12, k
+    assert (poses.r.grad - 2 * r1).abs().max() <= 1e-4 * r1.abs().max() + 1e-12
