@@ -190,6 +190,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 "cov3D_precomp is not on the Free-SurGS path (cov3D_precomp=None, "
                 "scene/gaussian_model.py:309); pass scales and rotations")
         P = means3D.shape[0]
+        # the kernels index raw pointers: a wrong trailing dimension would read out of bounds, so say so here
+        for name, t, tail in (("means3D", means3D, (3,)), ("scales", scales, (3,)), ("rotations", rotations, (4,))):
+            if tuple(t.shape) != (P,) + tail:
+                raise ValueError("%s must have shape [%d, %d], got %s" % (name, P, tail[0], tuple(t.shape)))
+        if opacities.numel() != P or colors_precomp.shape[0] != P:
+            raise ValueError("opacities / colors_precomp must have one row per Gaussian (%d)" % P)
+        for name, t in (("colors_precomp", colors_precomp), ("opacities", opacities), ("scales", scales),
+                        ("rotations", rotations)):
+            if t.device != means3D.device:
+                raise ValueError("%s is on %s, means3D on %s" % (name, t.device, means3D.device))
+        if not means3D.is_cuda:
+            raise RuntimeError("the rasteriser needs CUDA/HIP tensors; there is no CPU fallback")
         m3 = _f32c(means3D)
         col = _f32c(colors_precomp)
         col = col.reshape(P, -1) if P > 0 else col.reshape(0, 3)

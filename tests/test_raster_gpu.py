@@ -413,3 +413,26 @@ def test_non_contiguous_inputs_and_a_side_stream():
     assert torch.equal(img1, img0)
     for a, b in zip(g1, g0):
         assert a.shape == b.shape and (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
+
+
+def test_malformed_inputs_raise_before_any_kernel_runs():
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    cam = synth.make_camera(48, 32)
+    rast = GaussianRasterizer(raster_settings=_settings(cam))
+    m3, col, op, sc, rot = _scene_tensors(cam, 20, 0)
+    call = lambda **kw: rast(**{**dict(means3D=m3, means2D=torch.zeros_like(m3), opacities=op, colors_precomp=col,
+                                       scales=sc, rotations=rot), **kw})
+    call()
+    with pytest.raises(ValueError):
+        call(rotations=rot[:, :3])          # a quaternion has four components
+    with pytest.raises(ValueError):
+        call(scales=sc[:10])                # fewer rows than Gaussians
+    with pytest.raises(ValueError):
+        call(opacities=op[:5])
+    with pytest.raises(ValueError):
+        call(colors_precomp=col.cpu())      # mixed devices
+    with pytest.raises(Exception):
+        call(colors_precomp=None)           # neither shs nor colours (upstream's own check)
+    with pytest.raises(NotImplementedError):
+        call(colors_precomp=None, shs=torch.zeros(20, 16, 3, device=DEV))
