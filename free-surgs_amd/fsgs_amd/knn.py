@@ -11,6 +11,8 @@ def distCUDA2(points):
     lib = _lib.load()
     if not points.is_cuda:
         raise RuntimeError("distCUDA2 needs a CUDA/HIP tensor; there is no CPU fallback")
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError("distCUDA2 expects points of shape [P, 3], got %s" % (tuple(points.shape),))
     pts = points.detach().contiguous().to(torch.float32)
     P = int(pts.shape[0])
     out = torch.zeros((P,), dtype=torch.float32, device=pts.device)  # spatial.cu:20: zeros
