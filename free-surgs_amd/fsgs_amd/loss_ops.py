@@ -18,6 +18,11 @@ class _RgbLoss(torch.autograd.Function):
         lib = _lib.load()
         if not img.is_cuda:
             raise RuntimeError("fsgs rgb_loss needs CUDA/HIP tensors; there is no CPU fallback")
+        if tuple(img.shape) != tuple(gt.shape) or img.dim() not in (3, 4):
+            raise ValueError("rgb_loss: image %s and target %s must both be [C,H,W] (or [1,C,H,W])" % (
+                tuple(img.shape), tuple(gt.shape)))
+        if gt.device != img.device or (mask is not None and mask.device != img.device):
+            raise ValueError("rgb_loss: image, target and mask must be on one device")
         x, y = _f32c(img), _f32c(gt)
         if x.dim() == 4:
             x, y = x.reshape(-1, *x.shape[-2:]), y.reshape(-1, *y.shape[-2:])
