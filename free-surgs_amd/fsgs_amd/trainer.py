@@ -57,13 +57,21 @@ class PoseTrack:
         self.pred_w2c[int(i)] = w2c.detach()
         return w2c
 
+    def _pose_key(self):
+        # the tensor OBJECTS (kept alive by the entry) and their version counters: addresses alone can be recycled
+        return (self.r, self.t, self.r._version, self.t._version)
+
+    @staticmethod
+    def _same_pose_key(a, b):
+        return a[0] is b[0] and a[1] is b[1] and a[2:] == b[2:]
+
     def get_pose_detached(self, i):
         """w2c of frame i for callers that do not differentiate through the pose (mapping): cached until r / t change
         (in-place updates bump the tensors' version counters), so a mapping iteration does not relaunch the kernel."""
-        key = (self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr())
+        key = self._pose_key()
         cache = self.__dict__.setdefault("_w2c_cache", {})
         hit = cache.get(int(i))
-        if hit is None or hit[0] != key:
+        if hit is None or not self._same_pose_key(hit[0], key):
             with torch.no_grad():
                 w2c = self.get_pose(i).detach().contiguous()
             # the fused optimizer kernels write r / t behind autograd's back and bump the versions themselves
@@ -118,8 +126,7 @@ class PoseTrack:
         _lib.check(rc, "fsgs_pose_adam_step")
         mark_updated([self.r, self.t])
         self.pred_w2c[int(i)] = w2c_next
-        self.__dict__.setdefault("_w2c_cache", {})[int(i)] = (
-            (self.r._version, self.t._version, self.r.data_ptr(), self.t.data_ptr()), w2c_next)
+        self.__dict__.setdefault("_w2c_cache", {})[int(i)] = (self._pose_key(), w2c_next)
 
     def initialize_pose(self, i):
         """constant-velocity prediction for i >= 2 (scene/pose_optimizer.py:498-516)."""
