@@ -210,31 +210,64 @@ __device__ __forceinline__ size_t compact_index(int group, size_t idx) {
        : group == 4 ? (idx / 3) * COMPACT_ROW + 7 + idx % 3
                     : (idx >> 2) * COMPACT_ROW + 10 + (idx & 3);
 }
+// The 14 "small" parameters of a Gaussian (everything but the SH-rest block), as slots of one register file:
+// [0..2] xyz | [3..5] features_dc | [6] opacity | [7..9] scaling | [10..13] rotation
+__device__ __forceinline__ constexpr int small_slot(int group) {
+  return group == 0 ? 0 : group == 1 ? 3 : group == 3 ? 6 : group == 4 ? 7 : 10;
+}
+__device__ __forceinline__ constexpr int small_width(int group) { return group == 3 ? 1 : group == 5 ? 4 : 3; }
 template <int OUT>
 struct GradSink {
   const RenderGradsDev &out;
   const RenderDev &a;
   const AdamDev &ad;
   static constexpr bool ADAM = OUT == OUT_ADAM;
-  __device__ __forceinline__ void put(int group, size_t idx, float g) const {
+  // OUT_ADAM: parameter and both moments of the 14 small parameters, loaded in ONE burst by prefetch() before any
+  // arithmetic.  Load -> update -> store value by value is 14 dependent memory round trips per thread: the compiler
+  // may not move the next value's loads above the previous value's stores (the arrays could alias), and at 3 waves
+  // per SIMD nothing hides them (measured: 36 us of the kernel's 115 at C2 went there).
+  float sp[ADAM ? 14 : 1], sm[ADAM ? 14 : 1], sv[ADAM ? 14 : 1];
+  __device__ __forceinline__ float *param_of(int group) const {
+    const float *cp = group == 0 ? a.xyz : group == 1 ? a.f_dc : group == 3 ? a.opacity : group == 4 ? a.scaling
+                                                                                                        : a.rotation;
+    return const_cast<float *>(cp);
+  }
+  __device__ __forceinline__ void prefetch(int i) {
+    if constexpr (ADAM) {
+#pragma unroll
+      for (int group = 0; group < 6; group++) {
+        if (group == 2) continue;
+        const int w = small_width(group), s0 = small_slot(group);
+        const float *pp = param_of(group);
+#pragma unroll
+        for (int c = 0; c < w; c++) {
+          const size_t idx = (size_t)i * w + c;
+          sp[s0 + c] = pp[idx];
+          sm[s0 + c] = ad.m[group][idx];
+          sv[s0 + c] = ad.v[group][idx];
+        }
+      }
+    }
+  }
+  // component c of Gaussian i in `group` (0 xyz, 1 features_dc, 3 opacity, 4 scaling, 5 rotation)
+  __device__ __forceinline__ void put(int group, int i, int c, float g) {
+    const size_t idx = (size_t)i * small_width(group) + c;
     if (OUT == OUT_COMPACT) {
-      if (group != 1 && group != 2) out.compact[compact_index(group, idx)] = g;
+      if (group != 1) out.compact[compact_index(group, idx)] = g;
       return;
     }
-    float *gp = group == 0 ? out.xyz : group == 1 ? out.f_dc : group == 2 ? out.f_rest : group == 3 ? out.opacity
-              : group == 4 ? out.scaling : out.rotation;
-    if (!ADAM) {
+    if constexpr (!ADAM) {
+      float *gp = group == 0 ? out.xyz : group == 1 ? out.f_dc : group == 3 ? out.opacity : group == 4 ? out.scaling
+                                                                                                        : out.rotation;
       gp[idx] = g;
-      return;
+    } else {
+      const int sl = small_slot(group) + c;
+      float pv = sp[sl], mv = sm[sl], vv = sv[sl];
+      adam_one(pv, g, mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[group], ad.inv_bc2_sqrt[group]);
+      param_of(group)[idx] = pv;
+      ad.m[group][idx] = mv;
+      ad.v[group][idx] = vv;
     }
-    const float *cp = group == 0 ? a.xyz : group == 1 ? a.f_dc : group == 2 ? a.f_rest : group == 3 ? a.opacity
-                    : group == 4 ? a.scaling : a.rotation;
-    float *pp = const_cast<float *>(cp);
-    float pv = pp[idx], mv = ad.m[group][idx], vv = ad.v[group][idx];
-    adam_one(pv, g, mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[group], ad.inv_bc2_sqrt[group]);
-    pp[idx] = pv;
-    ad.m[group][idx] = mv;
-    ad.v[group][idx] = vv;
   }
 };
 
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
                                                              RenderGradsDev out, AdamDev ad) {
-  const GradSink<OUT> sink{out, a, ad};
+  GradSink<OUT> sink{out, a, ad};
   constexpr bool ADAM = OUT == OUT_ADAM;
   __shared__ float red[12][RB / 64];
   __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];  // coefficients in, their gradients out
@@ -289,6 +322,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   const int row = (a.K - 1) * 3;
   const bool stage = (mode & MODE_PARAM_GRAD) && row > 0;
   const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
+  if (i < P) sink.prefetch(i);  // OUT_ADAM: in flight together with the coefficient block below
   if (stage) {
     if (a.deg > 0) stage_in(s_rest, a.f_rest, (size_t)b0 * row, stage_cnt);
     __syncthreads();
@@ -324,16 +358,16 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     }
     if (mode & MODE_PARAM_GRAD) {
       // activations
-      sink.put(4, 3 * (size_t)i, gg.ds[0] * act.scale.x);
-      sink.put(4, 3 * (size_t)i + 1, gg.ds[1] * act.scale.y);
-      sink.put(4, 3 * (size_t)i + 2, gg.ds[2] * act.scale.z);
+      sink.put(4, i, 0, gg.ds[0] * act.scale.x);
+      sink.put(4, i, 1, gg.ds[1] * act.scale.y);
+      sink.put(4, i, 2, gg.ds[2] * act.scale.z);
       float qd = act.q.x * gg.dq[0] + act.q.y * gg.dq[1] + act.q.z * gg.dq[2] + act.q.w * gg.dq[3];
       float inv = 1.0f / act.qnorm;
-      sink.put(5, 4 * (size_t)i, (gg.dq[0] - act.q.x * qd) * inv);
-      sink.put(5, 4 * (size_t)i + 1, (gg.dq[1] - act.q.y * qd) * inv);
-      sink.put(5, 4 * (size_t)i + 2, (gg.dq[2] - act.q.z * qd) * inv);
-      sink.put(5, 4 * (size_t)i + 3, (gg.dq[3] - act.q.w * qd) * inv);
-      sink.put(3, (size_t)i, gg.dop * act.op * (1.0f - act.op));
+      sink.put(5, i, 0, (gg.dq[0] - act.q.x * qd) * inv);
+      sink.put(5, i, 1, (gg.dq[1] - act.q.y * qd) * inv);
+      sink.put(5, i, 2, (gg.dq[2] - act.q.z * qd) * inv);
+      sink.put(5, i, 3, (gg.dq[3] - act.q.w * qd) * inv);
+      sink.put(3, i, 0, gg.dop * act.op * (1.0f - act.op));
       // SH colour
       float vx = xw[0] - a.cam_center[0], vy = xw[1] - a.cam_center[1], vz = xw[2] - a.cam_center[2];
       float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
@@ -348,7 +382,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
       for (int c = 0; c < 3; c++) {
         float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
         if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = gcol;
-        else sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
+        else sink.put(1, i, c, b[0] * gcol);
         for (int k = 1; k < a.K; k++) {
           const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
           if (k < nk) {
@@ -371,14 +405,14 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   } else if (i < P && (mode & MODE_PARAM_GRAD)) {
     // zero gradient: plain mode writes the zeros, Adam mode still decays the moments and applies them
 #pragma unroll
-    for (int c = 0; c < 3; c++) sink.put(4, 3 * (size_t)i + c, 0.f);
+    for (int c = 0; c < 3; c++) sink.put(4, i, c, 0.f);
 #pragma unroll
-    for (int c = 0; c < 4; c++) sink.put(5, 4 * (size_t)i + c, 0.f);
-    sink.put(3, (size_t)i, 0.f);
+    for (int c = 0; c < 4; c++) sink.put(5, i, c, 0.f);
+    sink.put(3, i, 0, 0.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = 0.f;
-      else sink.put(1, 3 * (size_t)i + c, 0.f);
+      else sink.put(1, i, c, 0.f);
     }
     if (OUT != OUT_COMPACT)
       for (int k = 0; k < row; k++) my_rest[k] = 0.f;
@@ -394,9 +428,9 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   if (i < P) {
     if (out.means2D) { out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f; }
     if (OUT != OUT_GRADS || out.xyz) {
-      sink.put(0, 3 * (size_t)i, dxyz[0]);
-      sink.put(0, 3 * (size_t)i + 1, dxyz[1]);
-      sink.put(0, 3 * (size_t)i + 2, dxyz[2]);
+      sink.put(0, i, 0, dxyz[0]);
+      sink.put(0, i, 1, dxyz[1]);
+      sink.put(0, i, 2, dxyz[2]);
     }
   }
   if (mode & MODE_CAM_GRAD) {  // dL/dw2c[r][c] = sum_i g_r [x;1]_c   (scene/pose_optimizer.py:985-987 adjoint)
@@ -425,12 +459,13 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
 __global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc, AdamDev ad) {
   __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
   const RenderGradsDev none{};
-  const GradSink<OUT_ADAM> sink{none, a, ad};
+  GradSink<OUT_ADAM> sink{none, a, ad};
   const int b0 = blockIdx.x * blockDim.x;
   const int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;
   const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
   if (i < P) {
+    sink.prefetch(i);
     const float *g = gc + (size_t)i * COMPACT_ROW;
     const float vx = a.xyz[3 * i] - a.cam_center[0], vy = a.xyz[3 * i + 1] - a.cam_center[1],
                 vz = a.xyz[3 * i + 2] - a.cam_center[2];
@@ -442,16 +477,16 @@ __global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, co
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const float gcol = g[3 + c];
-      sink.put(1, 3 * (size_t)i + c, b[0] * gcol);
+      sink.put(1, i, c, b[0] * gcol);
       for (int k = 1; k < a.K; k++) my_rest[(k - 1) * 3 + c] = k < nk ? b[k] * gcol : 0.f;
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++) sink.put(0, 3 * (size_t)i + c, g[c]);
-    sink.put(3, (size_t)i, g[6]);
+    for (int c = 0; c < 3; c++) sink.put(0, i, c, g[c]);
+    sink.put(3, i, 0, g[6]);
 #pragma unroll
-    for (int c = 0; c < 3; c++) sink.put(4, 3 * (size_t)i + c, g[7 + c]);
+    for (int c = 0; c < 3; c++) sink.put(4, i, c, g[7 + c]);
 #pragma unroll
-    for (int c = 0; c < 4; c++) sink.put(5, 4 * (size_t)i + c, g[10 + c]);
+    for (int c = 0; c < 4; c++) sink.put(5, i, c, g[10 + c]);
   }
   if (row > 0) {
     __syncthreads();
