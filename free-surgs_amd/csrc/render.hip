@@ -81,19 +81,34 @@ struct Activated {
   float qnorm;        // max(||raw||, 1e-12)
   float op;           // sigmoid
 };
-__device__ __forceinline__ Activated activate(const RenderDev &a, int i) {
+// The raw parameters of one Gaussian, loaded without touching them: the per-Gaussian kernels issue these loads BEFORE
+// they stage the SH block through LDS, so that both are in flight together (nothing may be hoisted above the
+// workgroup barrier that follows the staging by the compiler itself).
+struct RawGaussian {
+  float x, y, z, s0, s1, s2, opacity;
+  float4 r;
+};
+__device__ __forceinline__ RawGaussian load_raw(const RenderDev &a, int i) {
+  RawGaussian g;
+  g.x = a.xyz[3 * i]; g.y = a.xyz[3 * i + 1]; g.z = a.xyz[3 * i + 2];
+  g.s0 = a.scaling[3 * i]; g.s1 = a.scaling[3 * i + 1]; g.s2 = a.scaling[3 * i + 2];
+  g.r = make_float4(a.rotation[4 * i], a.rotation[4 * i + 1], a.rotation[4 * i + 2], a.rotation[4 * i + 3]);
+  g.opacity = a.opacity[i];
+  return g;
+}
+__device__ __forceinline__ Activated activate(const RenderDev &a, const RawGaussian &g) {
   Activated o;
-  const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+  const float x = g.x, y = g.y, z = g.z;
   const float *w = a.w2c;  // wave-uniform address -> scalar loads
   o.xc = w[0] * x + w[1] * y + w[2] * z + w[3];
   o.yc = w[4] * x + w[5] * y + w[6] * z + w[7];
   o.zc = w[8] * x + w[9] * y + w[10] * z + w[11];
-  o.scale = make_float3(expf(a.scaling[3 * i]), expf(a.scaling[3 * i + 1]), expf(a.scaling[3 * i + 2]));
-  float4 r = make_float4(a.rotation[4 * i], a.rotation[4 * i + 1], a.rotation[4 * i + 2], a.rotation[4 * i + 3]);
+  o.scale = make_float3(expf(g.s0), expf(g.s1), expf(g.s2));
+  const float4 r = g.r;
   o.qnorm = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);  // F.normalize eps
   float inv = 1.0f / o.qnorm;
   o.q = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
-  o.op = 1.0f / (1.0f + expf(-a.opacity[i]));
+  o.op = 1.0f / (1.0f + expf(-g.opacity));
   return o;
 }
 
@@ -137,6 +152,12 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   const int b0 = blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;  // floats of f_rest per Gaussian
+  RawGaussian raw;
+  float fdc[3] = {0.f, 0.f, 0.f};
+  if (i < P) {  // issued before the staging loads and their barrier
+    raw = load_raw(a, i);
+    fdc[0] = a.f_dc[3 * i]; fdc[1] = a.f_dc[3 * i + 1]; fdc[2] = a.f_dc[3 * i + 2];
+  }
   if (a.deg > 0) {
     size_t cnt = (size_t)min(RB, P - b0) * row;
     stage_in(s_rest, a.f_rest, (size_t)b0 * row, cnt);
@@ -144,10 +165,9 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   }
   if (i >= P) return;
   const float *my_rest = s_rest + (size_t)threadIdx.x * row;
-  Activated act = activate(a, i);
+  Activated act = activate(a, raw);
   // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
-  float dx = a.xyz[3 * i] - a.cam_center[0], dy = a.xyz[3 * i + 1] - a.cam_center[1],
-        dz = a.xyz[3 * i + 2] - a.cam_center[2];
+  float dx = raw.x - a.cam_center[0], dy = raw.y - a.cam_center[1], dz = raw.z - a.cam_center[2];
   float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
   dx *= inv_n; dy *= inv_n; dz *= inv_n;
   float b[16];
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   uint32_t fl = 0;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    float v = b[0] * a.f_dc[3 * i + c];
+    float v = b[0] * fdc[c];
     for (int k = 1; k < nk; k++) v = fmaf(b[k], my_rest[(k - 1) * 3 + c], v);
     v += 0.5f;
     if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
@@ -322,28 +342,42 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   const int row = (a.K - 1) * 3;
   const bool stage = (mode & MODE_PARAM_GRAD) && row > 0;
   const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
-  if (i < P) sink.prefetch(i);  // OUT_ADAM: in flight together with the coefficient block below
+  // every per-Gaussian input is requested here, before the coefficient block is staged and the workgroup meets at
+  // the barrier: one memory round trip for all of it instead of one before and one after the barrier
+  RawGaussian raw{};
+  float acc[kAccStride], dc[6];
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+  int rad = 0;
+  uint32_t fl = 0;
+  if (i < P) {
+    sink.prefetch(i);  // OUT_ADAM: parameters and moments of the small groups
+    raw = load_raw(a, i);
+    rad = radii[i];
+    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kAccStride);
+    const float4 a0 = ap[0], a1 = ap[1];
+    acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+    co = conic_op[i];
+#pragma unroll
+    for (int c = 0; c < 6; c++) dc[c] = dcolors6[(size_t)i * 6 + c];
+    if (mode & MODE_PARAM_GRAD) fl = flags[i];
+  }
   if (stage) {
     if (a.deg > 0) stage_in(s_rest, a.f_rest, (size_t)b0 * row, stage_cnt);
     __syncthreads();
   }
   float *my_rest = s_rest + (size_t)threadIdx.x * row;
   float gxc[3] = {0.f, 0.f, 0.f};  // dL/dx_cam
-  float xw[3] = {0.f, 0.f, 0.f};
+  const float xw[3] = {raw.x, raw.y, raw.z};
   float dxyz[3] = {0.f, 0.f, 0.f};
-  const bool live = i < P && radii[i] > 0;
-  if (i < P) {
-    xw[0] = a.xyz[3 * i]; xw[1] = a.xyz[3 * i + 1]; xw[2] = a.xyz[3 * i + 2];
-  }
+  const bool live = i < P && rad > 0;
   float m2x = 0.f, m2y = 0.f;
   if (live) {
-    Activated act = activate(a, i);
+    Activated act = activate(a, raw);
     float ga[8];
-    unpack_moments(grad_acc + (size_t)i * kAccStride, conic_op[i], ga);
+    unpack_moments(acc, co, ga);
     GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
     m2x = ga[6] * (0.5f * cam.W);
     m2y = ga[7] * (0.5f * cam.H);
-    const float *dc = dcolors6 + (size_t)i * 6;
     const float *V = cam.V;
     float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
     float dzq = dc[3] + 2.f * zq * dc[5];
@@ -376,7 +410,6 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
       sh_basis(a.deg, dx, dy, dz, b);
       sh_basis_grad(a.deg, dx, dy, dz, bx, by, bz);
       const int nk = (a.deg + 1) * (a.deg + 1);
-      const uint32_t fl = flags[i];
       float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -618,6 +651,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   if (state_bytes < SL.total) return FSGS_ERR_STATE;
   const size_t need = (size_t)P * (kAccStride + 6) * sizeof(float);
   if (scratch_bytes < need) return FSGS_ERR_CAPACITY;
+  if (((uintptr_t)scratch) & 15) return FSGS_ERR_INVALID;  // the accumulator rows are read as float4
   CamParams cam = make_cam(cfg);
   for (int ch = 3; ch < 6; ch++) cam.bg[ch] = cfg->bg[ch - 3];
   const int ntiles = cam.gx * cam.gy;

@@ -189,7 +189,8 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
 /* dL_dimage / dL_ddepth_sil [3,H,W] or NULL (= zero).  gs_grad / cam_grad as in render(...):
  * gs_grad routes the mean gradient to xyz, cam_grad reduces dL/dw2c.  param_grads = 0 skips the
  * gradients of features / opacity / scaling / rotation (pose-only backward of the tracking step,
- * observationally equivalent because train.py:220 discards them; SURVEY.md a1 note v). */
+ * observationally equivalent because train.py:220 discards them; SURVEY.md a1 note v).
+ * scratch: >= P * 56 bytes, 16-byte aligned (FSGS_ERR_INVALID otherwise). */
 int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil,
