@@ -325,6 +325,17 @@ __device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const Ada
   }
 }
 
+__global__ void loss_total_kernel(const float *terms, const float *weights, int n, float *total) {
+  float t = 0.f;
+  for (int k = 0; k < n; k++) t = fmaf(terms[k], weights[k], t);
+  total[0] = t;
+}
+struct StepTailDev {  // FsgsStepTail by value
+  float *max_radii2D, *accum, *denom;
+  const float *terms, *weights;
+  int n_terms;
+  float *total;
+};
 template <int OUT>
 __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
                                                              const float *__restrict__ grad_acc,
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
-                                                             RenderGradsDev out, AdamDev ad) {
+                                                             RenderGradsDev out, AdamDev ad, StepTailDev tail) {
   GradSink<OUT> sink{out, a, ad};
   constexpr bool ADAM = OUT == OUT_ADAM;
   __shared__ float red[12][RB / 64];
@@ -360,6 +371,17 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
 #pragma unroll
     for (int c = 0; c < 6; c++) dc[c] = dcolors6[(size_t)i * 6 + c];
     if (mode & MODE_PARAM_GRAD) fl = flags[i];
+  }
+  float st_mr = 0.f, st_acc = 0.f, st_den = 0.f;  // densification statistics of this Gaussian (read-modify-write)
+  if (tail.accum && i < P) {
+    st_mr = tail.max_radii2D[i];
+    st_acc = tail.accum[i];
+    st_den = tail.denom[i];
+  }
+  if (tail.total && blockIdx.x == 0 && threadIdx.x == 0) {  // the iteration's scalar loss (reporting only)
+    float t = 0.f;
+    for (int k = 0; k < tail.n_terms; k++) t = fmaf(tail.terms[k], tail.weights[k], t);
+    tail.total[0] = t;
   }
   if (stage) {
     if (a.deg > 0) stage_in(s_rest, a.f_rest, (size_t)b0 * row, stage_cnt);
@@ -460,6 +482,12 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   }
   if (i < P) {
     if (out.means2D) { out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f; }
+    if (tail.accum && rad > 0) {  // add_densification_stats of train.py:298-303 (the holder's z component is 0)
+      const float gz = 0.f;
+      tail.max_radii2D[i] = fmaxf(st_mr, (float)rad);
+      tail.accum[i] = st_acc + sqrtf(m2x * m2x + m2y * m2y + gz * gz);
+      tail.denom[i] = st_den + 1.0f;
+    }
     if (OUT != OUT_GRADS || out.xyz) {
       sink.put(0, i, 0, dxyz[0]);
       sink.put(0, i, 1, dxyz[1]);
@@ -625,10 +653,18 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
                          int param_grads, const FsgsRenderGrads *grads, const FsgsFusedAdam *adam, float *compact,
-                         void *scratch, size_t scratch_bytes, fsgs_stream_t stream_) {
+                         const FsgsStepTail *tail, void *scratch, size_t scratch_bytes, fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
-  if (P == 0) return FSGS_OK;
+  if (P == 0) {  // an emptied cloud: nothing to differentiate, but the iteration still reports its loss
+    if (tail && tail->loss_total) {
+      if (!tail->loss_terms || !tail->loss_weights || tail->n_terms < 0 || tail->n_terms > 16) return FSGS_ERR_INVALID;
+      hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, stream, tail->loss_terms, tail->loss_weights,
+                         tail->n_terms, tail->loss_total);
+      FSGS_HIP(hipGetLastError());
+    }
+    return FSGS_OK;
+  }
   if (!args_ok(args, P) || !radii || !scratch) return FSGS_ERR_INVALID;
   if (!grads->means2D && !adam && !compact) return FSGS_ERR_INVALID;  // the autograd-facing form always has a holder
   if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
@@ -699,20 +735,32 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);
   RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
                      grads->rotation, grads->means2D, grads->w2c, compact};
+  StepTailDev td{};
+  if (tail) {
+    if (tail->xyz_gradient_accum || tail->denom || tail->max_radii2D) {
+      if (!(tail->xyz_gradient_accum && tail->denom && tail->max_radii2D)) return FSGS_ERR_INVALID;
+      td.max_radii2D = tail->max_radii2D; td.accum = tail->xyz_gradient_accum; td.denom = tail->denom;
+    }
+    if (tail->loss_total) {
+      if (!tail->loss_terms || !tail->loss_weights || tail->n_terms < 0 || tail->n_terms > 16) return FSGS_ERR_INVALID;
+      td.terms = tail->loss_terms; td.weights = tail->loss_weights; td.n_terms = tail->n_terms;
+      td.total = tail->loss_total;
+    }
+  }
   {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     if (adam)
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
     else if (compact)
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
     else
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad);
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
@@ -727,32 +775,34 @@ int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          int param_grads, const FsgsRenderGrads *grads, void *scratch, size_t scratch_bytes,
                          fsgs_stream_t stream) {
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
-                              dL_ddepth_sil, gs_grad, cam_grad, param_grads, grads, nullptr, nullptr, scratch,
+                              dL_ddepth_sil, gs_grad, cam_grad, param_grads, grads, nullptr, nullptr, nullptr, scratch,
                               scratch_bytes, stream);
 }
 
 int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                               const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                               const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
-                              float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
+                              float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
+                              fsgs_stream_t stream) {
   if (!adam) return FSGS_ERR_INVALID;
   FsgsRenderGrads g;
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
-                              dL_ddepth_sil, 1, 0, 1, &g, adam, nullptr, scratch, scratch_bytes, stream);
+                              dL_ddepth_sil, 1, 0, 1, &g, adam, nullptr, tail, scratch, scratch_bytes, stream);
 }
 
 int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                                  const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                                  const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
-                                 float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream) {
+                                 float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
+                                 fsgs_stream_t stream) {
   if (!gcompact) return FSGS_ERR_INVALID;
   FsgsRenderGrads g;
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
-                              dL_ddepth_sil, 1, 0, 1, &g, nullptr, gcompact, scratch, scratch_bytes, stream);
+                              dL_ddepth_sil, 1, 0, 1, &g, nullptr, gcompact, tail, scratch, scratch_bytes, stream);
 }
 
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,

@@ -58,6 +58,12 @@ class FsgsFusedAdam(C.Structure):
                 ("step", C.c_int32 * 6), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
 
+class FsgsStepTail(C.Structure):
+    _fields_ = [("max_radii2D", C.c_void_p), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("loss_terms", C.c_void_p), ("loss_weights", C.c_void_p), ("n_terms", C.c_int32),
+                ("loss_total", C.c_void_p)]
+
+
 class FsgsDensifyGroup(C.Structure):
     _fields_ = [("in_param", C.c_void_p), ("in_exp_avg", C.c_void_p), ("in_exp_avg_sq", C.c_void_p),
                 ("out_param", C.c_void_p), ("out_exp_avg", C.c_void_p), ("out_exp_avg_sq", C.c_void_p),
@@ -118,14 +124,14 @@ _PROTOTYPES = {
     ),
     "fsgs_render_backward_compact": (
         _i,
-        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
-         _sz, _vp],
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp, _vp,
+         C.POINTER(FsgsStepTail), _vp, _sz, _vp],
     ),
     "fsgs_adam_step_compact": (_i, [_i, C.POINTER(FsgsRenderArgs), _vp, C.POINTER(FsgsFusedAdam), _vp]),
     "fsgs_render_backward_adam": (
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp,
-         C.POINTER(FsgsFusedAdam), _vp, _vp, _sz, _vp],
+         C.POINTER(FsgsFusedAdam), _vp, C.POINTER(FsgsStepTail), _vp, _sz, _vp],
     ),
     "fsgs_knn_meandist2": (_i, [_i, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
     "fsgs_photometric_scratch_bytes": (_sz, [_i, _i, _i]),

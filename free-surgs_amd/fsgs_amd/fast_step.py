@@ -207,6 +207,26 @@ class FastStepper:
         g.w2c = None if w2c is None else w2c.data_ptr()
         return g
 
+    def _step_tail(self, b, weights, with_stats):
+        """FsgsStepTail for the per-Gaussian backward launch: the iteration's scalar loss (sum of the loss kernels'
+        terms times `weights`) into a fresh 0-d tensor and, with_stats, the densification statistics of view 0.
+        -> (struct, total tensor, tensors to keep alive until the launch is enqueued)"""
+        pc = self.pc
+        t = _lib.FsgsStepTail()
+        total = torch.empty((), dtype=torch.float32, device=b.terms.device)
+        t.loss_terms, t.loss_weights, t.n_terms, t.loss_total = (b.terms.data_ptr(), weights.data_ptr(),
+                                                                int(b.terms.numel()), total.data_ptr())
+        keep = []
+        if with_stats:
+            v = pc.variables
+            for k in ("max_radii2D", "xyz_gradient_accum", "denom"):
+                if not (v[k].is_contiguous() and v[k].dtype == torch.float32):
+                    v[k] = v[k].contiguous().float()
+            t.max_radii2D, t.xyz_gradient_accum, t.denom = (v["max_radii2D"].data_ptr(),
+                                                           v["xyz_gradient_accum"].data_ptr(), v["denom"].data_ptr())
+            keep = [v["max_radii2D"], v["xyz_gradient_accum"], v["denom"]]
+        return t, total, keep
+
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
     def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None,
                      collect_stats=True):
@@ -222,6 +242,7 @@ class FastStepper:
         H, W = int(pc.cam.image_height), int(pc.cam.image_width)
         n_patches = int(P_CORR * (H // BOX) * (W // BOX))
         total = None
+        stats_done = False  # the statistics of view 0 went into the backward launch itself
         with torch.no_grad(), torch.cuda.device(dev):
             b = self._buffers(pc.num_points, H, W, n_patches, dev)
             stream = _lib.current_stream()
@@ -265,15 +286,17 @@ class FastStepper:
                 if fuse_adam:
                     adam = self._fused_adam_struct()
                     cfg = self._cfg_zeroed()
+                    # statistics and the scalar loss ride in the same launch (no densify_stats / dot kernels)
+                    tail, total, _keep = self._step_tail(b, b.term_w, collect_stats)
                     _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                                              _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
                                                              _lib.ptr(b.d_depth_sil), C.byref(adam),
                                                              _lib.ptr(b.means2D_grad) if collect_stats else None,
-                                                             _lib.ptr(b.bwd_scratch),
+                                                             C.byref(tail), _lib.ptr(b.bwd_scratch),
                                                              b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
                     optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
                     step_optimizer = False  # done
-                    total = torch.dot(b.terms, b.term_w)
+                    stats_done = True
                     radii0 = b.radii
                     break
                 if self.compact and fused_ok:
@@ -285,18 +308,20 @@ class FastStepper:
                     # the densification statistic comes from view 0 only (train.py:260-263): later views skip its terms
                     m2 = b.means2D_grad if (first and collect_stats) else None
                     cfg = self._cfg_zeroed()
+                    tail, loss_k, _keep = self._step_tail(b, b.term_w, first and collect_stats)
                     _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
                                                                 _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
                                                                 _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
                                                                 _lib.ptr(tgt_gc), None if m2 is None else _lib.ptr(m2),
-                                                                _lib.ptr(b.bwd_scratch),
+                                                                C.byref(tail), _lib.ptr(b.bwd_scratch),
                                                                 b.bwd_scratch.numel(), stream),
                                "fsgs_render_backward_compact")
-                    if not first:
+                    if first:
+                        stats_done = collect_stats
+                    else:
                         b.gc.add_(b.gc_view)
                         if collect_stats:
                             pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
-                    loss_k = torch.dot(b.terms, b.term_w)
                     total = loss_k if total is None else total + loss_k
                     if first:
                         radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
@@ -346,7 +371,7 @@ class FastStepper:
                     radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
             if grad_sync is not None:
                 grad_sync(pc)
-            if collect_stats:
+            if collect_stats and not stats_done:
                 optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
                                     pc.variables["xyz_gradient_accum"], pc.variables["denom"])
             self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil}

@@ -212,10 +212,27 @@ typedef struct FsgsFusedAdam {
   int32_t step[6];
   double beta1, beta2, eps;
 } FsgsFusedAdam;
+/* What train.py does between loss.backward() and optimizer.step() on the same iteration, folded into the same
+ * launch (all optional; tail == NULL or NULL members = skipped):
+ *  - add_densification_stats + the max_radii2D update (train.py:298-303, scene/gaussian_model.py:678-681) for the
+ *    Gaussians with radii > 0:  max_radii2D = max(., radius), xyz_gradient_accum += ||dL/dmeans2D (RGB pass)||,
+ *    denom += 1   (what fsgs_densify_stats does from the means2D_grad tensor in a launch of its own);
+ *  - the scalar loss of the iteration, loss_total[0] = sum_k loss_terms[k] * loss_weights[k] (n_terms <= 16 device
+ *    floats each, written by the loss kernels earlier on the stream): reporting only, nothing reads it back. */
+typedef struct FsgsStepTail {
+  float *max_radii2D;         /* [P] */
+  float *xyz_gradient_accum;  /* [P] */
+  float *denom;               /* [P] */
+  const float *loss_terms;
+  const float *loss_weights;
+  int32_t n_terms;
+  float *loss_total;
+} FsgsStepTail;
 int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                               const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                               const float *dL_dimage, const float *dL_ddepth_sil, const FsgsFusedAdam *adam,
-                              float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+                              float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
+                              fsgs_stream_t stream);
 
 /* Compact gradient for steps that sum several views and / or several ranks: gcompact [P,14] =
  * [d xyz (3) | gcol (3) | d opacity | d scaling (3) | d rotation (4)] where gcol is the clamped dL/dcolour.  The
@@ -225,7 +242,8 @@ int fsgs_render_backward_adam(const FsgsRasterCfg *cfg, int P, const FsgsRenderA
 int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                                  const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                                  const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
-                                 float *means2D_grad, void *scratch, size_t scratch_bytes, fsgs_stream_t stream);
+                                 float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
+                                 fsgs_stream_t stream);
 /* Adam step of the six groups from the (summed / all-reduced) compact gradient: the SH outer products are formed
  * on the fly.  Updates args->xyz ... args->rotation and the moments in place; args->w2c is not read. */
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,

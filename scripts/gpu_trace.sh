@@ -4,14 +4,14 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/tr && mkdir -p /tmp/tr
-timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o tr -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline ${TRACE_ARGS:-} > gpurun_out/trace.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o tr -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-tracking ${TRACE_ARGS:-} > gpurun_out/trace.log 2>&1
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# one step = between the last two densify_stats launches (the last kernel of a mapping step)
-idx = [i for i, r in enumerate(rows) if "densify_stats_kernel" in r["Kernel_Name"]]
+# one step = between the last two launches of the per-Gaussian backward (the last kernel of a mapping step)
+idx = [i for i, r in enumerate(rows) if "render_pre_bwd_kernel" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 seg = rows[a + 1:b + 1]
 t0 = int(seg[0]["Start_Timestamp"]); t1 = int(seg[-1]["End_Timestamp"])
