@@ -128,8 +128,8 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--two-pass", action="store_true", help="unfused render (two rasteriser calls)")
     ap.add_argument("--torch-losses", action="store_true", help="plain-PyTorch losses instead of the HIP kernels")
