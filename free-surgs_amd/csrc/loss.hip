@@ -49,9 +49,17 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
 // sums[0] += sum |x-y| ; sums[1] += sum ssim_map          (doubles, zeroed by the caller)
 // maps: [3][C][H][W] = d ssim / d m1, d ssim / d e11, d ssim / d e12   (m1 = G*x, e11 = G*x^2, e12 = G*xy)
 // ---------------------------------------------------------------------------------------------------
+// The mask of a pixel: mask[p] (a multiplicative factor, or 1) times [presence[p] > 0] (the tracking step's
+// "rendered depth > 0" test of train.py:176-178, evaluated here instead of by an elementwise kernel of its own).
+__device__ __forceinline__ float pixel_mask(const float *__restrict__ mask, const float *__restrict__ presence, size_t p) {
+  float m = mask ? mask[p] : 1.0f;
+  if (presence) m = presence[p] > 0.f ? m : 0.f;
+  return m;
+}
 __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
                                                               const float *__restrict__ gt,
                                                               const float *__restrict__ mask,
+                                                              const float *__restrict__ presence,
                                                               float *__restrict__ maps,
                                                               float *__restrict__ partials) {
   __shared__ float sx[SS_IN][SS_IN + 1];
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
     float a = 0.f, b = 0.f;
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) {  // zero padding (F.conv2d padding=5)
       size_t p = (size_t)gy * W + gx;
-      float m = mask ? mask[p] : 1.0f;
+      float m = pixel_mask(mask, presence, p);
       a = ip[p] * m;
       b = gp[p] * m;
     }
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(256) void photometric_finish_kernel(const float *__
 __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W, const float *__restrict__ img,
                                                              const float *__restrict__ gt,
                                                              const float *__restrict__ mask,
+                                                             const float *__restrict__ presence,
                                                              const float *__restrict__ maps,
                                                              const float *__restrict__ upstream, float lambda_dssim,
                                                              float *__restrict__ dimg) {
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
       const int oy = y0 + r - 2 * SS_HALO;
       if (oy < H && gx < W) {
         const size_t pp = (size_t)oy * W + gx, p = ch * plane + pp;
-        const float mk = mask ? mask[pp] : 1.0f;
+        const float mk = pixel_mask(mask, presence, pp);
         const float x = img[p] * mk, y = gt[p] * mk;
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
@@ -410,7 +419,7 @@ size_t fsgs_photometric_scratch_bytes(int C, int H, int W) {
 }
 
 int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const float *gt, const float *mask,
-                                  float lambda_dssim, float *maps, void *sums2, float *out3,
+                                  const float *presence, float lambda_dssim, float *maps, void *sums2, float *out3,
                                   fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3) return FSGS_ERR_INVALID;
@@ -419,7 +428,7 @@ int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const f
   float *partials = (float *)sums2;  // caller-sized by fsgs_photometric_scratch_bytes
   {
     ProfScope ps(PROF_LOSS_RGB_FWD, stream);
-    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, maps, partials);
+    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, presence, maps, partials);
     hipLaunchKernelGGL(photometric_finish_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, (double)C * H * W,
                        lambda_dssim, out3);
   }
@@ -428,15 +437,15 @@ int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const f
 }
 
 int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
-                                   const float *maps, const float *upstream, float lambda_dssim, float *dimg,
+                                   const float *presence, const float *maps, const float *upstream, float lambda_dssim, float *dimg,
                                    fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !dimg) return FSGS_ERR_INVALID;
   dim3 grid((W + ST_W - 1) / ST_W, (H + ST_RS - 1) / ST_RS, C);
   {
     ProfScope ps(PROF_LOSS_RGB_BWD, stream);
-    hipLaunchKernelGGL(photometric_bwd_kernel, grid, dim3(64), 0, stream, C, H, W, img, gt, mask, maps, upstream,
-                       lambda_dssim, dimg);
+    hipLaunchKernelGGL(photometric_bwd_kernel, grid, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,
+                       upstream, lambda_dssim, dimg);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

@@ -256,10 +256,10 @@ class FastStepper:
                 side = self._side_stream(dev)
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
-                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, 0.2,
+                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2,
                                                              _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
                                                              stream), "fsgs_photometric_loss_forward")
-                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None,
+                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None,
                                                               _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
                                                               _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
@@ -418,16 +418,24 @@ class FastStepper:
                     flow_done.record()
                     wd.record_stream(side)
                 args, state, sbytes, cap, nr = self._render_forward(wd, b)
-                # presence mask depth > 0 (heaviside(x, 0) = 1 for x > 0) times the rigid mask (train.py:176-178)
-                mask = torch.heaviside(b.depth_sil[0], b.zero)
-                if rigid_mask is not None:  # None = every pixel rigid (no Sampson mask for this frame)
-                    mask = mask * rigid_mask
+                # mask = [rendered depth > 0] * rigid mask (train.py:176-178): the presence test is evaluated inside the
+                # loss kernels from the depth plane; the rigid mask (None = every pixel rigid) is handed over as floats,
+                # converted once per mask object -- a frame's 50 iterations share it
+                rigid_f = None
+                if rigid_mask is not None:
+                    hit = getattr(self, "_rigid_f", None)
+                    if hit is None or hit[0] is not rigid_mask or hit[1] != rigid_mask._version:
+                        hit = self._rigid_f = (rigid_mask, rigid_mask._version,
+                                               rigid_mask.to(torch.float32).reshape(H, W).contiguous())
+                    rigid_f = hit[2]
+                presence = b.depth_sil[0]
                 gt = self.frames.colors[t]
-                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
-                                                             0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
+                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(rigid_f),
+                                                             _lib.ptr(presence), 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
                                                              _lib.ptr(b.rgb_out), stream), "fsgs_photometric_loss_forward")
-                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(mask),
-                                                              _lib.ptr(b.maps), None, 0.2, _lib.ptr(b.d_image), stream),
+                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(rigid_f),
+                                                              _lib.ptr(presence), _lib.ptr(b.maps), None, 0.2,
+                                                              _lib.ptr(b.d_image), stream),
                            "fsgs_photometric_loss_backward")
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
                 grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)

@@ -37,7 +37,7 @@ class _RgbLoss(torch.autograd.Function):
         sums = torch.empty((int(lib.fsgs_photometric_scratch_bytes(Cc, H, W)),), dtype=torch.uint8, device=x.device)
         out = torch.empty((3,), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = lib.fsgs_photometric_loss_forward(Cc, H, W, _lib.ptr(x), _lib.ptr(y), _lib.ptr(m),
+            rc = lib.fsgs_photometric_loss_forward(Cc, H, W, _lib.ptr(x), _lib.ptr(y), _lib.ptr(m), None,
                                                    float(lambda_dssim), _lib.ptr(maps), _lib.ptr(sums),
                                                    _lib.ptr(out), _lib.current_stream())
         _lib.check(rc, "fsgs_photometric_loss_forward")
@@ -55,7 +55,7 @@ class _RgbLoss(torch.autograd.Function):
         up = _f32c(grad_out).reshape(1)
         dimg = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            rc = lib.fsgs_photometric_loss_backward(Cc, H, W, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ctx.mask),
+            rc = lib.fsgs_photometric_loss_backward(Cc, H, W, _lib.ptr(x), _lib.ptr(y), _lib.ptr(ctx.mask), None,
                                                     _lib.ptr(maps), _lib.ptr(up), ctx.lambda_dssim, _lib.ptr(dimg),
                                                     _lib.current_stream())
         _lib.check(rc, "fsgs_photometric_loss_backward")

@@ -258,17 +258,19 @@ int fsgs_knn_meandist2(int P, const float *points, float *out,
 
 /* ---- photometric loss: 0.8 L1 + 0.2 (1 - SSIM)  (utils/loss_utils.py:41-96) ------------------- */
 
-/* img, gt [C,H,W]; mask [H,W] or NULL (multiplies both images, utils/loss_utils.py:48-50).
+/* img, gt [C,H,W]; mask [H,W] or NULL (multiplies both images, utils/loss_utils.py:48-50); presence [H,W] or NULL:
+ * the mask is additionally zero where presence <= 0 -- the tracking step's `render_dep > 0` factor (train.py:176-178)
+ * read straight from the rendered depth plane instead of being materialised by an elementwise kernel.
  * maps [3,C,H,W] (kept for backward), scratch of fsgs_photometric_scratch_bytes(C,H,W) bytes (per-workgroup
  * partial sums), out3 float[3] = {loss, L1, SSIM} on the DEVICE (no host sync). */
 size_t fsgs_photometric_scratch_bytes(int C, int H, int W);
 int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const float *gt, const float *mask,
-                                  float lambda_dssim, float *maps, void *scratch, float *out3,
+                                  const float *presence, float lambda_dssim, float *maps, void *scratch, float *out3,
                                   fsgs_stream_t stream);
 /* dimg [C,H,W] = upstream[0] * dloss/dimg; upstream is a DEVICE scalar (NULL = 1). */
 int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
-                                   const float *maps, const float *upstream, float lambda_dssim, float *dimg,
-                                   fsgs_stream_t stream);
+                                   const float *presence, const float *maps, const float *upstream, float lambda_dssim,
+                                   float *dimg, fsgs_stream_t stream);
 
 /* ---- Pearson depth losses (utils/loss_utils.py:98-127) ------------------------------------------- */
 
