@@ -316,3 +316,59 @@ def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
     kinds = {e for e, _ in log}
     print("schedule:", " ".join("%s@%d" % (e, p) for e, p in log))
     assert {"M1", "M2", "D"} <= kinds and len({p for _, p in log}) >= 3, log  # the schedule did change P
+
+
+@pytest.mark.parametrize("own_streams", [True, False])
+def test_trainer_thread_and_viewer_thread_share_the_library(own_streams):
+    """train.py runs the viewer's render_custom from a second Python thread while the training thread iterates
+    (train.py:150,227-231; tracking iterations are not even locked): one thread steps a model through the step
+    driver, another renders a different model in a loop -- on their own streams, and (what the reference does) both on the default
+    stream, where the two threads' launches interleave.  The stepped model must end
+    where a solitary run ends, and every concurrent render must equal the solitary render bit for bit."""
+    import threading
+
+    from fsgs_amd.render import render
+
+    torch.manual_seed(0)
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    solo, busy = _world(seed=2, P=5000), _world(seed=2, P=5000)
+    view = _world(seed=9, P=3000)
+    with torch.no_grad():
+        want = render(view[1], 1, view[0], gs_grad=False, cam_grad=False)["render"].clone()
+    fs_solo = FastStepper(solo[0], solo[1], solo[2])
+    for it in range(12):
+        fs_solo.mapping_step([it % 3], corners=corners)
+    torch.cuda.synchronize()
+    stop, bad, count = threading.Event(), [], [0]
+
+    def viewer():
+        s = torch.cuda.Stream() if own_streams else torch.cuda.current_stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            while not stop.is_set():
+                img = render(view[1], 1, view[0], gs_grad=False, cam_grad=False)["render"]
+                if not torch.equal(img, want):
+                    bad.append(count[0])
+                count[0] += 1
+        s.synchronize()
+
+    def trainer():
+        s = torch.cuda.Stream() if own_streams else torch.cuda.current_stream()
+        with torch.cuda.stream(s):
+            fs = FastStepper(busy[0], busy[1], busy[2])
+            for it in range(12):
+                fs.mapping_step([it % 3], corners=corners)
+        s.synchronize()
+
+    tv, tt = threading.Thread(target=viewer), threading.Thread(target=trainer)
+    tv.start()
+    tt.start()
+    tt.join()
+    stop.set()
+    tv.join()
+    torch.cuda.synchronize()
+    assert count[0] >= 3 and not bad, (count[0], bad[:5])
+    for k in PARAM_NAMES:
+        a, b = solo[0].params[k].detach(), busy[0].params[k].detach()
+        assert ((a - b).abs() > 1e-5 * a.abs().max()).float().mean().item() < 2e-3, k
+    assert torch.equal(solo[0].variables["denom"], busy[0].variables["denom"])
