@@ -75,9 +75,27 @@ class FastStepper:
         self.cfg_key = None
         self.lib = _lib.load()
         self.last = {}
+        self._check_frames()
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
         self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
+
+    def _check_frames(self):
+        """the per-frame targets are handed to the kernels as raw pointers: float32, contiguous, on the cloud's device,
+        [3,H,W] colours and [H,W] mono-depths of one size (checked once here, not per step)"""
+        dev = self.pc.params["_xyz"].device
+        hw = None
+        for name, seq, lead in (("colors", self.frames.colors, (3,)), ("monodeps", self.frames.monodeps, ())):
+            for i, t in enumerate(seq or []):
+                if t is None:
+                    continue
+                ok = (torch.is_tensor(t) and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev
+                      and t.dim() == len(lead) + 2 and tuple(t.shape[:len(lead)]) == lead)
+                if ok and hw is None:
+                    hw = tuple(t.shape[-2:])
+                if not ok or tuple(t.shape[-2:]) != hw:
+                    raise ValueError("frames.%s[%d] must be a contiguous float32 tensor of shape %s on %s" % (
+                        name, i, lead + (hw or ("H", "W")), dev))
 
     # ---- helpers -----------------------------------------------------------------------------------------
     def _buffers(self, P, H, W, n_patches, dev):
@@ -112,6 +130,11 @@ class FastStepper:
     def _render_forward(self, w2c, b):
         pc, lib = self.pc, self.lib
         p = pc.params
+        for name in PARAM_NAMES:  # raw pointers go to the kernels: no silent reinterpretation of other layouts
+            t_ = p[name]
+            if t_.dtype != torch.float32 or not t_.is_contiguous() or not t_.is_cuda:
+                raise ValueError("%s must be a contiguous float32 device tensor for the step driver (got %s, %s)"
+                                 % (name, t_.dtype, "contiguous" if t_.is_contiguous() else "strided"))
         cfg = self._cfg()
         P, H, W = pc.num_points, cfg.image_height, cfg.image_width
         dev = p["_xyz"].device
