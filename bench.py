@@ -211,6 +211,8 @@ def main():
         one_step(it)
     barrier()
     dominant = "blend_bwd"
+    if use_fast:
+        stepper.pairs_total = stepper.forward_calls = 0
     _lib.profile_enable(None if args.profile_all else [dominant, "blend_fwd"], stride=max(1, args.profile_stride))
     t0 = time.perf_counter()
     for it in range(args.steps):
@@ -228,6 +230,8 @@ def main():
     from fsgs_amd import rasterizer
 
     R = int(getattr(rasterizer, "last_num_rendered", 0) or 0)
+    if use_fast and stepper.forward_calls:  # the cameras differ: mean pair count over the timed steps, like the mean time
+        R = int(round(stepper.pairs_total / stepper.forward_calls))
     C = 6 if fused else 3
     ms_total, launches = prof.get(dominant, (0.0, 0))
     roofline = None

@@ -76,6 +76,7 @@ class FastStepper:
         self.lib = _lib.load()
         self.last = {}
         self._check_frames()
+        self.pairs_total = self.forward_calls = 0
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
         self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
@@ -163,6 +164,8 @@ class FastStepper:
         else:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
         rasterizer.last_num_rendered = int(nr.value)
+        self.pairs_total += int(nr.value)  # (bench.py reports the mean pair count of the steps it timed)
+        self.forward_calls += 1
         return args, state, sz[0], cap, int(nr.value)
 
     def _fused_adam_struct(self):
