@@ -259,7 +259,7 @@ def main():
                     issue_s = wi * 4.0 / (256 * 4 * 2.4e9)
                     roofline["valu"] = {"wave_insts": wi, "issue_bound_ms": issue_s * 1e3,
                                         "frac_of_issue_bound": issue_s / avg_s,
-                                        "source": "SQ_INSTS_VALU, profiles/r01_v10_sq_counters.txt"}
+                                        "source": "SQ_INSTS_VALU, profiles/r01_v11_sq_counters.txt"}
         except Exception:
             pass
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
