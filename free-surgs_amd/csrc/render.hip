@@ -657,6 +657,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
   if (P == 0) {  // an emptied cloud: nothing to differentiate, but the iteration still reports its loss
+    if (cam_grad && grads->w2c) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));  // dL/dw2c = 0
     if (tail && tail->loss_total) {
       if (!tail->loss_terms || !tail->loss_weights || tail->n_terms < 0 || tail->n_terms > 16) return FSGS_ERR_INVALID;
       hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, stream, tail->loss_terms, tail->loss_weights,
@@ -797,7 +798,7 @@ int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRend
                                  const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
                                  float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
                                  fsgs_stream_t stream) {
-  if (!gcompact) return FSGS_ERR_INVALID;
+  if (!gcompact && P > 0) return FSGS_ERR_INVALID;  // (an emptied cloud has an empty, i.e. NULL, gradient tensor)
   FsgsRenderGrads g;
   std::memset(&g, 0, sizeof(g));
   g.means2D = means2D_grad;

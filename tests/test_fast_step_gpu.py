@@ -209,7 +209,8 @@ def test_four_million_gaussians_step_and_track():
     assert torch.isfinite(total) and torch.isfinite(poses.r).all() and not torch.equal(poses.r, r0)
 
 
-def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
+@pytest.mark.parametrize("sched", [7, 8, 9])
+def test_long_randomised_schedule_step_driver_tracks_the_autograd_path(sched):
     """ONE FastStepper (and one set of cached buffers, capacities and streams) driven through a seeded schedule of
     everything the harness does to it -- 1- and 2-view mapping iterations, tracking iterations with and without a
     rigid mask, densify + prune (P changes, up and down), opacity reset, SH degree steps -- each event replayed from
@@ -222,7 +223,7 @@ def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
     for w in (a, b):
         w[0].active_sh_degree = 0
     fs = FastStepper(b[0], b[1], b[2])
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(sched)
 
     def copy_state():  # b := a (parameters, Adam moments and step counts, statistics, SH degree, poses)
         checkpoint.restore_gaussians(b[0], checkpoint.capture_gaussians(a[0]))
@@ -279,8 +280,9 @@ def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
                 for _ in range(2):
                     l = fs.tracking_step(t, targets, rigid) if fast else tracking_step(w[0], w[1], w[2], t, targets, rigid)
                 res.append(l[0].item())
-            assert abs(res[0] - res[1]) <= 1e-4 * abs(res[0]), (step, ev, log)
-            assert torch.allclose(a[1].r, b[1].r, rtol=0, atol=2e-4) and torch.allclose(a[1].t, b[1].t, rtol=0, atol=2e-4)
+            assert abs(res[0] - res[1]) <= 1e-4 * abs(res[0]), (step, ev, P, res, log)
+            assert torch.allclose(a[1].r, b[1].r, rtol=0, atol=2e-4) and torch.allclose(a[1].t, b[1].t, rtol=0, atol=2e-4), (
+                step, ev, P, (a[1].r - b[1].r).abs().max().item(), (a[1].t - b[1].t).abs().max().item())
         elif ev == "D":
             # make the statistics select something: ~10 % above the gradient threshold, a few huge / transparent ones
             with torch.no_grad():
@@ -295,7 +297,7 @@ def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
             a[0].densify_and_prune(2e-4, 0.05, 20 if step % 2 else None)
             torch.manual_seed(100 + step)
             b[0].densify_and_prune_device(2e-4, 0.05, 20 if step % 2 else None)
-            assert a[0].num_points == b[0].num_points and a[0].num_points != P, (step, log)
+            assert a[0].num_points == b[0].num_points and (a[0].num_points != P or P == 0), (step, log)
             for k in PARAM_NAMES:
                 if k == "_xyz":  # the children's positions: batched GEMM there, FMAs here (tests/test_optim_gpu.py)
                     assert a[0].num_points == 0 or (
@@ -315,7 +317,7 @@ def test_long_randomised_schedule_step_driver_tracks_the_autograd_path():
             b[0].oneupSHdegree()
     kinds = {e for e, _ in log}
     print("schedule:", " ".join("%s@%d" % (e, p) for e, p in log))
-    assert {"M1", "M2", "D"} <= kinds and len({p for _, p in log}) >= 3, log  # the schedule did change P
+    assert {"M1", "M2"} <= kinds and (("D" not in kinds) or len({p for _, p in log}) >= 2), log
 
 
 @pytest.mark.parametrize("own_streams", [True, False])
