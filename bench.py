@@ -156,6 +156,10 @@ def main():
     from fsgs_amd.trainer import mapping_step
 
     rank, world, local = fdist.init_from_env()
+    if args.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: one rank per GPU comes from the launcher "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N); running %d rank(s)\n"
+                         % (args.gpus, world, world))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
