@@ -374,3 +374,50 @@ def test_trainer_thread_and_viewer_thread_share_the_library(own_streams):
         a, b = solo[0].params[k].detach(), busy[0].params[k].detach()
         assert ((a - b).abs() > 1e-5 * a.abs().max()).float().mean().item() < 2e-3, k
     assert torch.equal(solo[0].variables["denom"], busy[0].variables["denom"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_image_sizes_step_driver_equals_autograd(seed):
+    """one mapping and two tracking iterations at image sizes that are multiples of nothing (tile 16, loss tile 32,
+    streaming segment 64, Pearson patch 128) and cloud sizes off the 256-Gaussian workgroup: step driver against the
+    torch-autograd statement of the same iteration."""
+    from fsgs_amd import optim, trainer
+    from fsgs_amd.flow import FlowTargets
+
+    rng = np.random.default_rng(900 + seed)
+    W, H = int(rng.integers(131, 420)), int(rng.integers(130, 300))
+    P = int(rng.integers(300, 6000))
+    a, b = _world(seed=seed, W=W, H=H, P=P), _world(seed=seed, W=W, H=H, P=P)
+    assert a[0].num_points == b[0].num_points
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    views = [1] if seed % 2 else [2, 0]
+    fs = FastStepper(b[0], b[1], b[2])
+    loss, first = 0, None
+    for ts in views:
+        pkg = trainer.render(a[1], ts, a[0], gs_grad=True, cam_grad=False)
+        loss = loss + trainer.mapping_loss(pkg, a[2].colors[ts], a[2].monodeps[ts], corners)
+        first = first or pkg
+    loss.backward()
+    optim.densify_stats(first["radii"], first["viewspace_points"].grad, a[0].variables["max_radii2D"],
+                        a[0].variables["xyz_gradient_accum"], a[0].variables["denom"])
+    a[0].optimizer.step()
+    a[0].optimizer.zero_grad(set_to_none=True)
+    lb = fs.mapping_step(views, corners=corners)
+    assert abs(loss.item() - lb.item()) <= 1e-5 * abs(loss.item()), (W, H, P)
+    for k in PARAM_NAMES:
+        pa, pb = a[0].params[k].detach(), b[0].params[k].detach()
+        assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 4e-3, (k, W, H, P)
+    assert torch.equal(a[0].variables["denom"], b[0].variables["denom"])
+    assert torch.equal(a[0].variables["max_radii2D"], b[0].variables["max_radii2D"])
+    # tracking from the (slightly different) post-step clouds: losses agree to the clouds' agreement
+    rigid = torch.rand(H, W, device=DEV) > 0.1
+    depth_prev = torch.rand(1, H, W, device=DEV) + 0.5
+    out = []
+    for w, fast in ((a, False), (b, True)):
+        w[1].initialize_tracking_optimizer(50)
+        targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), w[2].K, w[2].flows_fw[0], rigid)
+        for _ in range(2):
+            l = fs.tracking_step(1, targets, rigid) if fast else tracking_step(w[0], w[1], w[2], 1, targets, rigid)
+        out.append(l[0].item())
+    assert abs(out[0] - out[1]) <= 2e-3 * abs(out[0]), (W, H, P, out)
+    assert torch.allclose(a[1].r, b[1].r, rtol=0, atol=4e-4) and torch.allclose(a[1].t, b[1].t, rtol=0, atol=4e-4)
