@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native Free-SurGS hot path.
 
-    python bench.py [--gpus N --steps K --warmup W]           (N = 1)
+    python bench.py [--gpus N --steps K --warmup W]           (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Metric (BASELINE.json): train iterations/s at 1280x1024 with 300k Gaussians (config C2).
@@ -125,6 +125,29 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
                       "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one rank
+    per GPU (RCCL), pass rank 0's JSON line through, return the launcher's exit code.  Non-zero when fewer than N GPUs
+    are visible (FSGS_DIST_ONE_GPU=1: every rank on device 0 over gloo -- the smoke test of this code path on a
+    one-GPU box, never a measurement)."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if os.environ.get("FSGS_DIST_ONE_GPU") != "1" and have < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, have))
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,15 +175,23 @@ def main():
                          "launch costs two event packets of dispatch gap); 1 = every launch.  Keep it coprime with the 8-frame cycle")
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        sys.exit(self_launch(args.gpus))  # no launcher around us: start the N ranks ourselves
+
     from fsgs_amd import _lib, dist as fdist
     from fsgs_amd.trainer import mapping_step
 
     rank, world, local = fdist.init_from_env()
-    if args.gpus != world and rank == 0:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: one rank per GPU comes from the launcher "
-                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N); running %d rank(s)\n"
-                         % (args.gpus, world, world))
+    if args.gpus != world:
+        # a launcher started a different number of ranks than --gpus names: refuse, a mislabelled line is worse than none
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback on the product path)"
+    if world > 1 and os.environ.get("FSGS_DIST_ONE_GPU") != "1" and torch.cuda.device_count() < world:
+        if rank == 0:
+            sys.stderr.write("bench.py: %d ranks but only %d GPU(s) visible\n" % (world, torch.cuda.device_count()))
+        sys.exit(3)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.manual_seed(0)
@@ -304,7 +335,9 @@ def main():
         comm_ms = (time.perf_counter() - tc) / 10 * 1e3
         comm = {"what": "all-reduce(SUM) of the %s gradient, alone" % ("compact [P,14]" if use_fast else "[59 P]"),
                 "bytes": nfloat * 4, "ms": comm_ms,
-                "algbw_GBps": nfloat * 4 / (comm_ms * 1e-3) / 1e9}
+                "algbw_GBps": nfloat * 4 / (comm_ms * 1e-3) / 1e9,
+                "backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                "devices": torch.cuda.device_count(), "one_gpu_smoke": os.environ.get("FSGS_DIST_ONE_GPU") == "1"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

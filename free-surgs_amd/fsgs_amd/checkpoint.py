@@ -17,12 +17,23 @@ from .model import PARAM_NAMES, OptimizationParams
 _CAPTURE_ORDER = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
 
 
+# what torch.optim.Adam's step() reads from a param_group besides lr / betas / eps.  Adam.load_state_dict adopts the
+# saved groups verbatim (its __setstate__ only defaults amsgrad / maximize / foreach / capturable / differentiable /
+# fused), so a group saved without weight_decay raises KeyError at the first step of whoever restored it.
+_TORCH_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                                  differentiable=False, fused=None, decoupled_weight_decay=False)
+
+
 def portable_state_dict(optimizer):
-    """optimizer.state_dict() with every `step` as the 0-d float32 CPU tensor torch.optim.Adam keeps."""
+    """optimizer.state_dict() as torch.optim.Adam would have written it: every `step` a 0-d float32 CPU tensor and
+    every param_group carrying the keys torch's Adam reads (FusedAdam's own defaults are lr / betas / eps only)."""
     sd = optimizer.state_dict()
     for st in sd["state"].values():
         if "step" in st and not torch.is_tensor(st["step"]):
             st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+    for g in sd["param_groups"]:
+        for k, v in _TORCH_ADAM_GROUP_DEFAULTS.items():
+            g.setdefault(k, v)
     return sd
 
 

@@ -61,6 +61,12 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom)
     lib = _lib.load()
     P = int(radii.shape[0])
     g = viewspace_grad.detach().contiguous()
+    # raw pointers cross the C ABI: the kernel reads int32 radii and fp32 [P,3] / [P,1] / [P] rows, nothing else
+    assert radii.dtype == torch.int32 and radii.is_contiguous() and radii.is_cuda, "radii: contiguous int32 on the GPU"
+    for name, t, n in (("viewspace_grad", g, 3 * P), ("max_radii2D", max_radii2D, P),
+                       ("xyz_gradient_accum", xyz_gradient_accum, P), ("denom", denom, P)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n and t.device == radii.device, \
+            "%s: contiguous fp32 with %d elements on %s" % (name, n, radii.device)
     with torch.cuda.device(radii.device):
         rc = lib.fsgs_densify_stats(P, _lib.ptr(radii), _lib.ptr(g), _lib.ptr(max_radii2D),
                                     _lib.ptr(xyz_gradient_accum), _lib.ptr(denom), _lib.current_stream())

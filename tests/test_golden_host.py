@@ -360,3 +360,39 @@ def test_checkpoint_round_trip_and_bad_tuples(tmp_path):
         checkpoint.restore_gaussians(pc2, (1, 2, 3))
     with pytest.raises(ValueError):
         checkpoint.restore_poses(poses2, (None, torch.zeros(4, 3), torch.zeros(3, 3), np.zeros((3, 4, 4)), np.eye(3)))
+
+
+def test_fused_adam_checkpoint_steps_under_torch_adam():
+    """A capture taken from the HIP FusedAdam (param_groups hold lr / betas / eps only, `step` is a python int) must be
+    steppable by torch.optim.Adam after restore(fused=False): torch adopts the saved groups verbatim and reads
+    weight_decay, amsgrad, maximize ... from them."""
+    from fsgs_amd import checkpoint, optim
+
+    torch.manual_seed(5)
+    P = 9
+    mk = lambda: model.GaussianCloud({"_xyz": torch.randn(P, 3), "_features_dc": torch.randn(P, 1, 3),
+                                      "_features_rest": torch.randn(P, 15, 3), "_opacity": torch.randn(P, 1),
+                                      "_scaling": torch.randn(P, 3), "_rotation": torch.randn(P, 4)}, device="cpu")
+    pc = mk()
+    pc.training_setup(fused=True)
+    assert isinstance(pc.optimizer, optim.FusedAdam)
+    for g in pc.optimizer.param_groups:  # the state FusedAdam.step() would have left (the kernel itself needs the GPU)
+        p = g["params"][0]
+        pc.optimizer.state[p] = {"step": 3, "exp_avg": torch.randn_like(p), "exp_avg_sq": torch.rand_like(p)}
+    cap = checkpoint.capture_gaussians(pc)
+    for g in cap[10]["param_groups"]:
+        assert g["weight_decay"] == 0 and g["amsgrad"] is False and g["maximize"] is False
+    pc2 = mk()
+    checkpoint.restore_gaussians(pc2, cap, fused=False)
+    assert isinstance(pc2.optimizer, torch.optim.Adam)
+    before = {k: pc2.params[k].detach().clone() for k in pc2.params}
+    for k in pc2.params:
+        pc2.params[k].grad = torch.randn_like(pc2.params[k])
+    pc2.optimizer.step()  # KeyError: 'weight_decay' before the fix
+    assert all(not torch.equal(before[k], pc2.params[k]) for k in pc2.params)
+    st = pc2.optimizer.state[pc2.params["_xyz"]]
+    assert float(st["step"]) == 4.0
+    # and the reverse direction keeps working: torch's groups (with the extra keys) load into FusedAdam
+    pc3 = mk()
+    checkpoint.restore_gaussians(pc3, checkpoint.capture_gaussians(pc2), fused=True)
+    assert isinstance(pc3.optimizer, optim.FusedAdam)
