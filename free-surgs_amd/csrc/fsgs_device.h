@@ -128,36 +128,53 @@ __device__ __forceinline__ int wave_max(int v) {
 // here may be re-associated or contracted differently between kernels (explicit *_rn ops).
 // power = -1/2 (A dx^2 + C dy^2) - B dx dy; skip power > 0; alpha = min(.99, o e^power);
 // skip alpha < 1/255.
-struct SplatEval {
-  float dx, dy, G, alpha;
+// The blend kernels stage every record once per batch, so the exponent's coefficients are pre-scaled there:
+// (a, b, c) = -log2(e) (A/2, B, C/2), p = a dx^2 + c dy^2 + b dx dy = power * log2(e), and e^power is ONE v_exp_f32
+// (2^p) with no scaling multiply in front of it -- 6 VALU for p instead of 8; `power > 0` is `p > 0`.
+struct SplatCoef {
+  float a, b, c;
 };
-__device__ __forceinline__ bool splat_alpha(float gx, float gy, float A, float B, float Cc, float o, float px,
+__device__ __forceinline__ SplatCoef splat_coef(float A, float B, float Cc) {
+  const float L2E = 1.44269504088896340736f;
+  SplatCoef k;
+  k.a = __fmul_rn(-0.5f * L2E, A);
+  k.b = __fmul_rn(-L2E, B);
+  k.c = __fmul_rn(-0.5f * L2E, Cc);
+  return k;
+}
+struct SplatEval {
+  float dx, dy;
+  float a;      // o * e^power, NOT clamped (the backward's dL/dG = o dL/dalpha rides on it: w o = a dL/dalpha)
+  float alpha;  // min(0.99, a)
+};
+__device__ __forceinline__ float splat_exponent(float ca, float cb, float cc, float dx, float dy) {
+  const float q = __fmaf_rn(__fmul_rn(cc, dy), dy, __fmul_rn(__fmul_rn(ca, dx), dx));
+  return __fmaf_rn(__fmul_rn(cb, dx), dy, q);
+}
+__device__ __forceinline__ bool splat_alpha(float gx, float gy, float ca, float cb, float cc, float o, float px,
                                             float py, SplatEval &e) {
   e.dx = __fsub_rn(gx, px);
   e.dy = __fsub_rn(gy, py);
-  float q = __fmaf_rn(__fmul_rn(Cc, e.dy), e.dy, __fmul_rn(__fmul_rn(A, e.dx), e.dx));
-  float power = __fmaf_rn(__fmul_rn(-B, e.dx), e.dy, __fmul_rn(-0.5f, q));
-  if (power > 0.0f) return false;
-  e.G = __expf(power);
-  e.alpha = fminf(0.99f, __fmul_rn(o, e.G));
-  return e.alpha >= (1.0f / 255.0f);
+  const float p = splat_exponent(ca, cb, cc, e.dx, e.dy);
+  if (p > 0.0f) return false;
+  e.a = __fmul_rn(o, __builtin_amdgcn_exp2f(p));
+  e.alpha = fminf(0.99f, e.a);
+  return e.a >= (1.0f / 255.0f);
 }
 
-// Branch-free variant for the backward replay: returns G and alpha forced to ZERO when the pair does not
-// contribute (power > 0, alpha < 1/255 or `live` false).  The skip decision is bit-identical to splat_alpha;
-// with alpha = G = 0 every gradient term of the pair vanishes and T / gB stay untouched, so no divergent
-// branch (v_cmp -> exec round trips cost ~10 cycles each on gfx950) is needed around the arithmetic.
-__device__ __forceinline__ bool splat_alpha_masked(float gx, float gy, float A, float B, float Cc, float o, float px,
+// Branch-free variant for the backward replay: a and alpha are forced to ZERO when the pair does not contribute
+// (power > 0, alpha < 1/255 or `live` false).  The skip decision is bit-identical to splat_alpha; with
+// alpha = a = 0 every gradient term of the pair vanishes and T / gB stay untouched, so no divergent branch is
+// needed around the arithmetic (one v_cndmask: alpha = min(0.99, a) follows from the masked a).
+__device__ __forceinline__ bool splat_alpha_masked(float gx, float gy, float ca, float cb, float cc, float o, float px,
                                                    float py, bool live, SplatEval &e) {
   e.dx = __fsub_rn(gx, px);
   e.dy = __fsub_rn(gy, py);
-  float q = __fmaf_rn(__fmul_rn(Cc, e.dy), e.dy, __fmul_rn(__fmul_rn(A, e.dx), e.dx));
-  float power = __fmaf_rn(__fmul_rn(-B, e.dx), e.dy, __fmul_rn(-0.5f, q));
-  float G = __expf(fminf(power, 0.0f));
-  float alpha = fminf(0.99f, __fmul_rn(o, G));
-  const bool ok = live && !(power > 0.0f) && alpha >= (1.0f / 255.0f);
-  e.G = ok ? G : 0.0f;
-  e.alpha = ok ? alpha : 0.0f;
+  const float p = splat_exponent(ca, cb, cc, e.dx, e.dy);
+  const float a = __fmul_rn(o, __builtin_amdgcn_exp2f(fminf(p, 0.0f)));
+  const bool ok = live && !(p > 0.0f) && a >= (1.0f / 255.0f);
+  e.a = ok ? a : 0.0f;
+  e.alpha = fminf(0.99f, e.a);
   return ok;
 }
 

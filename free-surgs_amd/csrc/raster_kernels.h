@@ -644,8 +644,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
     // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
     __syncthreads();  // previous batch fully consumed (single-wave workgroup: this is just a wait)
-    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, gco.x, gco.y);
-    rec[lane * REC4 + 1] = make_float4(gco.z, gco.w, gz, 0.f);
+    const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
+    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, kf.a, kf.b);
+    rec[lane * REC4 + 1] = make_float4(kf.c, gco.w, gz, 0.f);
     {
       float c6[8];
 #pragma unroll
@@ -704,23 +705,24 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // R7  backward blend
 // ------------------------------------------------------------------------------------------------
-// grad_acc layout per Gaussian (floats), with w = G dL/dalpha summed over every pixel the Gaussian blended into and
+// grad_acc layout per Gaussian (floats), with w = o G dL/dalpha summed over every pixel the Gaussian blended into and
 // d = mean2D - pixel:  [0,1] sum w d_x, w d_y | [2,3,4] sum w d_x^2, w d_x d_y, w d_y^2 | [5] sum w (= dL/dopacity)
 // | [6,7] as [0,1] for the RGB channels only (SPLIT).  8 floats stride; dcolors go straight to the output tensor.
 constexpr int kAccStride = 8;
 
-// Moments -> the gradients of SURVEY.md A.4: dL/dmean2D (pixel units) = -o (A m0 + B m1, C m1 + B m0),
-// dL/dconic (A,B,C) = -o (m2/2, m3, m4/2), dL/dopacity = m5; [6,7] the RGB-only dL/dmean2D.
+// Moments -> the gradients of SURVEY.md A.4.  The moments arrive multiplied by the opacity (w o = a dL/dalpha, see
+// SplatEval): dL/dmean2D (pixel units) = -(A m0 + B m1, C m1 + B m0), dL/dconic (A,B,C) = -(m2/2, m3, m4/2),
+// dL/dopacity = m5 / o; [6,7] the RGB-only dL/dmean2D.
 __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float ga[8]) {
-  const float A = co.x, B = co.y, Cc = co.z, no = -co.w;
-  ga[0] = no * fmaf(A, m[0], B * m[1]);
-  ga[1] = no * fmaf(Cc, m[1], B * m[0]);
-  ga[2] = 0.5f * no * m[2];
-  ga[3] = no * m[3];
-  ga[4] = 0.5f * no * m[4];
-  ga[5] = m[5];
-  ga[6] = no * fmaf(A, m[6], B * m[7]);
-  ga[7] = no * fmaf(Cc, m[7], B * m[6]);
+  const float A = co.x, B = co.y, Cc = co.z;
+  ga[0] = -fmaf(A, m[0], B * m[1]);
+  ga[1] = -fmaf(Cc, m[1], B * m[0]);
+  ga[2] = -0.5f * m[2];
+  ga[3] = -m[3];
+  ga[4] = -0.5f * m[4];
+  ga[5] = m[5] != 0.f ? m[5] / co.w : 0.f;  // a Gaussian that blended anywhere has o > 1/255
+  ga[6] = -fmaf(A, m[6], B * m[7]);
+  ga[7] = -fmaf(Cc, m[7], B * m[6]);
 }
 
 // SPLIT (fused 6-channel pass): channels 0..2 are the RGB pass, 3..5 the depth/silhouette pass of the
@@ -762,8 +764,9 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   // which is UPSTREAM's T (c - accum_rec) written with the absolute colour behind.  Only the scalar
   // gB = sum_ch g_ch B_ch is needed, so one register per pixel replaces accum_rec / last_color / last_alpha:
   //   gc = sum_ch g_ch c_ch;  dL/dalpha = T gc - (gB + T_final bg.g) / (1 - alpha);  gB += alpha T gc.
-  // tb[k] = T_final * (bg . dL/dpixel); gBr / tbr: the same restricted to the RGB channels (SPLIT).
-  float px[4], py[4], T[4], tb[4], tbr[4], gB[4], gBr[4], g[4][CG];
+  // gB[k] starts at T_final * (bg . dL/dpixel), so the sum in the bracket is one register; gBr: the same restricted
+  // to the RGB channels (SPLIT).
+  float px[4], py[4], T[4], gB[4], gBr[4], g[4][CG];
   int last[4], qlast[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -784,10 +787,8 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       bgdot = fmaf(cam.bg[ch], g[k][ch], bgdot);
       if (SPLIT && ch < 3) bgdot_rgb = fmaf(cam.bg[ch], g[k][ch], bgdot_rgb);
     }
-    tb[k] = Tfin * bgdot;
-    tbr[k] = Tfin * bgdot_rgb;
-    gB[k] = 0.0f;
-    gBr[k] = 0.0f;
+    gB[k] = Tfin * bgdot;  // the background term rides in the running sum from the start
+    gBr[k] = Tfin * bgdot_rgb;
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
@@ -809,12 +810,13 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     __syncthreads();  // records of the previous batch fully consumed
-    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, gco.x, gco.y);
+    const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
+    rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, kf.a, kf.b);
     {
       float c6[8];
 #pragma unroll
       for (int ch = 0; ch < 8; ch++) c6[ch] = ch < C ? gcol[ch < C ? ch : 0] : 0.f;
-      rec[lane * REC4 + 1] = make_float4(gco.z, gco.w, c6[0], c6[1]);
+      rec[lane * REC4 + 1] = make_float4(kf.c, gco.w, c6[0], c6[1]);
       rec[lane * REC4 + 2] = make_float4(c6[2], c6[3], c6[4], c6[5]);
     }
     __syncthreads();
@@ -854,11 +856,11 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
             if (SPLIT && ch == 2) gc_rgb = gc;
             if (!POSE_ONLY) s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
           }
-          const float dL_dalpha = fmaf(T[k], gc, -inv1ma * (gB[k] + tb[k]));
+          const float dL_dalpha = fmaf(T[k], gc, -inv1ma * gB[k]);
           gB[k] = fmaf(wgt, gc, gB[k]);
-          // moments of w = G dL/dalpha over the pixels; the conic / opacity factors are per-Gaussian constants
+          // moments of w = o G dL/dalpha over the pixels; the conic / opacity factors are per-Gaussian constants
           // and are applied once, after the tile and atomic sums, by unpack_moments()
-          const float w = e.G * dL_dalpha;
+          const float w = e.a * dL_dalpha;
           const float wdx = w * e.dx, wdy = w * e.dy;
           if (!POSE_ONLY) s[5] += w;
           s[0] += wdx;
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
           s[3] = fmaf(wdx, e.dy, s[3]);
           s[4] = fmaf(wdy, e.dy, s[4]);
           if (SPLIT) {
-            const float wr = e.G * fmaf(T[k], gc_rgb, -inv1ma * (gBr[k] + tbr[k]));
+            const float wr = e.a * fmaf(T[k], gc_rgb, -inv1ma * gBr[k]);
             gBr[k] = fmaf(wgt, gc_rgb, gBr[k]);
             s[6] = fmaf(wr, e.dx, s[6]);
             s[7] = fmaf(wr, e.dy, s[7]);
