@@ -81,6 +81,9 @@ class Oracle:
         L.oracle_knn_meandist2.argtypes = [C.c_int, rp, rp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_set_thresholds.argtypes = [C.c_double] * 7
+        L.oracle_set_thresholds.restype = None
+        L.oracle_reset_thresholds.restype = None
 
     # -- helpers -------------------------------------------------------------
     def set_threads(self, n):
@@ -163,6 +166,79 @@ class Oracle:
             self._p(out["means3D"]), self._p(out["scales"]), self._p(out["rotations"]),
         )
         return {k: v[:P] for k, v in out.items()}
+
+    # -- flip attribution ------------------------------------------------------------
+    # How far the decision thresholds are moved (relative unless noted).  The HIP path and this restatement evaluate
+    # the same comparisons in fp32 on differently rounded operands.  What dominates is the projected centre: it is
+    # good to an ulp (6e-5 px between 512 and 1024 px, 1.2e-4 px beyond), and alpha = o exp(-d' S^-1 d / 2) moves by
+    # |S^-1 d| per pixel of centre shift -- up to ~5.5 / px three sigma out on the smallest footprint the +0.3
+    # dilation allows (sigma = 0.55 px): ~3e-4 relative.  (The exponent's own rounding, pre-scaled coefficients +
+    # 1-ulp exp2 vs expf, is ~3e-6.)  T inherits the same error through its factors (1 - alpha).  Radius: 3 sigma is
+    # good to a few 1e-7; tile rects truncate (centre -+ radius) / 16.
+    FLIP_MARGINS = dict(alpha_min=4e-4, alpha_max_abs=4e-4, T_min=5e-4, power_abs=1e-5, radius=1e-6,
+                        near_plane_abs=1e-6, rect_abs=2e-4)
+
+    def set_thresholds(self, sign=0):
+        """sign = 0: the published constants; +1 / -1: every decision moved by FLIP_MARGINS towards 'contributes more'
+        / 'contributes less'.  Process-global in the C library: always restore with sign = 0."""
+        m = self.FLIP_MARGINS
+        s = float(sign)
+        self.lib.oracle_set_thresholds(
+            (1.0 / 255.0) * (1.0 - s * m["alpha_min"]), 0.99 + s * m["alpha_max_abs"], 1e-4 * (1.0 - s * m["T_min"]),
+            s * m["power_abs"], 1.0 + s * m["radius"], 0.2 - s * m["near_plane_abs"], s * m["rect_abs"])
+        if sign == 0:
+            self.lib.oracle_reset_thresholds()
+
+    _f64 = None
+
+    def flip_amplitudes(self, cam, means3D, colors, opacities, scales, rotations, dL_dcolor, roundoff=True):
+        """How much every output element can move when a near-tie decision flips: run the rasteriser (forward +
+        backward) with the nominal thresholds, then with every threshold moved a hair one way, then the other way
+        (FLIP_MARGINS).  amp[name] = elementwise max |difference| between any two of the three runs: zero wherever no
+        decision is within rounding distance of its threshold -- there two correct fp32 implementations must agree to
+        the parity tolerance with no exceptions; elsewhere they may differ by about amp.  -> (amp, nominal run) with
+        amp: image [C,H,W], depth [H,W], final_T [H*W], the six gradients [P,k] (float64) and boolean masks
+        radii [P], n_contrib [H*W]; nominal run = (image, depth, radii, grads, state).
+        roundoff=True adds, element by element, this fp32 restatement's OWN distance from its fp64 build on the same
+        inputs: a per-Gaussian gradient is a sum over thousands of pixels with cancellation (a needle covering the
+        whole image: 2e-4 of the norm between the f32 and f64 oracles), and one correct fp32 implementation cannot be
+        asked to sit closer to another than that one sits to the truth.  That distance is ONE sample of the summation
+        noise and the other implementation (atomics in arrival order) contributes its own, so it enters twice."""
+        runs = []
+        try:
+            for sign in (0, +1, -1):
+                self.set_thresholds(sign)
+                img, dep, radii, st = self.raster_forward(cam, means3D, colors, opacities, scales, rotations)
+                g = self.raster_backward(st, dL_dcolor)
+                runs.append((img, dep, radii, g, st, st.final_T().copy(), st.n_contrib().copy()))
+        finally:
+            self.set_thresholds(0)
+        nom = runs[0]
+        P = len(nom[2])
+
+        def amp(get):
+            a = [np.asarray(get(r), np.float64) for r in runs]
+            return np.maximum(np.maximum(np.abs(a[1] - a[0]), np.abs(a[2] - a[0])), np.abs(a[1] - a[2]))
+
+        out = {
+            "image": amp(lambda r: r[0]), "depth": amp(lambda r: r[1]), "final_T": amp(lambda r: r[5]),
+            "radii": (runs[1][2] != nom[2]) | (runs[2][2] != nom[2]),
+            "n_contrib": (runs[1][6] != nom[6]) | (runs[2][6] != nom[6]),
+        }
+        for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
+            out[k] = amp(lambda r, k=k: r[3][k].reshape(P, -1))
+        if roundoff and self.dtype != np.float64:
+            if Oracle._f64 is None:
+                Oracle._f64 = Oracle(np.float64)
+            o64 = Oracle._f64
+            i64, d64, r64, s64 = o64.raster_forward(cam, means3D, colors, opacities, scales, rotations)
+            g64 = o64.raster_backward(s64, dL_dcolor)
+            out["image"] += 2 * np.abs(i64 - nom[0])
+            out["depth"] += 2 * np.abs(d64 - nom[1])
+            out["final_T"] += 2 * np.abs(s64.final_T() - nom[5])
+            for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
+                out[k] += 2 * np.abs(g64[k].reshape(P, -1) - np.asarray(nom[3][k], np.float64).reshape(P, -1))
+        return out, nom[:5]
 
     # -- KNN ---------------------------------------------------------------------
     def knn_meandist2(self, pts):

@@ -133,6 +133,33 @@ static int pair_cmp(const void *a, const void *b) {
   return 0;
 }
 
+/* ---- the DECISION thresholds of the algorithm ---------------------------------
+ * Nominal values are the published constants.  The parity tests move them by a hair in both
+ * directions (oracle_set_thresholds) to find every output element whose value hinges on a comparison that two
+ * correct fp32 implementations may resolve differently ("flip attribution", tests/util.py): an element that is
+ * identical under the loose and the tight setting cannot owe a HIP-vs-oracle difference to such a flip.
+ * Process-global, like the thread count: the tests set, run, and restore. */
+typedef struct {
+  double alpha_min;     /* 1/255: skip below                       */
+  double alpha_max;     /* 0.99: clamp                             */
+  double T_min;         /* 1e-4: stop when T (1 - alpha) < T_min   */
+  double power_max;     /* 0: skip when power > power_max          */
+  double radius_scale;  /* 1: radius = ceil(3 sigma * scale)       */
+  double near_plane;    /* 0.2: cull t_z <= near_plane             */
+  double rect_shift;    /* 0: added to (p -+ radius) before the division by the tile size */
+} OracleThresholds;
+static OracleThresholds g_thr = {1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0};
+void oracle_set_thresholds(double alpha_min, double alpha_max, double T_min, double power_max, double radius_scale,
+                           double near_plane, double rect_shift) {
+  g_thr.alpha_min = alpha_min; g_thr.alpha_max = alpha_max; g_thr.T_min = T_min; g_thr.power_max = power_max;
+  g_thr.radius_scale = radius_scale; g_thr.near_plane = near_plane; g_thr.rect_shift = rect_shift;
+}
+void oracle_reset_thresholds(void) { oracle_set_thresholds(1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0); }
+#define THR_ALPHA_MIN ((real)g_thr.alpha_min)
+#define THR_ALPHA_MAX ((real)g_thr.alpha_max)
+#define THR_T_MIN ((real)g_thr.T_min)
+#define THR_POWER_MAX ((real)g_thr.power_max)
+
 /* ---- API ----------------------------------------------------------------- */
 
 void oracle_set_threads(int n) {
@@ -203,7 +230,7 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
     st->radii[i] = 0; st->tiles[i] = 0;
     real t[3];
     xform4x3(V, means3D + 3 * i, t);
-    if (t[2] <= (real)0.2) continue;                       /* near-plane cull */
+    if (t[2] <= (real)g_thr.near_plane) continue;          /* near-plane cull (0.2) */
     real h[4];
     xform4x4(PM, means3D + 3 * i, h);
     real pw = 1 / (h[3] + (real)0.0000001);
@@ -239,11 +266,13 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
     real mid = (real)0.5 * (a + c);
     real sq = R_SQRT(R_FMAX((real)0.1, mid * mid - det));
     real lam = R_FMAX(mid + sq, mid - sq);
-    int radius = (int)R_CEIL(3 * R_SQRT(lam));
+    int radius = g_thr.radius_scale == 1.0 ? (int)R_CEIL(3 * R_SQRT(lam))
+                                           : (int)ceil(3 * sqrt((double)lam) * g_thr.radius_scale);
     real px = ((ndcx + 1) * W - 1) * (real)0.5;
     real py = ((ndcy + 1) * H - 1) * (real)0.5;
-    int minx = (int)((px - radius) / TILE), miny = (int)((py - radius) / TILE);
-    int maxx = (int)((px + radius + TILE - 1) / TILE), maxy = (int)((py + radius + TILE - 1) / TILE);
+    const real rs = (real)g_thr.rect_shift; /* 0 nominally; widens (> 0) or narrows (< 0) the rect by a hair */
+    int minx = (int)((px - radius - rs) / TILE), miny = (int)((py - radius - rs) / TILE);
+    int maxx = (int)((px + radius + TILE - 1 + rs) / TILE), maxy = (int)((py + radius + TILE - 1 + rs) / TILE);
     minx = minx < 0 ? 0 : (minx > gx ? gx : minx); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
     miny = miny < 0 ? 0 : (miny > gy ? gy : miny); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
     int area = (maxx - minx) * (maxy - miny);
@@ -299,11 +328,11 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
           real dx = st->xy[2*g] - (real)px_, dy = st->xy[2*g+1] - (real)py_;
           const real *co = st->conic_op + 4 * g;
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-          if (power > 0) continue;
-          real alpha = R_FMIN((real)0.99, co[3] * R_EXP(power));
-          if (alpha < (real)(1.0 / 255.0)) continue;
+          if (power > THR_POWER_MAX) continue;
+          real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * R_EXP(power));
+          if (alpha < THR_ALPHA_MIN) continue;
           real test_T = T * (1 - alpha);
-          if (test_T < (real)0.0001) break;
+          if (test_T < THR_T_MIN) break;
           real w = alpha * T;
           for (int ch = 0; ch < C; ch++) Cacc[ch] += colors[(size_t)g * C + ch] * w;
           D += st->depth[g] * w;
@@ -365,10 +394,10 @@ void oracle_raster_backward(const OracleCfg *cfg, const OracleState *st, const r
           real dx = st->xy[2*id] - (real)px_, dy = st->xy[2*id+1] - (real)py_;
           const real *co = st->conic_op + 4 * id;
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-          if (power > 0) continue;
+          if (power > THR_POWER_MAX) continue;
           real G = R_EXP(power);
-          real alpha = R_FMIN((real)0.99, co[3] * G);
-          if (alpha < (real)(1.0 / 255.0)) continue;
+          real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * G);
+          if (alpha < THR_ALPHA_MIN) continue;
           T = T / (1 - alpha);
           real wgt = alpha * T, dL_dalpha = 0;
           for (int ch = 0; ch < C; ch++) {

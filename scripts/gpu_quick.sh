@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 tag=${1:-quick}; shift || true
 sel=${*:-tests/test_raster_gpu.py tests/test_render_gpu.py tests/test_fast_step_gpu.py}
-python -m pytest $sel -m gpu -x -q --tb=short 2>&1 | tail -15 > gpurun_out/${tag}_pytest.log
+python -m pytest $sel -m gpu -x -q --tb=short 2>&1 | tail -40 > gpurun_out/${tag}_pytest.log
 python bench.py --steps 60 --warmup 10 --profile-all --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/${tag}_bench.json
 python - "$tag" <<'PY'
 import json, sys

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from fsgs_amd import synth
-from tests.util import assert_close_flip_aware, c1_poses, sh0_colors, to_camera_frame
+from tests.util import assert_close_attributed, assert_close_flip_aware, c1_poses, sh0_colors, to_camera_frame
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -41,29 +41,39 @@ def _run_hip(cam, xyz, col, op, sc, rot, dL):
 
 
 def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False):
-    """HIP vs the fp32 oracle on the same inputs.  Tolerances per SURVEY.md s8d (1e-4; radii and
-    visibility exact) with the flip budget explained in tests/util.py:assert_close_flip_aware;
-    strict=True (small scenes) allows no outliers at all."""
+    """HIP vs the fp32 oracle on the same inputs.  Tolerances per SURVEY.md s8d (1e-4 of the tensor's inf-norm; radii
+    and visibility exact).  Every element beyond the tolerance needs a WITNESS: the oracle's own value there must move
+    by a comparable amount when the decision thresholds shift by a rounding-sized hair
+    (tests/util.py:assert_close_attributed, oracle Oracle.flip_amplitudes); strict=True (small scenes) allows no
+    outliers at all.  -> (num_rendered, {tensor: (outliers, fragile elements)})."""
     H, W = cam["image_height"], cam["image_width"]
     Cc = np.asarray(col).shape[1]
     P = len(xyz)
     dL = (np.random.default_rng(seed).uniform(-1, 1, (Cc, H, W)) / (Cc * H * W)).astype(np.float32)
     img, dep, radii, g = _run_hip(cam, xyz, col, op, sc, rot, dL)
-    oi, od, orad, st = oracle.raster_forward(cam, xyz, col, op, sc, rot)
-    og = oracle.raster_backward(st, dL)
-    kw = dict(max_frac=0.0, min_budget=0) if strict else {}
-    mism = int((radii != orad).sum())  # ceil(3 sigma) may flip on an exact boundary
-    assert mism <= (0 if strict else max(1, P // 10000)), "radii mismatch on %d of %d" % (mism, P)
+    if strict:
+        oi, od, orad, st = oracle.raster_forward(cam, xyz, col, op, sc, rot)
+        og = oracle.raster_backward(st, dL)
+        amp = None
+    else:
+        amp, (oi, od, orad, og, st) = oracle.flip_amplitudes(cam, xyz, col, op, sc, rot, dL)
+    zero = lambda a: np.zeros(np.shape(a))
+    # ceil(3 sigma) may land on the other side of an integer: only where the oracle's own radius moves with the hair
+    rogue_r = (radii != orad) & ~(amp["radii"] if amp is not None else np.zeros(P, bool))
+    assert not rogue_r.any(), "radii differ at %s without a ceil() near-tie" % np.nonzero(rogue_r)[0][:8].tolist()
     assert int(((radii > 0) != (orad > 0)).sum()) == 0, "visibility filter differs"
-    assert_close_flip_aware(img, oi, "image", floor=1.0, **kw)  # colours live in [0,1]: abs 1e-4 of full scale
-    assert_close_flip_aware(dep, od, "depth", floor=1.0, **kw)
+    stats = {}
+    # colours live in [0,1]: abs 1e-4 of full scale
+    stats["image"] = assert_close_attributed(img, oi, zero(oi) if strict else amp["image"], "image", floor=1.0)
+    stats["depth"] = assert_close_attributed(dep, od, zero(od) if strict else amp["depth"], "depth", floor=1.0)
     # an analytically-zero gradient (d/drotation of an isotropic Gaussian) is cancellation round-off of
     # terms of size ~|dL/dscale|*|scale| in both implementations: floor each norm at 1e-3 of the largest
     # gradient tensor, i.e. an absolute tolerance of 1e-7 of that for such tensors
     floor = 1e-3 * max(float(np.abs(v).max()) for v in og.values())
     for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
-        assert_close_flip_aware(g[k].reshape(P, -1), og[k].reshape(P, -1), k, floor=floor, rows=P, **kw)
-    return st.num_rendered
+        a, b = g[k].reshape(P, -1), og[k].reshape(P, -1)
+        stats[k] = assert_close_attributed(a, b, zero(b) if strict else amp[k], k, floor=floor)
+    return st.num_rendered, stats
 
 
 def test_c1_init_scene_eight_poses(oracle32):
@@ -76,8 +86,10 @@ def test_c1_init_scene_eight_poses(oracle32):
     col = sh0_colors(sc)
     for i, w2c in enumerate(c1_poses()):
         xyz = to_camera_frame(sc["_xyz"], w2c)
-        R = _compare(oracle32, cam, xyz, col, o.reshape(-1), s, r, seed=i)
+        R, stats = _compare(oracle32, cam, xyz, col, o.reshape(-1), s, r, seed=i)
         assert R > P
+        # the witnessed outliers are a handful, and so is the set of fragile pixels the allowance applies to
+        assert stats["image"][0] <= 40 and stats["depth"][0] <= 40, stats
 
 
 def test_trained_like_scene_with_view_matrix(oracle32):
@@ -98,6 +110,57 @@ def test_six_channel_fused_layout(oracle32):
     xyz, col, op, s, r = synth.random_small_scene(P, cam, seed=4, channels=6)
     _compare(oracle32, cam, xyz.astype(np.float32), col.astype(np.float32), op, s.astype(np.float32),
              r.astype(np.float32), seed=3, strict=True)
+
+
+@pytest.mark.parametrize("scene", ["c1_init", "trained"])
+def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
+    """The image state kept for the backward: final_T per pixel, and n_contrib.  The HIP lists are the oracle's lists
+    minus unreachable pairs, so the POSITION of the last contributor differs while the Gaussian it names must not:
+    both are mapped to Gaussian ids through their own sorted lists and compared exactly -- except at pixels whose
+    last contributor moves when the oracle's thresholds shift by a rounding-sized hair (Oracle.flip_amplitudes)."""
+    from fsgs_amd import rasterizer
+    from fsgs_amd.trainer import settings_from_cam
+
+    oracle32.set_threads(0)
+    if scene == "c1_init":
+        W, H, P = 640, 512, 20000
+        sc = synth.init_scene(W, H, P, seed=0)
+        xyz = to_camera_frame(sc["_xyz"], c1_poses()[1])
+        col = sh0_colors(sc)
+    else:
+        W, H, P = 320, 256, 6000
+        sc = synth.trained_like_scene(W, H, P, seed=2, base_ratio=0.02)
+        xyz = sc["_xyz"]
+        col = np.random.default_rng(5).uniform(0, 1, (P, 3)).astype(np.float32)
+    cam = synth.make_camera(W, H)
+    s, r, o = synth.activate(sc)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=DEV)
+    cfg = rasterizer.make_cfg(settings_from_cam(cam, DEV), 3)
+    img, depth, radii, st = rasterizer.raster_forward(cfg, T(xyz), T(col), T(o.reshape(-1)), T(s), T(r))
+    v = {k: t.cpu().numpy() for k, t in rasterizer.state_views(st).items()}
+    dL = np.zeros((3, H, W), np.float32)
+    amp, (oi, od, orad, og, ost) = oracle32.flip_amplitudes(cam, xyz, col, o.reshape(-1), s, r, dL)
+    gx = (W + 15) // 16
+    yy, xx = np.mgrid[0:H, 0:W]
+    tile = (yy // 16) * gx + xx // 16
+
+    def last_id(ranges, plist, n_contrib):
+        n = n_contrib.reshape(H, W).astype(np.int64)
+        pos = ranges[tile, 0].astype(np.int64) + n - 1
+        return np.where(n > 0, plist[np.clip(pos, 0, len(plist) - 1)].astype(np.int64), -1)
+
+    mine = last_id(v["ranges"], v["point_list"], v["n_contrib"])
+    ref = last_id(ost.ranges(), ost.point_list(), ost.n_contrib())
+    fragile = amp["n_contrib"].reshape(H, W)
+    rogue = (mine != ref) & ~fragile
+    assert not rogue.any(), "last contributor differs at %d pixels without a near-tie, e.g. %s" % (
+        int(rogue.sum()), np.argwhere(rogue)[:4].tolist())
+    assert int((mine != ref).sum()) <= 60 and int(fragile.sum()) < 0.005 * H * W, (int((mine != ref).sum()), int(fragile.sum()))
+    # positions: never beyond the tile's list, and a pixel nobody reached has none
+    lens = (v["ranges"][:, 1] - v["ranges"][:, 0])[tile]
+    assert (v["n_contrib"].reshape(H, W) <= lens).all()
+    assert_close_attributed(v["final_T"].reshape(-1), ost.final_T().reshape(-1), amp["final_T"].reshape(-1), "final_T",
+                            floor=1.0)
 
 
 def test_edge_cases_empty_ragged_and_culled(oracle32):
@@ -281,7 +344,7 @@ def test_large_grid_and_screen_filling_gaussians(oracle32):
     rot = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
     op = np.concatenate([rng.uniform(0.05, 0.9, n_small), [0.3, 0.02, 0.6]]).astype(np.float32)
     col = rng.uniform(0, 1, (n_small + n_big, 3)).astype(np.float32)
-    R = _compare(oracle32, cam, xyz, col, op, s, rot)
+    R, _ = _compare(oracle32, cam, xyz, col, op, s, rot)
     assert R > 9360  # the big ones alone reach most tiles
 
 
@@ -296,7 +359,7 @@ def test_pair_capacity_overflow_is_reported_and_retried(oracle32):
     key = (400, 160, 128)
     rasterizer._capacity[key] = 32  # far below the real R
     try:
-        R = _compare(oracle32, cam, xyz, col, op, scl, rot)
+        R, _ = _compare(oracle32, cam, xyz, col, op, scl, rot)
         assert R > 32
         assert rasterizer._capacity[key] >= R
     finally:
