@@ -589,6 +589,14 @@ int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
   return FSGS_OK;
 }
 
+int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, size_t offsets[9]) {
+  if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !offsets) return FSGS_ERR_INVALID;
+  StateLayout L = state_layout(P, width, height, max_pairs, 6);
+  offsets[0] = L.xy; offsets[1] = L.conic_op; offsets[2] = L.depth; offsets[3] = L.ranges;
+  offsets[4] = L.final_T; offsets[5] = L.n_contrib; offsets[6] = L.plist; offsets[7] = L.colors; offsets[8] = L.flags;
+  return FSGS_OK;
+}
+
 int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
                         float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
                         size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream_) {

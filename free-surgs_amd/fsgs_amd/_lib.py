@@ -112,6 +112,7 @@ _PROTOTYPES = {
          _vp, _vp, _sz, _vp],
     ),
     "fsgs_render_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
+    "fsgs_render_state_layout": (_i, [_i, _i, _i, _i64, C.POINTER(_sz)]),
     "fsgs_render_forward": (
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,

@@ -177,6 +177,11 @@ typedef struct FsgsRenderGrads {
 } FsgsRenderGrads;
 
 int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *state_bytes, size_t *scratch_bytes);
+/* Byte offsets inside the fused render's `state` (tests / debugging / a viewer): [0..6] as fsgs_raster_state_layout,
+ * [7] per-Gaussian colours float[P,6] = (r, g, b | z, 1, z^2): clamp_min(eval_sh + 0.5, 0) and the depth / silhouette
+ * pseudo-colours (scene/gaussian_model.py:260-275,316-320), [8] flag word uint32[P] (bit c = colour channel c
+ * was clamped at 0). */
+int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, size_t offsets[9]);
 
 /* out_image [3,H,W] = the RGB pass; out_depth_sil [3,H,W] = (depth, silhouette, depth^2) pass of
  * gaussian_renderer/__init__.py:68-73; radii [P].  cfg->channels is ignored; cfg->bg[0..2] is used for

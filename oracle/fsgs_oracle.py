@@ -81,9 +81,14 @@ class Oracle:
         L.oracle_knn_meandist2.argtypes = [C.c_int, rp, rp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_max_threads.restype = C.c_int
-        L.oracle_set_thresholds.argtypes = [C.c_double] * 7
+        L.oracle_set_thresholds.argtypes = [C.c_double] * 8
         L.oracle_set_thresholds.restype = None
         L.oracle_reset_thresholds.restype = None
+        L.oracle_set_depth_shift.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.oracle_set_depth_shift.restype = None
+        self._order_h = None
+        self._shift_buf = None
+        self.last_state = None
 
     # -- helpers -------------------------------------------------------------
     def set_threads(self, n):
@@ -145,6 +150,7 @@ class Oracle:
             self._p(rotations), self._p(out_color), self._p(out_depth), radii.ctypes.data_as(C.POINTER(C.c_int)),
         )
         state = OracleState(self, st, cfg, (means3D, colors, opacities, scales, rotations))
+        self.last_state = state
         return out_color, out_depth, radii[:P], state
 
     def raster_backward(self, state, dL_dcolor):
@@ -169,25 +175,85 @@ class Oracle:
 
     # -- flip attribution ------------------------------------------------------------
     # How far the decision thresholds are moved (relative unless noted).  The HIP path and this restatement evaluate
-    # the same comparisons in fp32 on differently rounded operands.  What dominates is the projected centre: it is
-    # good to an ulp (6e-5 px between 512 and 1024 px, 1.2e-4 px beyond), and alpha = o exp(-d' S^-1 d / 2) moves by
-    # |S^-1 d| per pixel of centre shift -- up to ~5.5 / px three sigma out on the smallest footprint the +0.3
-    # dilation allows (sigma = 0.55 px): ~3e-4 relative.  (The exponent's own rounding, pre-scaled coefficients +
-    # 1-ulp exp2 vs expf, is ~3e-6.)  T inherits the same error through its factors (1 - alpha).  Radius: 3 sigma is
-    # good to a few 1e-7; tile rects truncate (centre -+ radius) / 16.
-    FLIP_MARGINS = dict(alpha_min=4e-4, alpha_max_abs=4e-4, T_min=5e-4, power_abs=1e-5, radius=1e-6,
-                        near_plane_abs=1e-6, rect_abs=2e-4)
+    # the same comparisons in fp32 on differently rounded operands:
+    #  * the projected centre is good to an ulp (6e-5 px between 512 and 1024 px), and alpha = o exp(-d' S^-1 d / 2)
+    #    moves by |S^-1 d| per pixel of centre shift -- ~5.5 / px three sigma out on the smallest footprint the +0.3
+    #    dilation allows (sigma = 0.55 px): ~3e-4 relative -> alpha_min;
+    #  * the exponent is a sum of three products that cancel on elongated (correlated) footprints; each carries its
+    #    own rounding (~2 ulp, evaluated in a different order on either side: plain vs pre-scaled fma chain), so the
+    #    exponent is good to ~5e-7 * (|A dx^2| / 2 + |C dy^2| / 2 + |B dx dy|) absolute, which is the same relative
+    #    amount in alpha -> alpha_cond (per evaluated pair, on top of alpha_min);
+    #  * T inherits both through its factors (1 - alpha); 3 sigma is good to a few 1e-7; tile rects truncate
+    #    (centre -+ radius) / 16.
+    # All far inside "alpha within 1e-5 of 1/255" (2.5e-3 relative) / "T within 1e-7 of 1e-4" (1e-3 relative).
+    #  * the depth ORDER inside a tile: view-space depths computed by different glue differ in the last bit or two,
+    #    so list neighbours within depth_ulps ulp may be sorted either way (find_order_ties).
+    FLIP_MARGINS = dict(alpha_min=4e-4, alpha_cond=5e-7, alpha_max_abs=4e-4, T_min=5e-4, power_abs=1e-5, radius=1e-6,
+                        near_plane_abs=1e-6, rect_abs=2e-4, depth_ulps=3.0)
+
+    def find_order_ties(self, state=None):
+        """Per-Gaussian signs h in {-1, 0, +1} such that shifting every sort key by h * (a few ulp), one way and then
+        the other, swaps every pair of NEIGHBOURS in a tile's depth-sorted list whose depths are within
+        FLIP_MARGINS['depth_ulps'] ulp: h = +1 / -1 on the two members of such a pair (pairs are rare and almost always
+        disjoint; a Gaussian in two pairs keeps its first sign).  Stored for set_thresholds(+-1); None = no ties."""
+        st = state or self.last_state
+        self._order_h = None
+        if st is None:
+            return None
+        pl = st.point_list().astype(np.int64)
+        if len(pl) < 2:
+            return None
+        d = np.asarray(st.depth(), np.float64)[pl]
+        rg = st.ranges()
+        tile_of = np.zeros(len(pl), np.int64)  # which tile a list position belongs to
+        starts = rg[:, 0][rg[:, 1] > rg[:, 0]]
+        tile_of[starts] = 1
+        tile_of = np.cumsum(tile_of)
+        near = (tile_of[1:] == tile_of[:-1]) & (np.abs(d[1:] - d[:-1]) <= self.FLIP_MARGINS["depth_ulps"] * 1.2e-7 * np.abs(d[:-1])) \
+            & (pl[1:] != pl[:-1])
+        idx = np.nonzero(near)[0]
+        if len(idx) == 0:
+            return None
+        h = np.zeros(st.P, np.float64)
+        for k in idx:
+            i, j = pl[k], pl[k + 1]  # i sorts in front of j: moving i back and j forward swaps them
+            if h[i] == 0 and h[j] == 0:
+                h[i], h[j] = +1.0, -1.0
+            elif h[i] == 0:
+                h[i] = -h[j]
+            elif h[j] == 0:
+                h[j] = -h[i]
+        self._order_h = h
+        return h
 
     def set_thresholds(self, sign=0):
         """sign = 0: the published constants; +1 / -1: every decision moved by FLIP_MARGINS towards 'contributes more'
         / 'contributes less'.  Process-global in the C library: always restore with sign = 0."""
         m = self.FLIP_MARGINS
         s = float(sign)
-        self.lib.oracle_set_thresholds(
-            (1.0 / 255.0) * (1.0 - s * m["alpha_min"]), 0.99 + s * m["alpha_max_abs"], 1e-4 * (1.0 - s * m["T_min"]),
-            s * m["power_abs"], 1.0 + s * m["radius"], 0.2 - s * m["near_plane_abs"], s * m["rect_abs"])
+        if sign == 0 or self._order_h is None:
+            self.lib.oracle_set_depth_shift(None, 0)
+            self._shift_buf = None
+        else:  # swap the near-tie neighbours of the depth order (find_order_ties) one way, then the other
+            self._shift_buf = np.ascontiguousarray(self._order_h * (s * m["depth_ulps"] * 1.2e-7), np.float64)
+            self.lib.oracle_set_depth_shift(self._shift_buf.ctypes.data_as(C.POINTER(C.c_double)), len(self._shift_buf))
         if sign == 0:
             self.lib.oracle_reset_thresholds()
+            return
+        self.lib.oracle_set_thresholds(
+            (1.0 / 255.0) * (1.0 - s * m["alpha_min"]), 0.99 + s * m["alpha_max_abs"], 1e-4 * (1.0 - s * m["T_min"]),
+            s * m["power_abs"], 1.0 + s * m["radius"], 0.2 - s * m["near_plane_abs"], s * m["rect_abs"],
+            s * m["alpha_cond"])
+
+    # pixel classes of the gradient decomposition below: the backward is linear in dL/dpixel, so the gradient is the
+    # sum of the gradients of the four 2x2-interleaved pixel classes
+    FLIP_CLASSES = 4
+
+    @staticmethod
+    def pixel_class_masks(H, W):
+        yy, xx = np.mgrid[0:H, 0:W]
+        cls = (yy % 2) * 2 + (xx % 2)
+        return [(cls == c) for c in range(4)]
 
     _f64 = None
 
@@ -204,16 +270,26 @@ class Oracle:
         whole image: 2e-4 of the norm between the f32 and f64 oracles), and one correct fp32 implementation cannot be
         asked to sit closer to another than that one sits to the truth.  That distance is ONE sample of the summation
         noise and the other implementation (atomics in arrival order) contributes its own, so it enters twice."""
+        # A Gaussian's gradient is a SUM over its pixels; with the thresholds moved, several of its pixels flip at
+        # once and their signed contributions partly cancel in the sum, which would understate what ONE flip (all the
+        # other implementation may differ by) can do.  So the backward runs per pixel class (it is linear in
+        # dL/dpixel) and the amplitudes of the classes are added: flips only meet inside a class.
+        dL = np.asarray(dL_dcolor)
+        H, W = dL.shape[-2:]
+        masks = self.pixel_class_masks(H, W)
         runs = []
         try:
             for sign in (0, +1, -1):
                 self.set_thresholds(sign)
                 img, dep, radii, st = self.raster_forward(cam, means3D, colors, opacities, scales, rotations)
-                g = self.raster_backward(st, dL_dcolor)
-                runs.append((img, dep, radii, g, st, st.final_T().copy(), st.n_contrib().copy()))
+                if sign == 0:
+                    self.find_order_ties(st)
+                gs = [self.raster_backward(st, dL * m) for m in masks]
+                runs.append((img, dep, radii, gs, st, st.final_T().copy(), st.n_contrib().copy()))
         finally:
+            self._order_h = None
             self.set_thresholds(0)
-        nom = runs[0]
+        nom = list(runs[0])
         P = len(nom[2])
 
         def amp(get):
@@ -226,7 +302,8 @@ class Oracle:
             "n_contrib": (runs[1][6] != nom[6]) | (runs[2][6] != nom[6]),
         }
         for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
-            out[k] = amp(lambda r, k=k: r[3][k].reshape(P, -1))
+            out[k] = sum(amp(lambda r, k=k, c=c: r[3][c][k].reshape(P, -1)) for c in range(len(masks)))
+        nom[3] = self.raster_backward(nom[4], dL)  # the nominal gradient itself: one backward over all pixels
         if roundoff and self.dtype != np.float64:
             if Oracle._f64 is None:
                 Oracle._f64 = Oracle(np.float64)

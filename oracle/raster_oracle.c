@@ -147,14 +147,31 @@ typedef struct {
   double radius_scale;  /* 1: radius = ceil(3 sigma * scale)       */
   double near_plane;    /* 0.2: cull t_z <= near_plane             */
   double rect_shift;    /* 0: added to (p -+ radius) before the division by the tile size */
+  double alpha_cond;    /* 0: alpha_min is additionally scaled by (1 - alpha_cond * sum |terms of the exponent|): the
+                           exponent's three products cancel on elongated footprints and carry rounding in proportion
+                           to their magnitudes, not to their sum */
 } OracleThresholds;
-static OracleThresholds g_thr = {1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0};
+static OracleThresholds g_thr = {1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0};
 void oracle_set_thresholds(double alpha_min, double alpha_max, double T_min, double power_max, double radius_scale,
-                           double near_plane, double rect_shift) {
+                           double near_plane, double rect_shift, double alpha_cond) {
   g_thr.alpha_min = alpha_min; g_thr.alpha_max = alpha_max; g_thr.T_min = T_min; g_thr.power_max = power_max;
   g_thr.radius_scale = radius_scale; g_thr.near_plane = near_plane; g_thr.rect_shift = rect_shift;
+  g_thr.alpha_cond = alpha_cond;
 }
-void oracle_reset_thresholds(void) { oracle_set_thresholds(1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0); }
+void oracle_reset_thresholds(void) { oracle_set_thresholds(1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0); }
+/* The other discontinuity: the depth ORDER inside a tile.  Two implementations whose view-space depths differ in the
+ * last bit (different glue in front of the rasteriser) may sort a near-tie either way.  The tests find the pairs of
+ * list neighbours whose depths are within a few ulp and hand over a per-Gaussian relative shift of the SORT KEY only
+ * (the depth that is blended is untouched) that swaps exactly those pairs.  NULL = none. */
+static const double *g_depth_shift = 0;
+static int g_depth_shift_n = 0;
+void oracle_set_depth_shift(const double *rel_shift, int n) { g_depth_shift = rel_shift; g_depth_shift_n = n; }
+/* nominal: exactly (real)(1/255); perturbed: moved further in proportion to the exponent's conditioning */
+#define THR_ALPHA_MIN_AT(co, dx, dy)                                                                                  \
+  (g_thr.alpha_cond == 0.0 ? (real)g_thr.alpha_min                                                                    \
+                           : (real)(g_thr.alpha_min * (1.0 - g_thr.alpha_cond * (0.5 * (fabs((double)((co)[0] * (dx) * (dx))) + \
+                                                                                           fabs((double)((co)[2] * (dy) * (dy)))) + \
+                                                                                    fabs((double)((co)[1] * (dx) * (dy)))))))
 #define THR_ALPHA_MIN ((real)g_thr.alpha_min)
 #define THR_ALPHA_MAX ((real)g_thr.alpha_max)
 #define THR_T_MIN ((real)g_thr.T_min)
@@ -299,7 +316,10 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
     const int *rc = st->rect + 4 * i;
     for (int y = rc[1]; y < rc[3]; y++)
       for (int x = rc[0]; x < rc[2]; x++) {
-        keys[off].tile = (uint32_t)(y * gx + x); keys[off].depth = st->depth[i]; keys[off].idx = (uint32_t)i; off++;
+        keys[off].tile = (uint32_t)(y * gx + x); keys[off].idx = (uint32_t)i;
+        keys[off].depth = (g_depth_shift && i < g_depth_shift_n) ? (real)((double)st->depth[i] * (1.0 + g_depth_shift[i]))
+                                                                 : st->depth[i];
+        off++;
       }
   }
   qsort(keys, (size_t)R, sizeof(PairKey), pair_cmp);
@@ -330,7 +350,7 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
           if (power > THR_POWER_MAX) continue;
           real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * R_EXP(power));
-          if (alpha < THR_ALPHA_MIN) continue;
+          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy)) continue;
           real test_T = T * (1 - alpha);
           if (test_T < THR_T_MIN) break;
           real w = alpha * T;
@@ -397,7 +417,7 @@ void oracle_raster_backward(const OracleCfg *cfg, const OracleState *st, const r
           if (power > THR_POWER_MAX) continue;
           real G = R_EXP(power);
           real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * G);
-          if (alpha < THR_ALPHA_MIN) continue;
+          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy)) continue;
           T = T / (1 - alpha);
           real wgt = alpha * T, dL_dalpha = 0;
           for (int ch = 0; ch < C; ch++) {
