@@ -22,7 +22,9 @@ def test_rgb_loss_matches_reference_golden():
         l = losses.rgb_loss_func(x, gt, mask=m)
         l.backward()
         np.testing.assert_allclose(l.item(), g[f"loss_{tag}"], rtol=2e-5)
-        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"grad_{tag}"], rtol=1e-3, atol=2e-8)
+        # north_star: 1e-4 relative fp32 -- of the gradient's inf-norm (the L1 part is +-0.8 / N almost everywhere)
+        want = g[f"grad_{tag}"]
+        assert np.abs(x.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
 
 
 def test_pearson_matches_reference_golden():

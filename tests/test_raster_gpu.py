@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from fsgs_amd import synth
-from tests.util import assert_close_attributed, assert_close_flip_aware, c1_poses, sh0_colors, to_camera_frame
+from tests.util import assert_close_attributed, c1_poses, sh0_colors, to_camera_frame
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

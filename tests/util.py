@@ -41,41 +41,6 @@ def c1_poses():
     return poses
 
 
-def assert_close_flip_aware(got, want, what, tol=1e-4, floor=0.0, rows=None, max_frac=5e-4, min_budget=3,
-                            max_outlier=5e-2):
-    """The rasteriser is DISCONTINUOUS in its inputs: alpha < 1/255 skips, T < 1e-4 terminates,
-    radius = ceil(3 sigma).  Two correct fp32 implementations that round one
-    exp() differently flip such a decision for a handful of (pixel, Gaussian) pairs -- the f32
-    and f64 builds of the ORACLE ITSELF differ by 1.7e-3 (image) and 2e-3..7e-3 of the inf-norm
-    (gradients) on config C1 because of ~5 flips in 41M evaluated pairs.  So parity is asserted as:
-      * every element within `tol` of the tensor's inf-norm (1e-4), EXCEPT a flip
-        budget of max(min_budget, max_frac * N) elements (rows for per-Gaussian tensors), and
-      * the outliers themselves stay within `max_outlier` of the inf-norm (a flip moves one
-        pixel by at most alpha*T <= 1/255).
-    """
-    got = np.asarray(got, np.float64)
-    want = np.asarray(want, np.float64)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    if got.size == 0:
-        return 0
-    scale = float(np.max(np.abs(want))) + floor + 1e-30
-    err = np.abs(got - want) / scale
-    assert np.isfinite(err).all(), "%s: non-finite values" % what
-    bad = err > tol
-    if rows is not None:  # count whole Gaussians, not components
-        bad_units = int(bad.reshape(rows, -1).any(axis=1).sum())
-        n_units = rows
-    else:
-        bad_units = int(bad.sum())
-        n_units = got.size
-    budget = max(min_budget, int(max_frac * n_units))
-    assert bad_units <= budget, "%s: %d of %d beyond %g of the inf-norm (flip budget %d), worst %g" % (
-        what, bad_units, n_units, tol, budget, err.max())
-    assert err.max() <= max_outlier, "%s: worst error %g of the inf-norm exceeds the flip bound %g" % (
-        what, err.max(), max_outlier)
-    return bad_units
-
-
 def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.0, max_outlier=5e-2):
     """Parity with flip ATTRIBUTION (replaces the blanket flip budget wherever the oracle can be asked which elements
     are fragile).  The rasteriser is discontinuous (alpha < 1/255 skips, alpha clamps at 0.99, T < 1e-4 stops,
