@@ -231,8 +231,17 @@ class Runner:
     densification), validation (PSNR on the test frames) and eval_pose (RPE / ATE)."""
 
     def __init__(self, pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, fused=True,
-                 seed=0, densify=True, row0_depth_quirk=True):
+                 seed=0, densify=True, row0_depth_quirk=True, densify_interval=300, opacity_reset_interval=3000,
+                 densify_until=15000, trace=False):
         import random
+
+        # train.py:305-311: densify_and_prune at iteration % 300 == 0 while iteration < 15000, opacity reset at % 3000.
+        # (Parameters so that a pinned short trajectory can cross a densification, tests/test_harness_pin_gpu.py.)
+        self.densify_interval, self.opacity_reset_interval = int(densify_interval), int(opacity_reset_interval)
+        self.densify_until = int(densify_until)
+        # trace=True: every iteration's loss values are read back and appended to self.trace (one host sync each, like
+        # the reference's per-iteration .item() prints); off by default
+        self.trace = [] if trace else None
 
         self.pc, self.poses, self.frames = pc, poses, frames
         self.tracking_iter, self.mapping_iter, self.first_mapping_iter = tracking_iter, mapping_iter, first_mapping_iter
@@ -260,14 +269,16 @@ class Runner:
         it = self.iteration
         if not self.densify:
             return
-        if it % 300 == 0 and it < 15000:
+        if it % self.densify_interval == 0 and it < self.densify_until:
             fdist.sync_densification_stats(self.pc)
             size_threshold = 20 if it > 4000 else None
             if self.fast is not None:  # one plan + one gather on the device (csrc/densify.hip)
                 self.pc.densify_and_prune_device(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
             else:
                 self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
-        if it % 3000 == 0:
+            if self.trace is not None:
+                self.trace.append(("densify", it, self.pc.num_points))
+        if it % self.opacity_reset_interval == 0:
             self.pc.reset_opacity()
 
     def mapping(self, cur_t, mapping_iter, progressive):
@@ -278,21 +289,27 @@ class Runner:
             self.iteration += 1
             ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
             it = self.iteration
-            special = self.densify and ((it % 300 == 0 and it < 15000) or it % 3000 == 0)
+            special = self.densify and ((it % self.densify_interval == 0 and it < self.densify_until) or
+                                        it % self.opacity_reset_interval == 0)
             if self.fast is not None and not special:
                 # nothing happens between backward and optimizer.step() on this iteration (train.py:266-272):
                 # the step driver may consume the gradient itself (Adam fused / compact gradient)
                 self.fast.pc = self.pc
                 # the statistics feed densify_and_prune only, whose last call is at iteration 14 700 (train.py:305)
-                self.fast.mapping_step(ts, step_optimizer=True, collect_stats=self.densify and it < 15000)
+                loss = self.fast.mapping_step(ts, step_optimizer=True,
+                                              collect_stats=self.densify and it < self.densify_until)
+                if self.trace is not None:
+                    self.trace.append(("map", it, tuple(ts), float(loss)))
                 pkg = None
                 continue
             if self.fast is not None:
                 self.fast.pc = self.pc
-                self.fast.mapping_step(ts, step_optimizer=False)
+                loss = self.fast.mapping_step(ts, step_optimizer=False)
                 _first = None
             else:
                 loss, _first = mapping_step(self.pc, self.poses, self.frames, ts, fused=False, step_optimizer=False)
+            if self.trace is not None:
+                self.trace.append(("map", it, tuple(ts), float(loss)))
             with torch.no_grad():
                 self.densification()
                 self.pc.optimizer.step()
@@ -331,9 +348,11 @@ class Runner:
                 # the loss values are only logged once per frame (the reference prints them every iteration through
                 # .item(), i.e. a host sync per iteration)
                 out = self.fast.tracking_step(t, targets, None if all_rigid else rigid,
-                                              want_losses=it_ == self.tracking_iter - 1) + (None,)
+                                              want_losses=self.trace is not None or it_ == self.tracking_iter - 1) + (None,)
             else:
                 out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
+            if self.trace is not None:
+                self.trace.append(("track", t, it_, float(out[0]), float(out[1]), float(out[2])))
         return out
 
     def progressive_run(self):

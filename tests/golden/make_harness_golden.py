@@ -1,0 +1,59 @@
+"""Writes tests/golden/harness_pin.npz: the inputs of a tiny 3-frame progressive run and what the CPU-oracle harness
+(tests/ref_harness.py: oracle rasteriser + reference-pinned torch losses + torch Adam + the reference's densify
+sequence) makes of them -- per-iteration losses, the poses after every tracked frame, the cloud size after the
+densification.  Runs in the dev container (no GPU, no reference import):   python tests/golden/make_harness_golden.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "free-surgs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle.fsgs_oracle import Oracle  # noqa: E402
+from tests import ref_harness  # noqa: E402
+
+
+def run(fx, oracle):
+    pin = ref_harness.PIN
+    pc, poses, frames = ref_harness.load_inputs(fx, "cpu")
+    pc.training_setup(fused=False)  # Adam eps 1e-15, the progressive-run learning rates (scene/gaussian_model.py:382-409)
+    h = ref_harness.CpuHarness(oracle, pc, poses, frames, tracking_iter=pin["tracking_iter"], mapping_iter=pin["mapping_iter"],
+                               first_mapping_iter=pin["first_mapping_iter"], densify_interval=pin["densify_interval"],
+                               seed=pin["seed"])
+    torch.manual_seed(0)
+    with ref_harness.deterministic_rng(pin["rng_seed"]):
+        h.progressive_run()
+    return h
+
+
+def main():
+    oracle = Oracle(np.float32)
+    oracle.set_threads(1)  # deterministic accumulation order
+    fx = ref_harness.make_inputs(oracle)
+    h = run(fx, oracle)
+    tr = h.trace
+    out = dict(fx)
+    out["map_loss"] = np.array([e[3] for e in tr if e[0] == "map"], np.float64)
+    out["map_iter"] = np.array([e[1] for e in tr if e[0] == "map"], np.int64)
+    out["map_views"] = np.array([list(e[2]) + [-1] * (2 - len(e[2])) for e in tr if e[0] == "map"], np.int64)
+    out["track_loss"] = np.array([[e[3], e[4], e[5]] for e in tr if e[0] == "track"], np.float64)
+    out["track_frame_iter"] = np.array([[e[1], e[2]] for e in tr if e[0] == "track"], np.int64)
+    out["densify"] = np.array([[e[1], e[2]] for e in tr if e[0] == "densify"], np.int64)
+    out["pose_r"] = h.poses.r.detach().numpy()
+    out["pose_t"] = h.poses.t.detach().numpy()
+    out["final_P"] = h.pc.num_points
+    out["final_xyz_mean"] = h.pc.params["_xyz"].detach().mean(0).numpy()
+    np.savez_compressed(os.path.join(HERE, "harness_pin.npz"), **out)
+    print("P0 %d -> densify %s -> final %d" % (fx["_xyz"].shape[0], out["densify"].tolist(), out["final_P"]))
+    print("map loss", np.round(out["map_loss"], 5).tolist())
+    print("track loss", np.round(out["track_loss"][:, 0], 5).tolist())
+    print("fixture bytes", os.path.getsize(os.path.join(HERE, "harness_pin.npz")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,253 @@
+"""CPU-oracle harness (TEST INFRASTRUCTURE): the reference's training sequence -- FreeSurGS.tracking / mapping /
+densification / progressive_run, train.py:154-376 -- restated on CPU tensors with
+
+    render        = fsgs_amd.render.render_two_pass around the CPU oracle rasteriser (tests/ref_cpu.py)
+    losses        = the torch statements pinned to the reference's golden vectors (losses.rgb_loss_torch, pearson_torch,
+                    local_pearson_torch, flow.projection_flow_loss_torch, epipolar.*_torch)
+    optimisers    = torch.optim.Adam / MultiStepLR exactly as the reference builds them
+    densification = GaussianCloud.densify_and_prune (the reference's sequence, bit-for-bit vs tests/golden/densify.npz)
+
+It exists to PIN the product harness (fsgs_amd.trainer.Runner on the HIP step driver): the per-iteration losses, the
+poses and the cloud size after a densification that tests/golden/make_harness_golden.py records with it are what
+tests/test_harness_pin_gpu.py demands of the GPU run on the same inputs."""
+import contextlib
+import random
+
+import numpy as np
+import torch
+
+from fsgs_amd import epipolar, flow, losses, synth
+from fsgs_amd.model import GaussianCloud
+from fsgs_amd.render import render_two_pass
+from fsgs_amd.trainer import LOSS_W_MAPPING, LOSS_W_TRACKING, FrameData, PoseTrack, settings_from_cam
+from tests import ref_cpu
+
+
+@contextlib.contextmanager
+def deterministic_rng(seed):
+    """Both harnesses consume random numbers on their own device (patch corners: torch.randint; split samples:
+    torch.normal / torch.randn); the streams of a CPU and a GPU generator differ.  Inside this context those three draw
+    from ONE seeded CPU generator and move the result to the device that was asked for, so a CPU run and a GPU run see
+    the same numbers in the same order."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    o_randint, o_randn, o_normal = torch.randint, torch.randn, torch.normal
+
+    def randint(low, high=None, size=None, **kw):
+        if high is None:
+            low, high = 0, low
+        dev = kw.pop("device", None)
+        kw.pop("generator", None)
+        return o_randint(low, high, size, generator=g, **kw).to(dev or "cpu")
+
+    def randn(*size, **kw):
+        dev = kw.pop("device", None)
+        kw.pop("generator", None)
+        size = size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+        return o_randn(tuple(size), generator=g, **kw).to(dev or "cpu")
+
+    def normal(mean, std, **kw):
+        z = o_randn(tuple(std.shape), generator=g, dtype=torch.float32).to(std.device)
+        return mean + std * z
+
+    torch.randint, torch.randn, torch.normal = randint, randn, normal
+    try:
+        yield
+    finally:
+        torch.randint, torch.randn, torch.normal = o_randint, o_randn, o_normal
+
+
+class CpuHarness:
+    """Runner's counterpart on CPU; same constructor meaning, same trace format."""
+
+    def __init__(self, oracle, pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, seed=0,
+                 row0_depth_quirk=True, densify_interval=300, opacity_reset_interval=3000, densify_until=15000):
+        self.oracle, self.pc, self.poses, self.frames = oracle, pc, poses, frames
+        self.tracking_iter, self.mapping_iter, self.first_mapping_iter = tracking_iter, mapping_iter, first_mapping_iter
+        self.iteration, self.keyframes, self.rng = 0, [], random.Random(seed)
+        self.row0_depth_quirk = row0_depth_quirk
+        self.densify_interval, self.opacity_reset_interval, self.densify_until = densify_interval, opacity_reset_interval, densify_until
+        self.trace = []
+        self.h, self.w = (int(v) for v in frames.colors[0].shape[-2:])
+
+    def render(self, t, gs_grad, cam_grad):
+        with ref_cpu.oracle_backend(self.oracle):
+            return render_two_pass(self.poses, t, self.pc, gs_grad=gs_grad, cam_grad=cam_grad)
+
+    # ---- train.py:297-316 ----
+    def densification(self):
+        it = self.iteration
+        if it % self.densify_interval == 0 and it < self.densify_until:
+            self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, 20 if it > 4000 else None)
+            self.trace.append(("densify", it, self.pc.num_points))
+        if it % self.opacity_reset_interval == 0:
+            self.pc.reset_opacity()
+
+    # ---- train.py:213-295 ----
+    def mapping(self, cur_t, mapping_iter, progressive):
+        views = 2 if (progressive and cur_t != 0) else 1
+        self.pc.optimizer.zero_grad(set_to_none=True)
+        pkg = None
+        for _ in range(mapping_iter):
+            self.iteration += 1
+            ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
+            loss, first = 0, None
+            for k, t in enumerate(ts):
+                pkg = self.render(t, gs_grad=True, cam_grad=False)
+                rgb = losses.rgb_loss_torch(pkg["render"], self.frames.colors[t]) * LOSS_W_MAPPING["rgb"]
+                pear = losses.pearson_torch(self.frames.monodeps[t], pkg["render_dep"])
+                lp = losses.local_pearson_torch(self.frames.monodeps[t], pkg["render_dep"], 128, 0.5)
+                loss = loss + rgb + pear * LOSS_W_MAPPING["pearson"] + lp * LOSS_W_MAPPING["local_pearson"]
+                if k == 0:
+                    first = pkg
+            loss.backward()
+            self.trace.append(("map", self.iteration, tuple(ts), float(loss)))
+            with torch.no_grad():
+                vis = first["visibility_filter"]  # train.py:260-263,298-303: statistics from view 0
+                self.pc.variables["max_radii2D"][vis] = torch.max(self.pc.variables["max_radii2D"][vis],
+                                                                  first["radii"][vis].float())
+                self.pc.add_densification_stats(first["viewspace_points"].grad, vis)
+                self.densification()
+                self.pc.optimizer.step()
+                self.pc.optimizer.zero_grad(set_to_none=True)
+        return pkg  # the render of the LAST view of the last iteration (train.py:291)
+
+    # ---- train.py:154-210 ----
+    def tracking(self, t):
+        rigid = None
+        if t > 1:
+            with torch.no_grad():
+                Fm = epipolar.fundamental_from_w2c(self.poses.get_pose(t - 2), self.poses.get_pose(t - 1), self.frames.K)
+            rigid = epipolar.rigid_mask_torch(epipolar.sampson_distance_torch(self.frames.flows_fw[t - 2], Fm))
+        depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
+        w2c_prev = self.poses.pred_w2c[t - 1]
+        for it_ in range(self.tracking_iter):
+            pkg = self.render(t, gs_grad=False, cam_grad=True)
+            mask = pkg["render_dep"] > 0
+            if rigid is not None:
+                mask = mask * rigid
+            rgb = LOSS_W_TRACKING["rgb"] * losses.rgb_loss_torch(pkg["render"], self.frames.colors[t], mask=mask.unsqueeze(0))
+            fl = LOSS_W_TRACKING["flow"] * flow.projection_flow_loss_torch(depth_prev, w2c_prev, pkg["render_w2c"],
+                                                                          self.frames.K, self.frames.flows_fw[t - 1], rigid)
+            loss = fl + rgb
+            loss.backward()
+            self.poses.scheduler.step()  # before optimizer.step(), as train.py:189,194
+            with torch.no_grad():
+                self.poses.optimizer.step()
+                self.poses.optimizer.zero_grad(set_to_none=True)
+            self.trace.append(("track", t, it_, float(loss), float(rgb), float(fl)))
+
+    def _tracking_optimizer(self):
+        """Adam(lr .01, eps 1e-15) + MultiStepLR(milestones 0,16,32,48 for 50 iterations; gamma .5)
+        (scene/pose_optimizer.py:489-496)."""
+        p = self.poses
+        p.optimizer = torch.optim.Adam([{"params": p.r, "lr": 0.01}, {"params": p.t, "lr": 0.01}], lr=0.001, eps=1e-15)
+        step = int(self.tracking_iter / 3)
+        p.scheduler = torch.optim.lr_scheduler.MultiStepLR(p.optimizer, milestones=list(range(0, int(self.tracking_iter), step)),
+                                                           gamma=0.5)
+
+    # ---- train.py:318-345 ----
+    def progressive_run(self):
+        n = len(self.frames.colors)
+        with torch.no_grad():
+            self.poses.get_pose(0)
+        for t in range(n):
+            self.pc.update_learning_rate(self.iteration)
+            if t > 0:
+                if t > 1:
+                    self.poses.initialize_pose(t)
+                else:
+                    with torch.no_grad():
+                        self.poses.r[..., t] = self.poses.r[..., t - 1]
+                        self.poses.t[..., t] = self.poses.t[..., t - 1]
+                self._tracking_optimizer()
+                self.tracking(t)
+            if t in self.frames.i_train:
+                if self.iteration % 1000 == 0:
+                    self.pc.oneupSHdegree()
+                pkg = self.mapping(t, self.first_mapping_iter if t == 0 else self.mapping_iter, progressive=True)
+                d = pkg["render_dep"].detach().float()
+                self.frames.pred_depths[t] = d[0].expand(self.h, self.w).contiguous() if self.row0_depth_quirk else d.contiguous()
+                self.keyframes.append(t)
+
+
+# ---- the pinned inputs: a tiny synthetic sequence made entirely on CPU ----------------------------------------------
+def make_inputs(oracle, W=256, H=192, n_frames=3, P_scene=3000, ratio=0.02, seed=0):
+    """A hidden opaque scene rendered along a smooth trajectory by the CPU reference render -> per frame colours
+    (8-bit), mono-depth (affine-normalised to [0.5,1.5], fp16) and forward flow (fp16), plus the learner's first-frame
+    cloud (GaussianModel.initialize_first_timestep, scene/gaussian_model.py:237-258, scales from the oracle's exact
+    3-NN).  Everything is quantised BEFORE it is used, so the arrays written to the fixture are bit-for-bit what both
+    harnesses consume.  -> dict of numpy arrays."""
+    from fsgs_amd.sequence import _rot_to_quat, gt_trajectory
+
+    cam = synth.make_camera(W, H)
+    knn = lambda pts: oracle.knn_meandist2(pts)
+    sc = dict(synth.init_scene(W, H, P_scene, seed=seed, knn_fn=knn))
+    sc["_opacity"] = np.full_like(sc["_opacity"], 3.0)
+    sc["_scaling"] = sc["_scaling"] + 0.35
+    gt = GaussianCloud(sc, sh_degree=3, device="cpu")
+    gt.cam = settings_from_cam(cam, "cpu")
+    w2cs = gt_trajectory(n_frames, seed=seed)
+    poses = PoseTrack(n_frames, "cpu")
+    for i, m in enumerate(w2cs):
+        poses.set_pose(i, _rot_to_quat(m[:3, :3]), m[:3, 3])
+    colors, depths = [], []
+    with torch.no_grad(), ref_cpu.oracle_backend(oracle):
+        for i in range(n_frames):
+            pkg = render_two_pass(poses, i, gt, gs_grad=False, cam_grad=False)
+            colors.append(pkg["render"].clamp(0, 1))
+            depths.append(pkg["render_dep"])
+    colors_u8 = np.stack([(c * 255.0 + 0.5).to(torch.uint8).numpy() for c in colors])
+    mono = np.stack([(((d - d.min()) / (d.max() - d.min())) + 0.5).numpy() for d in depths]).astype(np.float16)
+    K = torch.tensor(cam["K"], dtype=torch.float32)
+    vv, uu = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flows = []
+    for i in range(n_frames - 1):
+        d = depths[i]
+        ci = torch.stack([(uu - K[0, 2]) / K[0, 0] * d, (vv - K[1, 2]) / K[1, 1] * d, d, torch.ones_like(d)], 0).reshape(4, -1)
+        rel = torch.tensor(w2cs[i + 1] @ np.linalg.inv(w2cs[i]), dtype=torch.float32)
+        p = K @ (rel @ ci)[:3]
+        flows.append(torch.stack([(p[0] / (p[2] + 1e-5)).reshape(H, W) - uu, (p[1] / (p[2] + 1e-5)).reshape(H, W) - vv], 0).numpy())
+    flows = np.stack(flows).astype(np.float16)
+    # the learner's cloud from frame 0, from the QUANTISED inputs
+    c0 = torch.tensor(colors_u8[0].astype(np.float32) / 255.0)
+    m0 = torch.tensor(mono[0].astype(np.float32))
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    perm = torch.randperm(H * W, generator=g)[: int(ratio * H * W)].sort().values
+    v_, u_ = perm // W, perm % W
+    z = m0[v_, u_]
+    xyz = torch.stack([(u_.float() - K[0, 2]) / K[0, 0] * z, (v_.float() - K[1, 2]) / K[1, 1] * z, z], 1).numpy().astype(np.float32)
+    rgb = c0[:, v_, u_].T.numpy()
+    dist2 = np.maximum(oracle.knn_meandist2(xyz), 1e-7).astype(np.float32)
+    Pn = xyz.shape[0]
+    return {
+        "colors_u8": colors_u8, "monodeps_f16": mono, "flows_fw_f16": flows, "K": np.asarray(cam["K"], np.float64),
+        "gt_w2c": np.stack(w2cs).astype(np.float32), "W": W, "H": H,
+        "_xyz": xyz, "_features_dc": ((rgb - 0.5) / synth.SH_C0).reshape(Pn, 1, 3).astype(np.float32),
+        "_features_rest": np.zeros((Pn, 15, 3), np.float32),
+        "_opacity": np.full((Pn, 1), np.log(0.1 / 0.9), np.float32),
+        "_scaling": np.repeat(np.log(np.sqrt(dist2))[:, None], 3, 1).astype(np.float32),
+        "_rotation": np.tile(np.array([[1.0, 0, 0, 0]], np.float32), (Pn, 1)),
+        "scene_radius": float(mono[0].astype(np.float32).max()) / 2.0,
+    }
+
+
+def load_inputs(fx, device):
+    """fixture arrays -> (GaussianCloud with its progressive-run optimizer NOT yet built, PoseTrack, FrameData)."""
+    from fsgs_amd.model import PARAM_NAMES
+
+    W, H = int(fx["W"]), int(fx["H"])
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)
+    colors = [t(c.astype(np.float32) / 255.0) for c in fx["colors_u8"]]
+    mono = [t(m.astype(np.float32)) for m in fx["monodeps_f16"]]
+    flows = [t(f.astype(np.float32)) for f in fx["flows_fw_f16"]]
+    frames = FrameData(colors, mono, flows_fw=flows, K=np.asarray(fx["K"], np.float64), gt_w2c=[m for m in fx["gt_w2c"]])
+    # (copies: on CPU a tensor made from a numpy array shares its memory, and Adam updates parameters in place)
+    pc = GaussianCloud({k: np.array(fx[k], dtype=np.float32, copy=True) for k in PARAM_NAMES}, sh_degree=3, device=device,
+                       scene_radius=float(fx["scene_radius"]))
+    pc.cam = settings_from_cam(synth.make_camera(W, H), device)
+    poses = PoseTrack(len(colors), device)
+    return pc, poses, frames
+
+
+# what the pinned run does (shared by the fixture script and the GPU test)
+PIN = dict(tracking_iter=5, mapping_iter=5, first_mapping_iter=5, densify_interval=8, rng_seed=11, seed=0)

@@ -1,0 +1,76 @@
+"""The product harness (fsgs_amd.trainer.Runner on the HIP step driver: fused render, HIP losses, fused Adam, device
+densification, fused pose update) must REPRODUCE the trajectory the CPU-oracle harness recorded on the same inputs
+(tests/golden/harness_pin.npz, written by tests/golden/make_harness_golden.py with tests/ref_harness.py): 3 frames at
+256x192, 983 Gaussians, 5 tracking + 5 mapping iterations per frame, one densification (SURVEY.md s8 a15;
+train.py:154-376, scene/pose_optimizer.py:489-516).  Same call sequence, same hyper-parameters, same random numbers
+(ref_harness.deterministic_rng) -- so every per-iteration loss, every pose and the cloud size after the densification
+are comparable number by number."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import ref_harness
+
+pytestmark = pytest.mark.gpu
+FX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness_pin.npz")
+
+
+def _run_gpu(fx, fused=True):
+    from fsgs_amd.trainer import Runner
+
+    pin = ref_harness.PIN
+    pc, poses, frames = ref_harness.load_inputs(fx, "cuda")
+    pc.training_setup()
+    run = Runner(pc, poses, frames, tracking_iter=pin["tracking_iter"], mapping_iter=pin["mapping_iter"],
+                 first_mapping_iter=pin["first_mapping_iter"], densify_interval=pin["densify_interval"], seed=pin["seed"],
+                 fused=fused, trace=True)
+    torch.manual_seed(0)
+    with ref_harness.deterministic_rng(pin["rng_seed"]):
+        run.progressive_run()
+    torch.cuda.synchronize()
+    return run
+
+
+def test_runner_reproduces_the_cpu_oracle_trajectory():
+    fx = dict(np.load(FX))
+    run = _run_gpu(fx)
+    tr = run.trace
+    maps = [e for e in tr if e[0] == "map"]
+    tracks = [e for e in tr if e[0] == "track"]
+    dens = [e for e in tr if e[0] == "densify"]
+    # the schedule itself: which iteration mapped which views, which frame tracked when, when the cloud was densified
+    assert [e[1] for e in maps] == fx["map_iter"].tolist()
+    assert [list(e[2]) + [-1] * (2 - len(e[2])) for e in maps] == fx["map_views"].tolist()
+    assert [[e[1], e[2]] for e in tracks] == fx["track_frame_iter"].tolist()
+    # cloud size after densify_and_prune: EXACT (same clone / split / prune decisions from the accumulated statistics)
+    assert [[e[1], e[2]] for e in dens] == fx["densify"].tolist(), (dens, fx["densify"].tolist())
+    assert run.pc.num_points == int(fx["final_P"])
+    # per-iteration losses.  Before the densification the two runs differ by fp32 rounding only; Adam (eps 1e-15)
+    # turns a rounding-sized gradient difference on a parameter the image does not depend on (the quaternion of an
+    # isotropic Gaussian) into a full-size step of that parameter, which the loss does not see.
+    got_map = np.array([e[3] for e in maps])
+    n_pre = int((fx["map_iter"] < fx["densify"][0, 0]).sum())
+    np.testing.assert_allclose(got_map[:n_pre], fx["map_loss"][:n_pre], rtol=1e-4)
+    np.testing.assert_allclose(got_map[n_pre:], fx["map_loss"][n_pre:], rtol=5e-4)
+    got_trk = np.array([[e[3], e[4], e[5]] for e in tracks])
+    np.testing.assert_allclose(got_trk, fx["track_loss"], rtol=5e-4, atol=1e-6)
+    # the poses of all three frames after the run (quaternion r, translation t): each took 5 Adam steps of 5e-3 .. 6e-4
+    # (lr 0.01 halved at 0, 1, 2, 3, 4 -- MultiStepLR(range(0, 5, 1))); 3e-5 is half a percent of one step
+    np.testing.assert_allclose(run.poses.r.detach().cpu().numpy(), fx["pose_r"], atol=3e-5)
+    np.testing.assert_allclose(run.poses.t.detach().cpu().numpy(), fx["pose_t"], atol=3e-5)
+    np.testing.assert_allclose(run.pc.params["_xyz"].detach().mean(0).cpu().numpy(), fx["final_xyz_mean"], atol=5e-5)
+
+
+def test_autograd_harness_route_reproduces_it_too():
+    """Runner(fused=False): the reference's own call sequence on the drop-in rasteriser + HIP loss / Adam ops under
+    torch.autograd -- the path an unchanged train.py takes."""
+    fx = dict(np.load(FX))
+    run = _run_gpu(fx, fused=False)
+    maps = [e for e in run.trace if e[0] == "map"]
+    dens = [e for e in run.trace if e[0] == "densify"]
+    assert [[e[1], e[2]] for e in dens] == fx["densify"].tolist()
+    n_pre = int((fx["map_iter"] < fx["densify"][0, 0]).sum())
+    np.testing.assert_allclose(np.array([e[3] for e in maps])[:n_pre], fx["map_loss"][:n_pre], rtol=1e-4)
+    np.testing.assert_allclose(run.poses.t.detach().cpu().numpy(), fx["pose_t"], atol=3e-5)
