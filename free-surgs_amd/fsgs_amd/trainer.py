@@ -57,6 +57,15 @@ class PoseTrack:
         self.pred_w2c[int(i)] = w2c.detach()
         return w2c
 
+    def peek_pose(self, i):
+        """w2c of frame i WITHOUT recording it in pred_w2c (the reference's pose_param_net.forward, as
+        get_fundamental_matrix calls it, scene/pose_optimizer.py:640-648)."""
+        old = self.pred_w2c[int(i)]
+        with torch.no_grad():
+            w = self.get_pose(i).detach()
+        self.pred_w2c[int(i)] = old
+        return w
+
     def _pose_key(self):
         # the tensor OBJECTS (kept alive by the entry) and their version counters: addresses alone can be recycled
         return (self.r, self.t, self.r._version, self.t._version)
@@ -232,7 +241,7 @@ class Runner:
 
     def __init__(self, pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, fused=True,
                  seed=0, densify=True, row0_depth_quirk=True, densify_interval=300, opacity_reset_interval=3000,
-                 densify_until=15000, trace=False):
+                 densify_until=15000, trace=False, test_frame_quirks=True):
         import random
 
         # train.py:305-311: densify_and_prune at iteration % 300 == 0 while iteration < 15000, opacity reset at % 3000.
@@ -253,6 +262,15 @@ class Runner:
         # train.py:343 stores render_dep[0] -- ROW 0 of the [H,W] depth, broadcast over all rows -- as the
         # previous-frame depth of the flow loss.  True reproduces the reference; False stores the full map.
         self.row0_depth_quirk = row0_depth_quirk
+        # What an unchanged train.py does with a TEST frame t (every 8th, never mapped; train.py:333-343):
+        #  * record_data['pred_depths'][t] stays at its initial zeros, so when frame t+1 is tracked get_pointcloud finds
+        #    no valid pixel and projection_flow_loss returns the constant 0 (scene/pose_optimizer.py:176-186): that
+        #    frame is tracked by the RGB loss alone;
+        #  * record_data['pred_w2c'][t] is whatever the LAST get_pose(t) wrote (scene/pose_optimizer.py:635-638): the
+        #    pose the 50th tracking iteration rendered with, i.e. BEFORE its optimizer step -- a mapped frame is
+        #    refreshed by its mapping renders, a test frame is not (get_fundamental_matrix calls the network directly).
+        # True reproduces both; False renders the test frame's depth once and records its final pose.
+        self.test_frame_quirks = test_frame_quirks
         self.fast = None
         if fused:
             from .fast_step import FastStepper
@@ -334,8 +352,8 @@ class Runner:
         if t > 1 and self.frames.flows_fw is not None:
             from .epipolar import fundamental_from_w2c, rigid_mask
 
-            with torch.no_grad():
-                Fm = fundamental_from_w2c(self.poses.get_pose(t - 2), self.poses.get_pose(t - 1), self.frames.K)
+            with torch.no_grad():  # get_fundamental_matrix asks the network, not get_pose: pred_w2c is not refreshed
+                Fm = fundamental_from_w2c(self.poses.peek_pose(t - 2), self.poses.peek_pose(t - 1), self.frames.K)
             rigid, self.last_sampson, _ = rigid_mask(self.frames.flows_fw[t - 2], Fm)
         all_rigid = rigid is None
         if all_rigid:
@@ -343,7 +361,11 @@ class Runner:
         depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
         targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
         out = None
+        rendered_last = None
         for it_ in range(self.tracking_iter):
+            if it_ == self.tracking_iter - 1 and self.test_frame_quirks and t not in self.frames.i_train:
+                with torch.no_grad():
+                    rendered_last = self.poses.peek_pose(t).detach().clone()
             if self.fast is not None:
                 # the loss values are only logged once per frame (the reference prints them every iteration through
                 # .item(), i.e. a host sync per iteration)
@@ -353,6 +375,8 @@ class Runner:
                 out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
             if self.trace is not None:
                 self.trace.append(("track", t, it_, float(out[0]), float(out[1]), float(out[2])))
+        if rendered_last is not None:
+            self.poses.pred_w2c[t] = rendered_last
         return out
 
     def progressive_run(self):
@@ -380,9 +404,13 @@ class Runner:
                 self.frames.pred_depths[t] = self._stored_depth(pkg)
                 self.keyframes.append(t)
             elif self.frames.pred_depths[t] is None:
-                with torch.no_grad():
-                    pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
-                self.frames.pred_depths[t] = self._stored_depth(pkg)
+                if self.test_frame_quirks:  # never rendered upstream: the next frame's flow loss sees no valid depth
+                    self.frames.pred_depths[t] = torch.zeros((self.h, self.w), dtype=torch.float32,
+                                                             device=self.frames.colors[0].device)
+                else:
+                    with torch.no_grad():
+                        pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
+                    self.frames.pred_depths[t] = self._stored_depth(pkg)
 
     def _stored_depth(self, pkg):
         d = pkg["render_dep"].detach().float()
@@ -390,9 +418,12 @@ class Runner:
             return d[0].expand(self.h, self.w).contiguous()
         return d.contiguous()
 
-    def global_run(self, iterations):
+    def global_run(self, iterations, first_iter=0):
+        """train.py:378-393: `for iter in range(self.first_iter, iterations + 1)` -- first_iter is 0 unless a checkpoint
+        was loaded, so iteration 0 runs too (iterations + 1 mapping steps) and, 0 being a multiple of 1000, raises the SH
+        degree at the very start of the global phase."""
         self.pc.initialize_optimizer()
-        for it in range(1, iterations + 1):
+        for it in range(int(first_iter), iterations + 1):
             ts = int(self.rng.choice(list(self.frames.i_train)))
             if it % 1000 == 0:
                 self.pc.oneupSHdegree()
@@ -415,5 +446,14 @@ class Runner:
 
         with torch.no_grad():
             pred = np.stack([self.poses.get_pose(i).detach().cpu().numpy() for i in range(len(self.frames.colors))])
+        # train.py:492-506: every <data> run of the sequence is Sim(3)-aligned on its own and the three metrics are summed
+        # with the runs' frame-count weights (dataset.read_sequence keeps data_ind / weights / gt_poses per run)
+        runs = getattr(self.frames, "gt_poses", None)
+        if runs:
+            ind, wts = self.frames.data_ind, self.frames.weights
+            total = np.zeros(3)
+            for i, (_, gt_run) in enumerate(runs.items()):
+                total += np.array(metrics.pose_metrics(pred[ind[i]:ind[i + 1]], gt_run)[1]) * wts[i]
+            return [float(v) for v in total]
         gt = np.stack([np.asarray(g, np.float32) for g in self.frames.gt_w2c])
         return metrics.pose_metrics(pred, gt)[1]

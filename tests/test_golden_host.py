@@ -396,3 +396,41 @@ def test_fused_adam_checkpoint_steps_under_torch_adam():
     pc3 = mk()
     checkpoint.restore_gaussians(pc3, checkpoint.capture_gaussians(pc2), fused=True)
     assert isinstance(pc3.optimizer, optim.FusedAdam)
+
+
+def test_eval_pose_aligns_every_run_on_its_own_and_global_run_starts_at_iteration_zero():
+    """train.py:492-506: one Sim(3) alignment per <data> run, metrics summed with the runs' weights -- two runs that are
+    each a perfect copy of their ground truth up to a DIFFERENT similarity must score ~0 (one joint alignment cannot).
+    train.py:381: global_run covers range(first_iter = 0, iterations + 1)."""
+    from fsgs_amd import synth
+    from fsgs_amd.sequence import _rot_to_quat, gt_trajectory
+    from fsgs_amd.trainer import FrameData, PoseTrack, Runner
+
+    gt = [np.asarray(m, np.float32) for m in gt_trajectory(8, step_t=0.02, step_r=0.01, seed=3)]
+    runs = {"1_5": np.stack(gt[:4]), "1_6": np.stack(gt[4:])}
+    frames = FrameData([torch.zeros(3, 4, 4)] * 8, [torch.zeros(4, 4)] * 8, gt_w2c=gt)
+    frames.gt_poses, frames.data_ind, frames.weights = runs, [0, 4, 8], [0.5, 0.5]
+    poses = PoseTrack(8, "cpu")
+    sims = [(1.0, synth.pose_matrix((1, 0, 0, 0), (0, 0, 0))), (2.5, synth.pose_matrix((0.9, 0.1, -0.2, 0.3), (0.4, -0.2, 0.1)))]
+    for i, m in enumerate(gt):
+        s, S = sims[i // 4]
+        p = np.eye(4)
+        p[:3, :3] = S[:3, :3] @ m[:3, :3]
+        p[:3, 3] = s * (S[:3, :3] @ m[:3, 3]) + S[:3, 3]  # a similarity of the whole run
+        poses.set_pose(i, _rot_to_quat(p[:3, :3]), p[:3, 3])
+    pc = model.GaussianCloud({"_xyz": torch.randn(5, 3), "_features_dc": torch.randn(5, 1, 3),
+                              "_features_rest": torch.randn(5, 15, 3), "_opacity": torch.randn(5, 1),
+                              "_scaling": torch.randn(5, 3), "_rotation": torch.randn(5, 4)}, device="cpu")
+    run = Runner(pc, poses, frames, fused=False)
+    rpe_t, rpe_r, ate = run.eval_pose()
+    assert ate < 1e-4 and rpe_r < 0.3, (rpe_t, rpe_r, ate)
+    del frames.gt_poses  # one joint alignment of the two differently-scaled runs cannot fit both
+    assert run.eval_pose()[2] > 1e-2
+    # the iterations of the global phase
+    seen = []
+    run.mapping = lambda ts, n, progressive: seen.append(ts)
+    pc.training_setup(fused=False)
+    pc.initialize_optimizer = lambda fused=True: None
+    deg0 = pc.active_sh_degree
+    run.global_run(3)
+    assert len(seen) == 4 and pc.active_sh_degree == deg0 + 1  # iterations 0..3; 0 % 1000 == 0 raises the SH degree

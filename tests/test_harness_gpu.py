@@ -24,6 +24,11 @@ def test_progressive_then_global_run_on_a_synthetic_sequence():
     # the second test below.)
     run = Runner(pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, row0_depth_quirk=False)
     run.progressive_run()
+    # frame 4 is a TEST frame (i_test = idx[4::8]): an unchanged train.py never renders it, its stored depth stays zero
+    # and the flow term of the next frame's tracking is the constant 0 (Runner.test_frame_quirks, train.py:333-343)
+    assert list(frames.i_test) == [4] and float(frames.pred_depths[4].abs().max()) == 0.0
+    flow_by_frame = {e[1]: e[4] for e in run.log if e[0] == "track"}
+    assert flow_by_frame[5] == 0.0 and flow_by_frame[3] > 0.0 and flow_by_frame[6] > 0.0
     rpe_t, rpe_r, ate = run.eval_pose()
     # untracked baseline: every pose left at identity
     ident = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
