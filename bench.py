@@ -28,6 +28,9 @@ for _p in (ROOT, os.path.join(ROOT, "free-surgs_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+# scene variants of the trained-like cloud: scale multiplier of every Gaussian.  "dense" brings the UPSTREAM pair count
+# (sum of rect tiles, what SURVEY.md s8d's nominal 3.0 M at C2 refers to) to ~10 tiles per Gaussian
+SCENES = {"default": 1.0, "dense": 1.62}
 CONFIGS = {
     # name: (W, H, P, scene)
     "C1": (640, 512, 20_000, "init"),
@@ -38,7 +41,7 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def build_problem(cfg_name, device, rank, world, n_frames=8):
+def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default"):
     from fsgs_amd import synth
     from fsgs_amd.model import GaussianCloud
     from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
@@ -50,6 +53,9 @@ def build_problem(cfg_name, device, rank, world, n_frames=8):
         sc = synth.init_scene(W, H, P, seed=0, knn_fn=knn)
     else:
         sc = synth.trained_like_scene(W, H, P, seed=0, knn_fn=knn)
+        if SCENES[scene] != 1.0:
+            sc = dict(sc)
+            sc["_scaling"] = (sc["_scaling"] + np.log(SCENES[scene])).astype(np.float32)
     cam = synth.make_camera(W, H)
     pc = GaussianCloud(sc, sh_degree=3, device=device, scene_radius=float(sc["depth_map"].max()) / 2.0)
     pc.cam = settings_from_cam(cam, device)
@@ -65,6 +71,29 @@ def build_problem(cfg_name, device, rank, world, n_frames=8):
     dep = torch.tensor(sc["depth_map"], device=device)
     frames = FrameData([img + 0.01 * i for i in range(n_frames)], [dep * (1 + 0.01 * i) for i in range(n_frames)])
     return pc, poses, frames, cam, sc
+
+
+def upstream_pairs(stepper, W, H):
+    """Sum over the visible Gaussians of the tiles in their 3-sigma rect: UPSTREAM's num_rendered (what SURVEY.md s8d's
+    nominal R refers to); the HIP path's own R counts only the pairs that survive the exact footprint test."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+
+    last = getattr(stepper, "last", None)
+    if not last or "state" not in last:
+        return None
+    P = int(stepper.pc.num_points)
+    off = (C.c_size_t * 9)()
+    _lib.check(_lib.load().fsgs_render_state_layout(P, W, H, int(last["max_pairs"]), off), "fsgs_render_state_layout")
+    xy = last["state"][off[0]:off[0] + 8 * P].view(torch.float32).reshape(P, 2)
+    r = last["radii_last"].float()
+    vis = r > 0
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    lo = lambda c, n: torch.clamp(torch.trunc((c - r) / 16), 0, n)
+    hi = lambda c, n: torch.clamp(torch.trunc((c + r + 15) / 16), 0, n)
+    area = (hi(xy[:, 0], gx) - lo(xy[:, 0], gx)) * (hi(xy[:, 1], gy) - lo(xy[:, 1], gy))
+    return int(area[vis].sum().item())
 
 
 def usable_cores():
@@ -169,6 +198,14 @@ def main():
                          "(PipelinedCompactReducer); default one collective: at 16.8 MB the per-collective latency of "
                          "several smaller ones eats the ~60 us of Adam they could hide")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
+    ap.add_argument("--scene", default="default", choices=sorted(SCENES),
+                    help="dense: every Gaussian 1.62x larger -> upstream pair count ~ SURVEY s8d's nominal 10 tiles per "
+                         "Gaussian (3 M at C2); the default run reports it as the extra `dense_scene` anyway")
+    ap.add_argument("--densify-every", type=int, default=0,
+                    help="> 0: densify_and_prune (device-side, csrc/densify.hip) every N steps INSIDE the timed loop, as "
+                         "train.py:305-311 does every 300 iterations -- configuration 4 as BASELINE.json states it "
+                         "(--config C4 --densify-every 300)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (raster-only timing, dense scene)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     ap.add_argument("--profile-stride", type=int, default=3,
                     help="HIP-event time every n-th launch of the dominant kernels inside the timed region (each timed "
@@ -198,7 +235,7 @@ def main():
     np.random.seed(0)
     _lib.load()
 
-    pc, poses, frames, cam, sc = build_problem(args.config, device, rank, world)
+    pc, poses, frames, cam, sc = build_problem(args.config, device, rank, world, scene=args.scene)
     W, H, P, _ = CONFIGS[args.config]
     fused = not args.two_pass
     hip_losses = not args.torch_losses
@@ -222,6 +259,22 @@ def main():
 
     # N > 1: ONE all-reduce of the compact gradient (optionally chunked and pipelined with Adam, --ar-chunks)
     reducer = fdist.PipelinedCompactReducer(args.ar_chunks) if args.ar_chunks > 1 else fdist.all_reduce_compact
+
+    densify_log = []
+
+    def maybe_densify(it):
+        """train.py:305-311 inside the timed region: statistics were accumulated by every step since the last call."""
+        if not args.densify_every or (it + 1) % args.densify_every:
+            return
+        if world > 1:
+            fdist.sync_densification_stats(pc)
+        t0d = time.perf_counter()
+        P0 = pc.num_points
+        pc.densify_and_prune_device(pc.opt.densify_grad_threshold, 0.05, None)
+        torch.cuda.synchronize()
+        densify_log.append({"step": it + 1, "P_before": P0, "P_after": pc.num_points, "ms": (time.perf_counter() - t0d) * 1e3})
+        if use_fast:
+            stepper.pc = pc
 
     def one_step(it):
         ts = (rank + it * world) % n_frames  # 1 camera per rank, a different one each step
@@ -252,6 +305,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         loss, pkg = one_step(args.warmup + it)
+        maybe_densify(it)
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
@@ -280,24 +334,73 @@ def main():
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": ms_total / launches,
                     "launches": launches, "algorithmic_bytes": b_alg, "num_rendered": R, "channels": C}
-        # HBM bytes per launch measured offline with rocprofv3 --pmc (scripts/gpu_pmc.sh, separate passes,
-        # gfx950 FETCH_SIZE x2 correction calibrated on the Adam kernel) for exactly this workload
+        # HBM bytes per launch measured offline with rocprofv3 --pmc (scripts/gpu_pmc.sh: separate passes, gfx950
+        # FETCH_SIZE x2 correction calibrated on the Adam kernel) and VALU instruction counts (scripts/gpu_sq.sh) for
+        # exactly this workload; a missing file or kernel key is an ERROR in the JSON line, never a silent null
+        key = "blend_bwd_kernel<%d; %s; false%s>" % (C, "true" if fused else "false", "; 4" if (use_fast and C == 6) else "")
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "blend_bwd_kernel<%d; %s; false%s>" % (C, "true" if fused else "false",
-                                                         "; 4" if (use_fast and C == 6) else "")
-            if pmc.get("config") == args.config and key in pmc["kernels"] and world == 1:
-                roofline["traffic"] = pmc["kernels"][key]["traffic_bytes"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
-                wi = pmc["kernels"][key].get("valu_wave_insts")
-                if wi:  # what actually bounds this kernel: VALU issue (4 cycles per wave64 instruction and SIMD)
-                    issue_s = wi * 4.0 / (256 * 4 * 2.4e9)
-                    roofline["valu"] = {"wave_insts": wi, "issue_bound_ms": issue_s * 1e3,
-                                        "frac_of_issue_bound": issue_s / avg_s,
-                                        "source": "SQ_INSTS_VALU, profiles/r01_v11_sq_counters.txt"}
-        except Exception:
-            pass
+            import glob
+
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+            if not files:
+                raise FileNotFoundError("no profiles/r*_pmc_traffic.json")
+            pmc = json.load(open(files[-1]))
+            src = os.path.relpath(files[-1], ROOT)
+            if world != 1 or pmc.get("config") != args.config or args.scene != "default" or args.densify_every:
+                roofline["traffic_note"] = "counters in %s were collected on config %s, default scene, 1 GPU" % (src, pmc.get("config"))
+            else:
+                if key not in pmc["kernels"]:
+                    raise KeyError("%s has no entry %r (kernels: %s)" % (src, key, [k for k in pmc["kernels"] if "blend" in k]))
+                ent = pmc["kernels"][key]
+                roofline["traffic"] = ent["traffic_bytes"]
+                roofline["traffic_over_algorithmic"] = ent["traffic_bytes"] / b_alg
+                roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % src
+                wi = ent.get("valu_wave_insts")
+                if wi:
+                    # what actually bounds this kernel: instruction issue.  Measured (scripts/ubench/inst_cost.hip,
+                    # profiles/r02_inst_cost_ubench.txt): a SIMD retires one plain VALU wave-instruction per ~2.0 ns
+                    # at 4 waves/SIMD and per ~1.4 ns at 8 (one wave alone: 3.8 ns) -- issue is paced per wave.
+                    per_simd = avg_s * 1e9 / (wi / 1024.0)
+                    roofline["valu"] = {"wave_insts": wi, "salu_wave_insts": ent.get("salu_wave_insts"),
+                                        "ns_per_valu_inst_per_simd": per_simd,
+                                        "ubench_ns_per_fma_at_4_and_8_waves": [2.02, 1.38],
+                                        "waves_per_simd": ent.get("waves_per_simd"),
+                                        "active_valu_cycles_per_inst": ent.get("active_valu_cycles_per_inst"),
+                                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU in %s" % src}
+        except Exception as e:  # noqa: BLE001
+            roofline["traffic_error"] = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("bench.py: roofline.traffic unavailable -- %s\n" % roofline["traffic_error"])
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1]} for k, v in prof.items()}
+
+    upstream_main = upstream_pairs(stepper, W, H) if use_fast else None
+
+    # ---- extra: the rasteriser alone (BASELINE.json: "fwd+bwd ms @1280x1024, 300k Gaussians"), rank 0 / N = 1 ----
+    # Untimed w.r.t. `value`: a second, short loop with HIP events around EVERY kernel of the fused rasteriser
+    # (preprocess + SH/activations/transform, binning, 6-channel blend, blend backward, per-Gaussian backward with the
+    # glue adjoints) and step_optimizer=False, so that no Adam work hides inside the backward kernel.
+    raster = None
+    RASTER_GROUPS = ("render_pre_fwd", "sort_depth", "sort_tile", "blend_fwd", "blend_bwd", "render_pre_bwd")
+    if use_fast and world == 1 and not args.no_extras:
+        _lib.profile_enable(list(RASTER_GROUPS), stride=1)
+        stepper.pairs_total = stepper.forward_calls = 0
+        n_r = 24
+        for it in range(n_r):
+            stepper.mapping_step([it % n_frames], step_optimizer=False)
+        torch.cuda.synchronize()
+        pr = _lib.profile_read()
+        _lib.profile_enable([])
+        Rr = int(round(stepper.pairs_total / max(stepper.forward_calls, 1)))
+        parts = {k: pr[k][0] / pr[k][1] for k in RASTER_GROUPS if k in pr and pr[k][1]}
+        if len(parts) == len(RASTER_GROUPS):
+            ms = sum(parts.values())
+            Pn = pc.num_points
+            b_r = 232 * Pn + 108 * Rr + 68 * H * W  # SURVEY.md s8d, fused 6-channel single pass, with the measured R
+            raster = {"raster_fwd_bwd_ms": ms, "kernels_ms": parts, "num_rendered": Rr,
+                      "what": "one fused 6-channel pass = both passes of render(): preprocess(+glue) + binning + blend fwd "
+                              "+ blend bwd + per-Gaussian bwd(+glue adjoints); Adam not included",
+                      "roofline_raster": {"bound": "hbm", "algorithmic_bytes": b_r, "achieved": b_r / (ms * 1e-3) / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_r / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "formula": "232 P + 108 R + 68 HW bytes (SURVEY.md s8d)"}}
 
     # ---- extra: the pose-only tracking iteration (train.py:166-200) on the same scene, rank 0 / N = 1 ----
     tracking = None
@@ -310,15 +413,42 @@ def main():
         flow_fw = torch.zeros((2, H, W), device=device)
         targets = FlowTargets(depth_prev, np.eye(4, dtype=np.float32), cam["K"], flow_fw, rigid)
         for _ in range(10):
-            stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
+            stepper.tracking_step(1, targets, None, want_losses=False)  # all-rigid frame (Runner.tracking does the same)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         nt = 40
         for _ in range(nt):
-            stepper.tracking_step(1, targets, None)  # all-rigid frame (Runner.tracking does the same)
+            stepper.tracking_step(1, targets, None, want_losses=False)
         torch.cuda.synchronize()
         tracking = {"iters_per_sec": nt / (time.perf_counter() - t1), "ms_per_iter": (time.perf_counter() - t1) / nt * 1e3,
                     "what": "render(gs_grad=False, cam_grad=True) + masked rgb loss + flow loss + pose Adam"}
+
+    # ---- extra: the same mapping step on the DENSE scene (upstream pair count ~ SURVEY s8d's nominal) ----
+    dense = None
+    if use_fast and world == 1 and not args.no_extras and args.scene == "default" and args.config in ("C2", "C4") \
+            and not args.densify_every:
+        del stepper
+        torch.cuda.empty_cache()
+        pc2, poses2, frames2, cam2, sc2 = build_problem(args.config, device, rank, world, scene="dense")
+        st2 = FastStepper(pc2, poses2, frames2)
+        for it in range(8):
+            st2.mapping_step([it % n_frames])
+        torch.cuda.synchronize()
+        _lib.profile_enable(["blend_bwd", "blend_fwd"], stride=3)
+        st2.pairs_total = st2.forward_calls = 0
+        td = time.perf_counter()
+        nd = 60
+        for it in range(nd):
+            st2.mapping_step([it % n_frames])
+        torch.cuda.synchronize()
+        dd = time.perf_counter() - td
+        pd_ = _lib.profile_read()
+        _lib.profile_enable([])
+        Rd = int(round(st2.pairs_total / max(st2.forward_calls, 1)))
+        dense = {"scene": "dense (every Gaussian x%.2f)" % SCENES["dense"], "num_rendered": Rd,
+                 "upstream_num_rendered": upstream_pairs(st2, W, H), "ms_per_step": dd / nd * 1e3, "iters_per_sec": nd / dd,
+                 "kernels_ms": {k: v[0] / v[1] for k, v in pd_.items() if v[1]}}
+        stepper = st2
 
     # ---- extra (N > 1): the step's one collective on its own, so the scaling numbers can be read ----
     comm = None
@@ -352,13 +482,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: mapping iteration, %dx%d, %d Gaussians (%s scene), 1 camera/rank" % (
                 args.config, W, H, P, CONFIGS[args.config][3]),
-                "num_rendered": R, "fused_render": fused, "hip_losses": hip_losses,
+                "num_rendered": R, "upstream_num_rendered": upstream_main,
+                "scene": args.scene, "densify_every": args.densify_every or None, "gaussians_at_end": pc.num_points,
+                "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"
                               if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step, from the all-reduced compact [P,14] gradient (fsgs_adam_step_compact)"
                               if use_fast else "FusedAdam / torch path"),
                 "parallelism": "dp%d" % world, "loss": float(loss)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels, "tracking_step": tracking, "comm": comm,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
+            "raster_fwd_bwd_ms": None if raster is None else raster["raster_fwd_bwd_ms"], "raster": raster,
+            "tracking_step": tracking, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
         }
         print(json.dumps(out))
     if world > 1:
