@@ -171,7 +171,8 @@ __device__ __forceinline__ bool splat_alpha_masked(float gx, float gy, float ca,
   e.dx = __fsub_rn(gx, px);
   e.dy = __fsub_rn(gy, py);
   const float p = splat_exponent(ca, cb, cc, e.dx, e.dy);
-  const float a = __fmul_rn(o, __builtin_amdgcn_exp2f(fminf(p, 0.0f)));
+  // (p > 0 is masked below: whatever 2^p is there -- even +inf -- only reaches the unselected side of the select)
+  const float a = __fmul_rn(o, __builtin_amdgcn_exp2f(p));
   const bool ok = live && !(p > 0.0f) && a >= (1.0f / 255.0f);
   e.a = ok ? a : 0.0f;
   e.alpha = fminf(0.99f, e.a);

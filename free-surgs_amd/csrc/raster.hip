@@ -59,9 +59,12 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   if (rc != FSGS_OK) return rc;
   if (P > 0) {
     ProfScope ps(PROF_PREPROCESS_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, opacities,
-                       scales, rotations, g);
+    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx};
+    switch (C) {  // the colours travel into the packed per-Gaussian record the blend kernels gather
+      case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, colors, opacities, scales, rotations, g); break;
+      case 3: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, colors, opacities, scales, rotations, g); break;
+      case 6: hipLaunchKernelGGL(preprocess_fwd_kernel<6>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, colors, opacities, scales, rotations, g); break;
+    }
   }
   FSGS_HIP(hipGetLastError());
   BinningTicket tk;
@@ -71,16 +74,14 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   const int2 *ranges = B.ranges;
   const uint32_t *order = B.order;
   const uint32_t *plist = B.plist;
-  const float2 *xy = B.xy;
-  const float4 *co = B.co;
-  const float *depth = B.depth;
+  const float4 *rec = B.rec;
   float *final_T = B.final_T;
   uint32_t *n_contrib = B.n_contrib;
   ProfScope ps_blend(PROF_BLEND_FWD, stream);
   switch (C) {
-    case 1: launch_blend_fwd<1>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
-    case 3: launch_blend_fwd<3>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
-    case 6: launch_blend_fwd<6>(cam, ntiles, order, ranges, plist, xy, co, depth, colors, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 1: launch_blend_fwd<1>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 3: launch_blend_fwd<3>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
+    case 6: launch_blend_fwd<6>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, out_color, out_color + 3 * (size_t)W * H, out_depth, stream); break;
   }
   FSGS_HIP(hipGetLastError());
   // only now does the host look at R (the blend is already queued behind the binning)
@@ -108,8 +109,8 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   CamParams cam = make_cam(cfg);
   const int ntiles = cam.gx * cam.gy;
   const char *sb = (const char *)state;
-  const float2 *xy = (const float2 *)(sb + SL.xy);
   const float4 *co = (const float4 *)(sb + SL.conic_op);
+  const float4 *rec = (const float4 *)(sb + SL.rec);  // colours as they were at the forward
   const int2 *ranges = (const int2 *)(sb + SL.ranges);
   const uint32_t *order = (ntiles <= ORDER_MAX_TILES && num_rendered > 0) ? (const uint32_t *)(sb + SL.order) : nullptr;
   const float *final_T = (const float *)(sb + SL.final_T);
@@ -121,9 +122,9 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   if (num_rendered > 0) {
     ProfScope ps(PROF_BLEND_BWD, stream);
     switch (C) {
-      case 1: launch_blend_bwd<1>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 3: launch_blend_bwd<3>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 6: launch_blend_bwd<6>(cam, ntiles, order, ranges, plist, xy, co, colors, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 1: launch_blend_bwd<1>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 3: launch_blend_bwd<3>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 6: launch_blend_bwd<6>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
     }
     FSGS_HIP(hipGetLastError());
   }

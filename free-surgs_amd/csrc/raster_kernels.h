@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/fsgs.h"
@@ -93,10 +94,17 @@ __device__ __forceinline__ Projected project_gaussian(const CamParams &cam, floa
   return o;
 }
 
+// What the blend kernels gather per (tile, Gaussian) pair: ONE 64-byte line per Gaussian instead of three or four
+// scattered ones (xy 8 B, conic + opacity 16 B, depth 4 B, colours 4 C B in four arrays): float4[4] =
+//   [0] mean2D x, y | conic A, B   [1] conic C | opacity | view depth | -   [2] colours 0..3   [3] colours 4..7
+// Every pair used to cost up to four cache lines from the fabric whenever the tile's XCD had not seen the Gaussian yet
+// (with the longest-first order that is almost always): 2.5x (forward) / 3.2x (backward) the algorithmic bytes.
+constexpr int kRecF4 = 4;
 struct GeomOut {  // per-Gaussian arrays written by every preprocess kernel
   float2 *xy;
   float4 *conic_op;
   float *depth;
+  float4 *rec;  // [P * kRecF4], 64-byte aligned; colours are filled in by the calling kernel
   int32_t *radii;
   uint32_t *tiles;
   ushort4 *rect;
@@ -117,14 +125,32 @@ __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const P
   g.xy[i] = o.xy;
   g.conic_op[i] = o.conic_op;
   g.depth[i] = o.tz;
+  g.rec[(size_t)i * kRecF4 + 0] = make_float4(o.xy.x, o.xy.y, o.conic_op.x, o.conic_op.y);
+  g.rec[(size_t)i * kRecF4 + 1] = make_float4(o.conic_op.z, o.conic_op.w, o.tz, 0.f);
+}
+template <int C>
+__device__ __forceinline__ void store_record_colors(float4 *rec, int i, const float *c) {
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = k < C ? c[k < C ? k : 0] : 0.f;
+  rec[(size_t)i * kRecF4 + 2] = make_float4(v[0], v[1], v[2], v[3]);
+  if (C > 4) rec[(size_t)i * kRecF4 + 3] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+template <int C>
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams cam, const float *__restrict__ means3D,
+                                                             const float *__restrict__ colors,
                                                              const float *__restrict__ opac,
                                                              const float *__restrict__ scales,
                                                              const float *__restrict__ rots, GeomOut g) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
+  {
+    float c[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) c[k] = colors[(size_t)i * C + k];
+    store_record_colors<C>(g.rec, i, c);
+  }
   float3 s = make_float3(cam.scale_modifier * scales[3 * i], cam.scale_modifier * scales[3 * i + 1],
                          cam.scale_modifier * scales[3 * i + 2]);
   float4 q = make_float4(rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]);
@@ -596,8 +622,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, 
 template <int C, bool WITH_DEPTH>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
-    const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-    const float *__restrict__ depth, const float *__restrict__ colors, float *__restrict__ final_T,
+    const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
     float *__restrict__ out_depth) {
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
@@ -634,12 +659,16 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     const int n = min(64, rg.y - base);
     // lane j gathers record j of this batch
     uint32_t g = plist[base + (lane < n ? lane : 0)];
-    float2 gxy = xy[g];
-    float4 gco = conic_op[g];
-    float gz = WITH_DEPTH ? depth[g] : 0.f;
+    const float4 *rp = grec + (size_t)g * kRecF4;  // one 64-byte line
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    const float4 q3 = C > 4 ? rp[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 gxy = make_float2(q0.x, q0.y);
+    const float4 gco = make_float4(q0.z, q0.w, q1.x, q1.y);
+    const float gz = WITH_DEPTH ? q1.z : 0.f;
+    const float g8[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
     float gcol[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)g * C + ch];
+    for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
     // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
@@ -709,6 +738,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // d = mean2D - pixel:  [0,1] sum w d_x, w d_y | [2,3,4] sum w d_x^2, w d_x d_y, w d_y^2 | [5] sum w (= dL/dopacity)
 // | [6,7] as [0,1] for the RGB channels only (SPLIT).  8 floats stride; dcolors go straight to the output tensor.
 constexpr int kAccStride = 8;
+// The fused render keeps moments AND colour sums of a Gaussian in ONE 64-byte row, [0..7] moments | [8..13] colours:
+// the up to 12 atomics a (tile, Gaussian) pair issues land in one cache line instead of two or three.
+constexpr int kFusedRow = 16;
 
 // Moments -> the gradients of SURVEY.md A.4.  The moments arrive multiplied by the opacity (w o = a dL/dalpha, see
 // SplatEval): dL/dmean2D (pixel units) = -(A m0 + B m1, C m1 + B m0), dL/dconic (A,B,C) = -(m2/2, m3, m4/2),
@@ -738,10 +770,10 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C>
 __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
-    const uint32_t *__restrict__ plist, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-    const float *__restrict__ colors, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2, float *__restrict__ grad_acc,
-    float *__restrict__ dcolors, float *__restrict__ clear16) {
+    const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
+    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16, int acc_stride,
+    int col_stride) {
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   // 16 floats the NEXT kernel accumulates into with atomics (dL/dw2c): cleared here instead of by a separate fill
   if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) clear16[threadIdx.x] = 0.f;
@@ -803,11 +835,15 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
     uint32_t gid = plist[rg.x + lo + (lane < n ? lane : 0)];
-    float2 gxy = xy[gid];
-    float4 gco = conic_op[gid];
+    const float4 *rp = grec + (size_t)gid * kRecF4;  // one 64-byte line
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    const float4 q3 = C > 4 ? rp[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 gxy = make_float2(q0.x, q0.y);
+    const float4 gco = make_float4(q0.z, q0.w, q1.x, q1.y);
+    const float g8[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
     float gcol[C];
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) gcol[ch] = colors[(size_t)gid * C + ch];
+    for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     __syncthreads();  // records of the previous batch fully consumed
     const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
@@ -890,8 +926,8 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
         gsel = my_u == u ? gu : gsel;
       }
       if (j_mine >= 0 && c_used && tot != 0.f) {
-        float *dst = (POSE_ONLY || my_c < 8) ? grad_acc + (size_t)gsel * kAccStride + my_c
-                                             : dcolors + (size_t)gsel * C + (my_c - 8);
+        float *dst = (POSE_ONLY || my_c < 8) ? grad_acc + (size_t)gsel * acc_stride + my_c
+                                             : dcolors + (size_t)gsel * col_stride + (my_c - 8);
         atomicAdd(dst, tot);
       }
     }
@@ -1059,9 +1095,9 @@ int tile_bits(int ntiles) {
 }
 
 struct StateLayout {
-  size_t xy, conic_op, depth, ranges, order, final_T, n_contrib, plist, colors, flags, total;
+  size_t xy, conic_op, depth, ranges, order, final_T, n_contrib, plist, colors, flags, rec, total;
 };
-// keep_channels > 0: the fused render also keeps colours[P, keep_channels] and a flag byte per Gaussian
+// keep_channels > 0 (fused render): also a clamp-flag word per Gaussian (the colours live in the packed records)
 StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0) {
   StateLayout L;
   Carver c;
@@ -1074,9 +1110,10 @@ StateLayout state_layout(int P, int W, int H, int64_t cap, int keep_channels = 0
   L.final_T = c.take(sizeof(float) * (size_t)W * H);
   L.n_contrib = c.take(sizeof(uint32_t) * (size_t)W * H);
   L.plist = c.take(sizeof(uint32_t) * (size_t)cap);
+  L.rec = c.take(sizeof(float4) * kRecF4 * (size_t)(P > 0 ? P : 1));
   L.colors = L.flags = 0;
   if (keep_channels > 0) {
-    L.colors = c.take(sizeof(float) * (size_t)P * keep_channels);
+    L.colors = 0;
     L.flags = c.take((size_t)P * 4);
   }
   L.total = c.total();
@@ -1102,7 +1139,7 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
 
 struct FwdBuffers {
   float2 *xy; float4 *co; float *depth; int2 *ranges; uint32_t *order; float *final_T; uint32_t *n_contrib; uint32_t *plist;
-  float *colors; uint32_t *flags;
+  float *colors; uint32_t *flags; float4 *rec;
   uint32_t *tiles; ushort4 *rect; uint32_t *tile_count; uint32_t *total; unsigned long long *keys;
 };
 int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channels, void *state, size_t state_bytes,
@@ -1115,7 +1152,8 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   B.xy = (float2 *)(sb + SL.xy); B.co = (float4 *)(sb + SL.conic_op); B.depth = (float *)(sb + SL.depth);
   B.ranges = (int2 *)(sb + SL.ranges); B.order = (uint32_t *)(sb + SL.order); B.final_T = (float *)(sb + SL.final_T);
   B.n_contrib = (uint32_t *)(sb + SL.n_contrib); B.plist = (uint32_t *)(sb + SL.plist);
-  B.colors = keep_channels ? (float *)(sb + SL.colors) : nullptr;
+  B.rec = (float4 *)(sb + SL.rec);
+  B.colors = nullptr;
   B.flags = keep_channels ? (uint32_t *)(sb + SL.flags) : nullptr;
   B.tiles = (uint32_t *)(xb + XL.tiles); B.rect = (ushort4 *)(xb + XL.rect);
   B.tile_count = (uint32_t *)(xb + XL.tile_count); B.total = (uint32_t *)(xb + XL.total);
@@ -1184,20 +1222,22 @@ inline int finish_binning(const CamParams &cam, FwdBuffers &B, int64_t max_pairs
 }
 
 template <int C, bool WITH_DEPTH = true>
-int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
-                     const float4 *co, const float *depth, const float *colors, float *final_T, uint32_t *n_contrib,
+int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
+                     const float4 *rec, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
-  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy,
-                     co, depth, colors, final_T, n_contrib, out_color, out_color2, out_depth);
+  static int dbg_lds = getenv("FSGS_DBG_LDS_FWD") ? atoi(getenv("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
+  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
+                     final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C>
-int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist, const float2 *xy,
-                     const float4 *co, const float *colors, const float *final_T, const uint32_t *n_contrib,
+int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
+                     const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
-                     float *clear16 = nullptr) {
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD>), dim3(ntiles), dim3(64), 0, s, cam, ntiles, order, ranges, plist, xy, co,
-                     colors, final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
+                     float *clear16 = nullptr, int acc_stride = kAccStride, int col_stride = C) {
+  static int dbg_lds = getenv("FSGS_DBG_LDS") ? atoi(getenv("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
+                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, acc_stride, col_stride);
   return 0;
 }
 

@@ -146,7 +146,6 @@ __device__ __forceinline__ void stage_out(float *dst, const float *lds, size_t f
 }
 
 __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
-                                                             float *__restrict__ colors6,
                                                              uint32_t *__restrict__ flags) {
   __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
   const int b0 = blockIdx.x * blockDim.x;
@@ -186,8 +185,10 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   // depth pseudo-colours: row 2 of cam.viewmatrix[0] AS STORED times [x_cam;1] (scene/gaussian_model.py:266-271)
   const float *V = cam.V;
   float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
-  float *c6 = colors6 + (size_t)i * 6;
-  c6[0] = rgb[0]; c6[1] = rgb[1]; c6[2] = rgb[2]; c6[3] = zq; c6[4] = 1.0f; c6[5] = zq * zq;
+  {
+    const float cc[6] = {rgb[0], rgb[1], rgb[2], zq, 1.0f, zq * zq};
+    store_record_colors<6>(g.rec, i, cc);  // what the blend kernels gather (one 64-byte line per Gaussian)
+  }
   flags[i] = fl;
   float3 s = make_float3(cam.scale_modifier * act.scale.x, cam.scale_modifier * act.scale.y,
                          cam.scale_modifier * act.scale.z);
@@ -364,12 +365,13 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     sink.prefetch(i);  // OUT_ADAM: parameters and moments of the small groups
     raw = load_raw(a, i);
     rad = radii[i];
-    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kAccStride);
-    const float4 a0 = ap[0], a1 = ap[1];
+    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kFusedRow);  // one 64-byte row: moments | colour sums
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    const float2 a3 = *(const float2 *)(ap + 3);
     acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+    dc[0] = a2.x; dc[1] = a2.y; dc[2] = a2.z; dc[3] = a2.w; dc[4] = a3.x; dc[5] = a3.y;
     co = conic_op[i];
-#pragma unroll
-    for (int c = 0; c < 6; c++) dc[c] = dcolors6[(size_t)i * 6 + c];
+    (void)dcolors6;
     if (mode & MODE_PARAM_GRAD) fl = flags[i];
   }
   float st_mr = 0.f, st_acc = 0.f, st_den = 0.f;  // densification statistics of this Gaussian (read-modify-write)
@@ -584,7 +586,7 @@ int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *s
   *state_bytes = state_layout(P, width, height, max_pairs, 6).total;
   ScratchLayout sl;
   scratch_layout(P, width, height, max_pairs, sl);
-  size_t bwd = (size_t)(P > 0 ? P : 1) * (kAccStride + 6) * sizeof(float) + 512;
+  size_t bwd = (size_t)(P > 0 ? P : 1) * kFusedRow * sizeof(float) + 512;
   *scratch_bytes = sl.total_bytes > bwd ? sl.total_bytes : bwd;
   return FSGS_OK;
 }
@@ -593,7 +595,7 @@ int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, si
   if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !offsets) return FSGS_ERR_INVALID;
   StateLayout L = state_layout(P, width, height, max_pairs, 6);
   offsets[0] = L.xy; offsets[1] = L.conic_op; offsets[2] = L.depth; offsets[3] = L.ranges;
-  offsets[4] = L.final_T; offsets[5] = L.n_contrib; offsets[6] = L.plist; offsets[7] = L.colors; offsets[8] = L.flags;
+  offsets[4] = L.final_T; offsets[5] = L.n_contrib; offsets[6] = L.plist; offsets[7] = L.rec; offsets[8] = L.flags;
   return FSGS_OK;
 }
 
@@ -614,9 +616,9 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (rc != FSGS_OK) return rc;
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, radii, B.tiles, B.rect, B.tile_count, cam.gx};
+    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx};
     hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args), g,
-                       B.colors, B.flags);
+                       B.flags);
   }
   FSGS_HIP(hipGetLastError());
   BinningTicket tk;
@@ -625,7 +627,7 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (rc != FSGS_OK) return rc;
   {
     ProfScope ps(PROF_BLEND_FWD, stream);
-    launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.xy, B.co, B.depth, B.colors, B.final_T,
+    launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
                                B.n_contrib, out_image, out_depth_sil, nullptr, stream);
   }
   FSGS_HIP(hipGetLastError());
@@ -694,7 +696,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   if (max_pairs < 0 || num_rendered < 0 || num_rendered > max_pairs) return FSGS_ERR_STATE;
   StateLayout SL = state_layout(P, W, H, max_pairs, 6);
   if (state_bytes < SL.total) return FSGS_ERR_STATE;
-  const size_t need = (size_t)P * (kAccStride + 6) * sizeof(float);
+  const size_t need = (size_t)P * kFusedRow * sizeof(float);
   if (scratch_bytes < need) return FSGS_ERR_CAPACITY;
   if (((uintptr_t)scratch) & 15) return FSGS_ERR_INVALID;  // the accumulator rows are read as float4
   CamParams cam = make_cam(cfg);
@@ -702,7 +704,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   const int ntiles = cam.gx * cam.gy;
   const char *sb = (const char *)state;
   float *grad_acc = (float *)scratch;
-  float *dcolors6 = grad_acc + (size_t)P * kAccStride;
+  float *dcolors6 = grad_acc + 8;  // floats 8..13 of every Gaussian's 64-byte row
   if (!(cfg->flags & FSGS_FLAG_SCRATCH_ZEROED)) FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
   const bool blend = num_rendered > 0 && (dL_dimage || dL_ddepth_sil);
   const bool pose_only_path = blend && cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
@@ -716,29 +718,25 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
     const bool pose_only = cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
     if (pose_only)
       launch_blend_bwd<6, false, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
-                                       (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
-                                       (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                       (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c);
+                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c, kFusedRow, kFusedRow);
     else if ((cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY) && !grads->means2D)
       // nobody wants the densification statistic (means2D_grad == NULL): the RGB-only mean2D moments are dropped too
       launch_blend_bwd<6, false, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
-                                           (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
-                                           (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                           (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                            (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, kFusedRow, kFusedRow);
     else if (cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY)  // dL_ddepth_sil is [1,H,W]: planes 1, 2 carry no gradient
       launch_blend_bwd<6, true, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
-                                          (const uint32_t *)(sb + SL.plist), (const float2 *)(sb + SL.xy),
-                                          (const float4 *)(sb + SL.conic_op), (const float *)(sb + SL.colors),
+                                          (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                           (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, kFusedRow, kFusedRow);
     else
       launch_blend_bwd<6, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
-                                (const float2 *)(sb + SL.xy), (const float4 *)(sb + SL.conic_op),
-                                (const float *)(sb + SL.colors), (const float *)(sb + SL.final_T),
+                                (const float4 *)(sb + SL.rec), (const float *)(sb + SL.final_T),
                                 (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
-                                stream);
+                                stream, nullptr, kFusedRow, kFusedRow);
   }
   FSGS_HIP(hipGetLastError());
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);

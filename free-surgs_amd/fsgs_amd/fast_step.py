@@ -63,7 +63,7 @@ class _Buffers:
         self.gc = self.gc_view = None  # compact gradient [P,14] (lazily: only multi-view / multi-rank steps)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
-        self.bwd_scratch = torch.empty((P * 56 + 512,), dtype=torch.uint8, device=dev)
+        self.bwd_scratch = torch.empty((P * 64 + 512,), dtype=torch.uint8, device=dev)
         self.sizes = {}
 
 

@@ -62,7 +62,7 @@ enum {
  * planes get no gradient from any loss of the reference (train.py:166-272: rgb + Pearson(depth); the presence
  * mask and the uncertainty are detached), and the backward blend drops their terms */
 #define FSGS_FLAG_DEPTH_GRAD_ONLY 2
-/* fsgs_render_backward*: the caller has already zeroed the first P * 56 bytes of `scratch` (e.g. on another stream,
+/* fsgs_render_backward*: the caller has already zeroed the first P * 64 bytes of `scratch` (e.g. on another stream,
  * beside the loss kernels); the call does not enqueue its own fill in front of the backward blend */
 #define FSGS_FLAG_SCRATCH_ZEROED 4
 
@@ -178,9 +178,11 @@ typedef struct FsgsRenderGrads {
 
 int fsgs_render_sizes(int P, int width, int height, int64_t max_pairs, size_t *state_bytes, size_t *scratch_bytes);
 /* Byte offsets inside the fused render's `state` (tests / debugging / a viewer): [0..6] as fsgs_raster_state_layout,
- * [7] per-Gaussian colours float[P,6] = (r, g, b | z, 1, z^2): clamp_min(eval_sh + 0.5, 0) and the depth / silhouette
- * pseudo-colours (scene/gaussian_model.py:260-275,316-320), [8] flag word uint32[P] (bit c = colour channel c
- * was clamped at 0). */
+ * [7] the packed per-Gaussian records float[P,16] the blend kernels gather, ONE 64-byte line per Gaussian:
+ *     floats 0,1 mean2D (pixels) | 2,3,4 conic A,B,C | 5 opacity | 6 view depth | 7 - | 8..13 colours
+ *     (r, g, b | z, 1, z^2) = clamp_min(eval_sh + 0.5, 0) and the depth / silhouette pseudo-colours
+ *     (scene/gaussian_model.py:260-275,316-320) | 14,15 -,
+ * [8] flag word uint32[P] (bit c = colour channel c was clamped at 0). */
 int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, size_t offsets[9]);
 
 /* out_image [3,H,W] = the RGB pass; out_depth_sil [3,H,W] = (depth, silhouette, depth^2) pass of
@@ -195,7 +197,8 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
  * gs_grad routes the mean gradient to xyz, cam_grad reduces dL/dw2c.  param_grads = 0 skips the
  * gradients of features / opacity / scaling / rotation (pose-only backward of the tracking step,
  * observationally equivalent because train.py:220 discards them; SURVEY.md a1 note v).
- * scratch: >= P * 56 bytes, 16-byte aligned (FSGS_ERR_INVALID otherwise). */
+ * scratch: >= P * 64 bytes (one 64-byte accumulator row per Gaussian), 16-byte aligned (FSGS_ERR_INVALID otherwise;
+ * fsgs_render_sizes covers it). */
 int fsgs_render_backward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil,

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/sq && mkdir -p /tmp/sq
-timeout -k 5 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/sq -o sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking > gpurun_out/sq.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/sq -o sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-extras > gpurun_out/sq.log 2>&1
 f=$(find /tmp/sq -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections, re

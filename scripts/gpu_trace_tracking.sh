@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/trk && mkdir -p /tmp/trk
-timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/trk -o tr -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/trace_trk.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/trk -o tr -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/trace_trk.log 2>&1
 f=$(find /tmp/trk -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, re

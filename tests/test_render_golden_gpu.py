@@ -41,7 +41,7 @@ class Fused:
         _lib.check(lib.fsgs_render_sizes(P, W, H, self.cap, C.byref(sb), C.byref(xb)), "sizes")
         self.sb = sb.value
         self.state = torch.zeros((sb.value,), dtype=torch.uint8, device=DEV)
-        self.scratch = torch.zeros((max(xb.value, P * 56 + 512),), dtype=torch.uint8, device=DEV)
+        self.scratch = torch.zeros((max(xb.value, P * 64 + 512),), dtype=torch.uint8, device=DEV)
         nr = C.c_int64(0)
         _lib.check(lib.fsgs_render_forward(C.byref(self.cfg), P, C.byref(self.args), _lib.ptr(self.image),
                                            _lib.ptr(self.depth_sil), _lib.ptr(self.radii), _lib.ptr(self.state), sb.value,
@@ -51,7 +51,8 @@ class Fused:
         off = (C.c_size_t * 9)()
         _lib.check(lib.fsgs_render_state_layout(P, W, H, self.cap, off), "layout")
         view = lambda i, n, shape: self.state[off[i]:off[i] + 4 * n].view(torch.float32).reshape(shape)
-        self.xy, self.depth, self.colors = view(0, 2 * P, (P, 2)), view(2, P, (P,)), view(7, 6 * P, (P, 6))
+        # [7]: the packed records the blend kernels gather, floats 8..13 of each 64-byte row are the six colours
+        self.xy, self.depth, self.colors = view(0, 2 * P, (P, 2)), view(2, P, (P,)), view(7, 16 * P, (P, 16))[:, 8:14]
         torch.cuda.synchronize()
 
     def backward(self, d_image, d_depth_sil=None):
