@@ -194,9 +194,10 @@ def main():
                     help="mapping iteration WITHOUT the densification statistics (the second half of global_run: "
                          "iteration >= 15000); the default keeps them, as the first 15000 iterations do")
     ap.add_argument("--ar-chunks", type=int, default=1,
-                    help="N > 1: > 1 splits the gradient all-reduce into row chunks pipelined with the Adam kernel "
-                         "(PipelinedCompactReducer); default one collective: at 16.8 MB the per-collective latency of "
-                         "several smaller ones eats the ~60 us of Adam they could hide")
+                    help="N > 1: > 1 produces the compact gradient in that many row chunks and starts each chunk's "
+                         "all-reduce while the next is produced, Adam per chunk behind it (dist.ProducerPipelinedReducer); "
+                         "default one collective: whether the extra collective launches pay depends on the fabric -- "
+                         "the driver's scaling run decides")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
     ap.add_argument("--scene", default="default", choices=sorted(SCENES),
                     help="dense: every Gaussian 1.62x larger -> upstream pair count ~ SURVEY s8d's nominal 10 tiles per "
@@ -258,7 +259,7 @@ def main():
         stepper = FastStepper(pc, poses, frames)
 
     # N > 1: ONE all-reduce of the compact gradient (optionally chunked and pipelined with Adam, --ar-chunks)
-    reducer = fdist.PipelinedCompactReducer(args.ar_chunks) if args.ar_chunks > 1 else fdist.all_reduce_compact
+    reducer = fdist.ProducerPipelinedReducer(args.ar_chunks) if args.ar_chunks > 1 else fdist.all_reduce_compact
 
     densify_log = []
 
@@ -469,6 +470,26 @@ def main():
                 "backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                 "devices": torch.cuda.device_count(), "one_gpu_smoke": os.environ.get("FSGS_DIST_ONE_GPU") == "1"}
 
+    # ---- extra (N > 1): the same step with the exchange pipelined on the producer side, so that the scaling record
+    # shows what hiding the collective behind the per-Gaussian backward and Adam is worth on this fabric ----
+    pipelined = None
+    if world > 1 and use_fast and not args.no_extras and args.ar_chunks == 1:
+        red4 = fdist.ProducerPipelinedReducer(4)
+        for it in range(5):
+            stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
+        barrier()
+        tp = time.perf_counter()
+        npipe = 40
+        for it in range(npipe):
+            stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
+        barrier()
+        dtp = time.perf_counter() - tp
+        tt = torch.tensor([dtp], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        pipelined = {"ar_chunks": 4, "ms_per_step": float(tt.item()) / npipe * 1e3, "iters_per_sec": npipe * world / float(tt.item()),
+                     "what": "dist.ProducerPipelinedReducer(4): all-reduce of row chunk i beside the production of chunk "
+                             "i+1 and the Adam of chunk i-1 (python bench.py --ar-chunks 4 makes it the timed route)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sc, cam, pc.active_sh_degree)
@@ -493,6 +514,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
             "raster_fwd_bwd_ms": None if raster is None else raster["raster_fwd_bwd_ms"], "raster": raster,
             "tracking_step": tracking, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
+            "comm_pipelined": pipelined,
         }
         print(json.dumps(out))
     if world > 1:

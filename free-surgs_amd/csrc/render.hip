@@ -344,12 +344,15 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
                                                              const float *__restrict__ grad_acc,
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
-                                                             RenderGradsDev out, AdamDev ad, StepTailDev tail) {
+                                                             RenderGradsDev out, AdamDev ad, StepTailDev tail,
+                                                             int row0) {
+  // Gaussians [row0, P) of this launch (row0 = 0, P = all of them, except for the row chunks of
+  // fsgs_render_backward_compact_rows, where P is the END of the chunk and row0 a multiple of RB)
   GradSink<OUT> sink{out, a, ad};
   constexpr bool ADAM = OUT == OUT_ADAM;
   __shared__ float red[12][RB / 64];
   __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];  // coefficients in, their gradients out
-  const int b0 = blockIdx.x * blockDim.x;
+  const int b0 = row0 + blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;
   const bool stage = (mode & MODE_PARAM_GRAD) && row > 0;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     st_acc = tail.accum[i];
     st_den = tail.denom[i];
   }
-  if (tail.total && blockIdx.x == 0 && threadIdx.x == 0) {  // the iteration's scalar loss (reporting only)
+  if (tail.total && b0 == 0 && threadIdx.x == 0) {  // the iteration's scalar loss (reporting only)
     float t = 0.f;
     for (int k = 0; k < tail.n_terms; k++) t = fmaf(tail.terms[k], tail.weights[k], t);
     tail.total[0] = t;
@@ -663,9 +666,12 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
                          const float *dL_dimage, const float *dL_ddepth_sil, int gs_grad, int cam_grad,
                          int param_grads, const FsgsRenderGrads *grads, const FsgsFusedAdam *adam, float *compact,
-                         const FsgsStepTail *tail, void *scratch, size_t scratch_bytes, fsgs_stream_t stream_) {
+                         const FsgsStepTail *tail, void *scratch, size_t scratch_bytes, fsgs_stream_t stream_,
+                         int row_lo = 0, int row_hi = -1, bool run_blend = true) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !state || !grads) return FSGS_ERR_INVALID;
+  if (row_hi < 0) row_hi = P;
+  if (row_lo < 0 || row_lo > row_hi || row_hi > P || (row_lo % RB) != 0) return FSGS_ERR_INVALID;
   if (P == 0) {  // an emptied cloud: nothing to differentiate, but the iteration still reports its loss
     if (cam_grad && grads->w2c) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));  // dL/dw2c = 0
     if (tail && tail->loss_total) {
@@ -705,8 +711,8 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   const char *sb = (const char *)state;
   float *grad_acc = (float *)scratch;
   float *dcolors6 = grad_acc + 8;  // floats 8..13 of every Gaussian's 64-byte row
-  if (!(cfg->flags & FSGS_FLAG_SCRATCH_ZEROED)) FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
-  const bool blend = num_rendered > 0 && (dL_dimage || dL_ddepth_sil);
+  if (run_blend && !(cfg->flags & FSGS_FLAG_SCRATCH_ZEROED)) FSGS_HIP(hipMemsetAsync(scratch, 0, need, stream));
+  const bool blend = run_blend && num_rendered > 0 && (dL_dimage || dL_ddepth_sil);
   const bool pose_only_path = blend && cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
   // dL/dw2c is accumulated with atomics by the preprocess backward: cleared by the blend kernel in front of it
   // (tracking), by a fill otherwise
@@ -754,20 +760,20 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
       td.total = tail->loss_total;
     }
   }
-  {
+  if (row_hi > row_lo) {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     if (adam)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
-                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
+                         cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
     else if (compact)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
-                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
+                         cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
     else
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
-                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td);
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
+                         cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
+                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
@@ -810,6 +816,20 @@ int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRend
   g.means2D = means2D_grad;
   return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
                               dL_ddepth_sil, 1, 0, 1, &g, nullptr, gcompact, tail, scratch, scratch_bytes, stream);
+}
+
+int fsgs_render_backward_compact_rows(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                                      const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                                      const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
+                                      float *means2D_grad, const FsgsStepTail *tail, void *scratch,
+                                      size_t scratch_bytes, int row_lo, int row_hi, int first, fsgs_stream_t stream) {
+  if (!gcompact && P > 0) return FSGS_ERR_INVALID;
+  FsgsRenderGrads g;
+  std::memset(&g, 0, sizeof(g));
+  g.means2D = means2D_grad;
+  return render_backward_impl(cfg, P, args, radii, state, state_bytes, max_pairs, num_rendered, dL_dimage,
+                              dL_ddepth_sil, 1, 0, 1, &g, nullptr, gcompact, tail, scratch, scratch_bytes, stream,
+                              row_lo, row_hi, first != 0);
 }
 
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,

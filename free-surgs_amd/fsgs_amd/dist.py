@@ -114,6 +114,70 @@ class PipelinedCompactReducer:
             adam_rows(lo, hi)
 
 
+class ProducerPipelinedReducer:
+    """Producer-side pipelining of the step's one exchange: the per-Gaussian backward is launched in
+    `nchunks` row chunks (fsgs_render_backward_compact_rows) and the all-reduce of chunk i starts on a second stream as
+    soon as chunk i is produced -- beside the production of chunks i+1.. -- and Adam consumes chunk i as soon as its
+    all-reduce is done, beside the all-reduces still in flight:
+
+        main : blend_bwd | pre_bwd 0 | pre_bwd 1 | pre_bwd 2 | pre_bwd 3 |      Adam 0 | Adam 1 | Adam 2 | Adam 3
+        comm :                       |   AR 0    |   AR 1    |   AR 2    |   AR 3   |
+
+    instead of  blend_bwd | pre_bwd | AR | Adam.  What it can hide is the per-Gaussian backward (~50 us at C2) and all but
+    the last chunk's Adam (~60 of 78 us); the price is nchunks - 1 extra collective launches.  Chunk boundaries are
+    multiples of 256 Gaussians (the workgroup of both kernels).  With CPU tensors (gloo tests) the same calls run in
+    order without streams."""
+
+    producer = True
+    pipelined = True
+
+    def __init__(self, nchunks=4):
+        self.nchunks = max(1, int(nchunks))
+        self.side = None
+        self._pending = []
+
+    def bounds(self, P):
+        per = -(-int(P) // self.nchunks)
+        per = max(256, -(-per // 256) * 256)
+        return [(lo, min(int(P), lo + per)) for lo in range(0, int(P), per)]
+
+    def produced(self, gc, lo, hi):
+        """rows [lo, hi) of gc are final on the current stream: start their all-reduce."""
+        live = dist.is_initialized() and dist.get_world_size() > 1
+        if not gc.is_cuda:
+            if live:
+                dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)
+            self._pending.append((lo, hi, None))
+            return
+        main = torch.cuda.current_stream(gc.device)
+        if self.side is None or self.side.device != gc.device:
+            self.side = torch.cuda.Stream(device=gc.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            if live:
+                dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)
+            done.record(self.side)
+        gc.record_stream(self.side)
+        self._pending.append((lo, hi, done))
+
+    def finish(self, adam_rows):
+        """Adam for every chunk, each as soon as its all-reduce has landed (in production order)."""
+        pending, self._pending = self._pending, []
+        for lo, hi, done in pending:
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
+            adam_rows(lo, hi)
+
+    def __call__(self, gc, adam_rows):
+        """consumer-side fallback (several views per step: the gradient is only final after the last view)."""
+        for lo, hi in self.bounds(gc.shape[0]):
+            self.produced(gc, lo, hi)
+        self.finish(adam_rows)
+
+
 def sync_gradients(pc, bucket=None):
     """all-reduce(SUM) of the Gaussian gradients.  With a bucket attached before backward this is a
     single collective on one contiguous buffer; otherwise gradients are packed first."""

@@ -335,13 +335,25 @@ class FastStepper:
                     m2 = b.means2D_grad if (first and collect_stats) else None
                     cfg = self._cfg_zeroed()
                     tail, loss_k, _keep = self._step_tail(b, b.term_w, first and collect_stats)
-                    _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
-                                                                _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
-                                                                _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
-                                                                _lib.ptr(tgt_gc), None if m2 is None else _lib.ptr(m2),
-                                                                C.byref(tail), _lib.ptr(b.bwd_scratch),
-                                                                b.bwd_scratch.numel(), stream),
-                               "fsgs_render_backward_compact")
+                    # one view per step and a producer-side reducer (N > 1): the per-Gaussian backward goes out in row
+                    # chunks, the all-reduce of each chunk starts while the next one is produced (dist.py)
+                    produce = (len(timesteps) == 1 and getattr(reduce_compact, "producer", False))
+                    if produce:
+                        for ci, (lo, hi) in enumerate(reduce_compact.bounds(pc.num_points)):
+                            _lib.check(lib.fsgs_render_backward_compact_rows(
+                                C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
+                                _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil), _lib.ptr(tgt_gc),
+                                None if m2 is None else _lib.ptr(m2), C.byref(tail), _lib.ptr(b.bwd_scratch),
+                                b.bwd_scratch.numel(), lo, hi, int(ci == 0), stream), "fsgs_render_backward_compact_rows")
+                            reduce_compact.produced(tgt_gc, lo, hi)
+                    else:
+                        _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
+                                                                    _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
+                                                                    _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
+                                                                    _lib.ptr(tgt_gc), None if m2 is None else _lib.ptr(m2),
+                                                                    C.byref(tail), _lib.ptr(b.bwd_scratch),
+                                                                    b.bwd_scratch.numel(), stream),
+                                   "fsgs_render_backward_compact")
                     if first:
                         stats_done = collect_stats
                     else:
@@ -364,6 +376,8 @@ class FastStepper:
 
                         if reduce_compact is None:
                             adam_rows(0, pc.num_points)
+                        elif produce:
+                            reduce_compact.finish(adam_rows)  # Adam per chunk, each behind its own all-reduce
                         elif getattr(reduce_compact, "pipelined", False):
                             reduce_compact(b.gc, adam_rows)  # chunked: all-reduce of chunk i+1 beside Adam of chunk i
                         else:

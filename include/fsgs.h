@@ -252,6 +252,16 @@ int fsgs_render_backward_compact(const FsgsRasterCfg *cfg, int P, const FsgsRend
                                  const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
                                  float *means2D_grad, const FsgsStepTail *tail, void *scratch, size_t scratch_bytes,
                                  fsgs_stream_t stream);
+/* The same in ROW CHUNKS, for producer-side pipelining of the multi-GPU step: the first call (first = 1) runs the blend
+ * backward over the whole image and the per-Gaussian backward of Gaussians [row_lo, row_hi); every further call
+ * (first = 0) only the per-Gaussian backward of its rows.  row_lo must be a multiple of 256.  The caller records an
+ * event after each call and starts that chunk's all-reduce (56 B per Gaussian) on a second stream while the next
+ * chunk is still being produced; fsgs_adam_step_compact then consumes chunk by chunk (fsgs_amd/dist.py). */
+int fsgs_render_backward_compact_rows(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, const int32_t *radii,
+                                      const void *state, size_t state_bytes, int64_t max_pairs, int64_t num_rendered,
+                                      const float *dL_dimage, const float *dL_ddepth_sil, float *gcompact,
+                                      float *means2D_grad, const FsgsStepTail *tail, void *scratch,
+                                      size_t scratch_bytes, int row_lo, int row_hi, int first, fsgs_stream_t stream);
 /* Adam step of the six groups from the (summed / all-reduced) compact gradient: the SH outer products are formed
  * on the fly.  Updates args->xyz ... args->rotation and the moments in place; args->w2c is not read. */
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,

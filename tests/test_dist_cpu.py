@@ -98,10 +98,31 @@ def _compact_worker(rank, world, port, out_dir):
 
     fdist.PipelinedCompactReducer(3)(gc, adam_rows)
     assert seen[0][0] == 0 and seen[-1][1] == P and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    # producer-side: chunks are handed over one by one as they are "produced" (rows beyond the produced ones still hold
+    # this rank's partial sums); Adam runs per chunk, in production order, only on rows whose all-reduce is done
+    gc = base * (rank + 1)
+    seen.clear()
+    red = fdist.ProducerPipelinedReducer(3)
+    bounds = red.bounds(P)
+    assert bounds[0][0] == 0 and bounds[-1][1] == P and all(lo % 256 == 0 for lo, _ in bounds) and len(bounds) == 2
+    for n, (lo, hi) in enumerate(bounds):
+        red.produced(gc, lo, hi)
+        assert torch.equal(gc[lo:hi], base[lo:hi] * 3)
+        if n + 1 < len(bounds):
+            nlo, nhi = bounds[n + 1]
+            assert torch.equal(gc[nlo:nhi], base[nlo:nhi] * (rank + 1))  # not yet exchanged
+    red.finish(adam_rows)
+    assert seen == bounds and red._pending == []
+    # and its consumer-side form (several views per step)
+    gc = base * (rank + 1)
+    seen.clear()
+    fdist.ProducerPipelinedReducer(2)(gc, adam_rows)
+    assert [s[0] for s in seen] == [0, 512] and seen[-1][1] == P
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_compact_gradient_reducers():
-    """all_reduce_compact / PipelinedCompactReducer (fsgs_amd/dist.py): the [P,14] gradient of the HIP step driver."""
+    """all_reduce_compact / PipelinedCompactReducer / ProducerPipelinedReducer (fsgs_amd/dist.py): the [P,14] gradient
+    of the HIP step driver, as one collective, consumer-side chunks and producer-side chunks."""
     mp.spawn(_compact_worker, args=(2, _free_port(), ""), nprocs=2, join=True)

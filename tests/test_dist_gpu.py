@@ -71,8 +71,10 @@ def _worker(rank, world, port, out_dir, mode):
             assert all(pc.params[k].grad.data_ptr() == bucket.views[k].data_ptr() for k in PARAM_NAMES)
         elif mode == "compact":  # compact [P,14] gradient, one all-reduce, Adam from the compact form
             loss = fs.mapping_step([rank], reduce_compact=fdist.all_reduce_compact, corners=cr)
-        else:  # the same in three row chunks, all-reduce of chunk i+1 beside the Adam kernel of chunk i
+        elif mode == "pipelined":  # the same in three row chunks, all-reduce of chunk i+1 beside the Adam kernel of chunk i
             loss = fs.mapping_step([rank], reduce_compact=fdist.PipelinedCompactReducer(3), corners=cr)
+        else:  # producer-side: the per-Gaussian backward itself goes out in row chunks, each all-reduced as it is made
+            loss = fs.mapping_step([rank], reduce_compact=fdist.ProducerPipelinedReducer(3), corners=cr)
     torch.cuda.synchronize()
     torch.save({k: pc.params[k].detach().cpu() for k in PARAM_NAMES} | {"loss": loss.detach().cpu()},
                os.path.join(out_dir, "rank%d.pt" % rank))
@@ -80,7 +82,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["compact", "pipelined", "bucket"])
+@pytest.mark.parametrize("mode", ["compact", "pipelined", "producer", "bucket"])
 def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
     from fsgs_amd.fast_step import FastStepper
     from fsgs_amd.model import PARAM_NAMES
