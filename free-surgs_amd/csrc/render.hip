@@ -630,8 +630,12 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (rc != FSGS_OK) return rc;
   {
     ProfScope ps(PROF_BLEND_FWD, stream);
-    launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
-                               B.n_contrib, out_image, out_depth_sil, nullptr, stream);
+    if (cfg->flags & FSGS_FLAG_RGB_DEPTH_ONLY)  // tracking: image + depth plane, 16 instead of 24 accumulators per lane
+      launch_blend_fwd<4, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
+                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream);
+    else
+      launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
+                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream);
   }
   FSGS_HIP(hipGetLastError());
   // only now does the host look at R (the blend is already queued behind the binning)

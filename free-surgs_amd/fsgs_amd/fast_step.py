@@ -128,7 +128,18 @@ class FastStepper:
             self._cfgz, self._cfgz_of = z, base
         return self._cfgz
 
-    def _render_forward(self, w2c, b):
+    def _cfg_tracking(self):
+        """the same configuration with FSGS_FLAG_RGB_DEPTH_ONLY: the tracking iteration reads the image and the depth
+        plane (`render_dep > 0`) and nothing else, so the silhouette and depth^2 planes are not blended"""
+        base = self._cfg()
+        if getattr(self, "_cfgt_of", None) is not base:
+            z = _lib.FsgsRasterCfg()
+            C.memmove(C.byref(z), C.byref(base), C.sizeof(z))
+            z.flags |= _lib.FSGS_FLAG_RGB_DEPTH_ONLY
+            self._cfgt, self._cfgt_of = z, base
+        return self._cfgt
+
+    def _render_forward(self, w2c, b, tracking=False):
         pc, lib = self.pc, self.lib
         p = pc.params
         for name in PARAM_NAMES:  # raw pointers go to the kernels: no silent reinterpretation of other layouts
@@ -136,7 +147,7 @@ class FastStepper:
             if t_.dtype != torch.float32 or not t_.is_contiguous() or not t_.is_cuda:
                 raise ValueError("%s must be a contiguous float32 device tensor for the step driver (got %s, %s)"
                                  % (name, t_.dtype, "contiguous" if t_.is_contiguous() else "strided"))
-        cfg = self._cfg()
+        cfg = self._cfg_tracking() if tracking else self._cfg()
         P, H, W = pc.num_points, cfg.image_height, cfg.image_width
         dev = p["_xyz"].device
         args = _args_struct(p["_xyz"], p["_features_dc"], p["_features_rest"], p["_opacity"], p["_scaling"],
@@ -458,7 +469,7 @@ class FastStepper:
                     flow_done = torch.cuda.Event()
                     flow_done.record()
                     wd.record_stream(side)
-                args, state, sbytes, cap, nr = self._render_forward(wd, b)
+                args, state, sbytes, cap, nr = self._render_forward(wd, b, tracking=True)
                 # mask = [rendered depth > 0] * rigid mask (train.py:176-178): the presence test is evaluated inside the
                 # loss kernels from the depth plane; the rigid mask (None = every pixel rigid) is handed over as floats,
                 # converted once per mask object -- a frame's 50 iterations share it

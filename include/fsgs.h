@@ -65,6 +65,10 @@ enum {
 /* fsgs_render_backward*: the caller has already zeroed the first P * 64 bytes of `scratch` (e.g. on another stream,
  * beside the loss kernels); the call does not enqueue its own fill in front of the backward blend */
 #define FSGS_FLAG_SCRATCH_ZEROED 4
+/* fsgs_render_forward: blend only the RGB planes and the depth plane -- out_depth_sil planes 1 (silhouette) and 2
+ * (depth^2) are NOT written.  For the tracking iteration (train.py:166-200), which reads the image and `depth > 0` and
+ * nothing else; the state it leaves serves the pose-only backward unchanged. */
+#define FSGS_FLAG_RGB_DEPTH_ONLY 8
 
 /* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
  * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
