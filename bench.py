@@ -83,11 +83,11 @@ def upstream_pairs(stepper, W, H):
     last = getattr(stepper, "last", None)
     if not last or "state" not in last:
         return None
-    P = int(stepper.pc.num_points)
+    P = int(last["P"])  # of that forward (a densification may have resized the cloud since)
     off = (C.c_size_t * 9)()
     _lib.check(_lib.load().fsgs_render_state_layout(P, W, H, int(last["max_pairs"]), off), "fsgs_render_state_layout")
     xy = last["state"][off[0]:off[0] + 8 * P].view(torch.float32).reshape(P, 2)
-    r = last["radii_last"].float()
+    r = last["radii_last"][:P].float()
     vis = r > 0
     gx, gy = (W + 15) // 16, (H + 15) // 16
     lo = lambda c, n: torch.clamp(torch.trunc((c - r) / 16), 0, n)

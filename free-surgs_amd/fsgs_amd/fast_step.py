@@ -426,7 +426,7 @@ class FastStepper:
                 optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
                                     pc.variables["xyz_gradient_accum"], pc.variables["denom"])
             self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil,
-                         "state": state, "max_pairs": cap, "radii_last": b.radii}  # LAST view (debugging / statistics)
+                         "state": state, "max_pairs": cap, "radii_last": b.radii, "P": pc.num_points}  # LAST view (debugging / statistics)
             if step_optimizer:
                 pc.optimizer.step()
                 # gradients are overwritten by the next step's backward; nothing to zero

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/tr && mkdir -p /tmp/tr
-timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o tr -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-tracking ${TRACE_ARGS:-} > gpurun_out/trace.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o tr -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-tracking --no-extras ${TRACE_ARGS:-} > gpurun_out/trace.log 2>&1
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, re
