@@ -60,6 +60,31 @@ __device__ __forceinline__ float fold_dpp(float x, float y, bool upper) {
   int t = __builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true);
   return keep + __int_as_float(t);
 }
+// The two fold steps whose lane bit selects whole DPP BANKS (4 lanes) need no select at all: a DPP add writes only
+// the banks its bank_mask enables, so "x + partner's x" goes to the banks with the lane bit clear and "y + partner's y"
+// to the others -- two instructions instead of two v_cndmask + one DPP add, and no VCC traffic.
+//   lane bit 3 (row_ror:8, partner l ^ 8): banks 0,1 <- x, banks 2,3 <- y
+//   lane bit 2 (row_half_mirror, partner l ^ 7): banks 0,2 <- x, banks 1,3 <- y
+__device__ __forceinline__ float fold_bit3(float x, float y) {
+  float r;
+  // (s_nop 1: a DPP read needs two wait states behind the VALU write of its source; the compiler inserts them for its
+  // own DPP instructions, not in front of inline assembly)
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+               : "=&v"(r)
+               : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float fold_bit2(float x, float y) {
+  float r;
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa"
+               : "=&v"(r)
+               : "v"(x), "v"(y));
+  return r;
+}
 __device__ __forceinline__ float wave_transpose_reduce64(const float (&v)[64], int lane) {
   float w[32], x[16], y[8], z[4], u[2];
 #pragma unroll
@@ -68,9 +93,9 @@ __device__ __forceinline__ float wave_transpose_reduce64(const float (&v)[64], i
   for (int i = 0; i < 16; i++) x[i] = swap16_add(w[i], w[i + 16]);
   const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
 #pragma unroll
-  for (int i = 0; i < 8; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 8], b3);  // row_ror:8
+  for (int i = 0; i < 8; i++) y[i] = fold_bit3(x[i], x[i + 8]);  // row_ror:8
 #pragma unroll
-  for (int i = 0; i < 4; i++) z[i] = fold_dpp<0x141>(y[i], y[i + 4], b2);  // row_half_mirror
+  for (int i = 0; i < 4; i++) z[i] = fold_bit2(y[i], y[i + 4]);  // row_half_mirror
 #pragma unroll
   for (int i = 0; i < 2; i++) u[i] = fold_dpp<0x4E>(z[i], z[i + 2], b1);   // quad_perm [2,3,0,1]
   return fold_dpp<0xB1>(u[0], u[1], b0);                                  // quad_perm [1,0,3,2]
@@ -86,11 +111,30 @@ __device__ __forceinline__ float wave_transpose_reduce32(const float (&v)[32], i
   for (int i = 0; i < 8; i++) x[i] = swap16_add(w[i], w[i + 8]);     // lane bit 4 <-> index bit 3
   const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
 #pragma unroll
-  for (int i = 0; i < 4; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 4], b3);  // lane bit 3 <-> index bit 2
+  for (int i = 0; i < 4; i++) y[i] = fold_bit3(x[i], x[i + 4]);  // lane bit 3 <-> index bit 2
 #pragma unroll
-  for (int i = 0; i < 2; i++) z[i] = fold_dpp<0x141>(y[i], y[i + 2], b2);  // lane bit 2 <-> index bit 1
+  for (int i = 0; i < 2; i++) z[i] = fold_bit2(y[i], y[i + 2]);  // lane bit 2 <-> index bit 1
   float u = fold_dpp<0x4E>(z[0], z[1], b1);                                 // lane bit 1 <-> index bit 0
   return dpp_add<0xB1>(u);                                                  // lanes l, l^1: plain sum
+}
+
+// The same when v[12..15] and v[28..31] are known to be ZERO (two Gaussians x 16 slots of which 12 are used): the
+// first halving step pairs v[i] with v[i + 16], so four of its sixteen swap + add pairs only move zeros.
+__device__ __forceinline__ float wave_transpose_reduce32_12of16(const float (&v)[32], int lane) {
+  float w[16], x[8], y[4], z[2];
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = swap32_add(v[i], v[i + 16]);
+#pragma unroll
+  for (int i = 12; i < 16; i++) w[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = swap16_add(w[i], w[i + 8]);
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+  for (int i = 0; i < 4; i++) y[i] = fold_bit3(x[i], x[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; i++) z[i] = fold_bit2(y[i], y[i + 2]);
+  float u = fold_dpp<0x4E>(z[0], z[1], b1);
+  return dpp_add<0xB1>(u);
 }
 
 // 16-value variant: lane l ends with the total of v[l >> 2] (four lanes hold the same value); ~40 VALU.
@@ -102,8 +146,8 @@ __device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], i
   for (int i = 0; i < 4; i++) x[i] = swap16_add(w[i], w[i + 4]);     // lane bit 4 <-> index bit 2
   const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-  for (int i = 0; i < 2; i++) y[i] = fold_dpp<0x128>(x[i], x[i + 2], b3);  // lane bit 3 <-> index bit 1
-  float z = fold_dpp<0x141>(y[0], y[1], b2);                                // lane bit 2 <-> index bit 0
+  for (int i = 0; i < 2; i++) y[i] = fold_bit3(x[i], x[i + 2]);  // lane bit 3 <-> index bit 1
+  float z = fold_bit2(y[0], y[1]);                                // lane bit 2 <-> index bit 0
   z = dpp_add<0x4E>(z);                                                     // lanes l, l^2, l^1, l^3: plain sum
   return dpp_add<0xB1>(z);
 }

@@ -769,13 +769,15 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // carry a gradient.
 // CGRAD < C: only the first CGRAD channels carry dL/dpixel (the fused render's losses never touch the silhouette
 // and depth^2 planes: CGRAD = 4 drops their two FMAs in the colour dot product and their two dcolour sums).
-template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C>
+// ROW: floats per accumulator row when moments and colour sums share one row per Gaussian (kFusedRow, the fused
+// render); 0 = the operator boundary's layout (moments [P,8] in scratch, colour sums straight into dcolors [P,C]).
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
 __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
-    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16, int acc_stride,
-    int col_stride) {
+    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16) {
+  constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;  // compile-time: shifts, no 64-bit mads
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   // 16 floats the NEXT kernel accumulates into with atomics (dL/dw2c): cleared here instead of by a separate fill
   if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) clear16[threadIdx.x] = 0.f;
@@ -919,6 +921,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
       float tot;
       if constexpr (POSE_ONLY) tot = wave_transpose_reduce16(v, lane);
+      else if constexpr (CG <= 4) tot = wave_transpose_reduce32_12of16(v, lane);  // slots 12..15 of a Gaussian stay zero
       else tot = wave_transpose_reduce32(v, lane);
       const int j_mine = jj - my_u;
       uint32_t gsel = readlane(gid, jj);
@@ -1232,14 +1235,14 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      final_T, n_contrib, out_color, out_color2, out_depth);
   return 0;
 }
-template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C>
+template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
 int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
                      const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
-                     float *clear16 = nullptr, int acc_stride = kAccStride, int col_stride = C) {
+                     float *clear16 = nullptr) {
   static int dbg_lds = getenv("FSGS_DBG_LDS") ? atoi(getenv("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
-                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, acc_stride, col_stride);
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
+                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
   return 0;
 }
 

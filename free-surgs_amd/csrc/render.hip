@@ -727,26 +727,26 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
     // tracking (pose gradient only, rgb loss only): the lean variant -- see blend_bwd_kernel
     const bool pose_only = cam_grad && !gs_grad && !param_grads && !dL_ddepth_sil;
     if (pose_only)
-      launch_blend_bwd<6, false, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+      launch_blend_bwd<6, false, true, 6, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                        (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c, kFusedRow, kFusedRow);
+                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c);
     else if ((cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY) && !grads->means2D)
       // nobody wants the densification statistic (means2D_grad == NULL): the RGB-only mean2D moments are dropped too
-      launch_blend_bwd<6, false, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+      launch_blend_bwd<6, false, false, 4, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                            (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                            (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, kFusedRow, kFusedRow);
+                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
     else if (cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY)  // dL_ddepth_sil is [1,H,W]: planes 1, 2 carry no gradient
-      launch_blend_bwd<6, true, false, 4>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
+      launch_blend_bwd<6, true, false, 4, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                           (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                           (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, kFusedRow, kFusedRow);
+                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
     else
-      launch_blend_bwd<6, true>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
+      launch_blend_bwd<6, true, false, 6, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
                                 (const float4 *)(sb + SL.rec), (const float *)(sb + SL.final_T),
                                 (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
-                                stream, nullptr, kFusedRow, kFusedRow);
+                                stream);
   }
   FSGS_HIP(hipGetLastError());
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);
