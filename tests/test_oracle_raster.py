@@ -217,3 +217,69 @@ def test_quaternion_is_not_renormalised_in_kernel(oracle64):
     i1 = oracle64.raster_forward(cam, xyz, c, op, s, q / np.linalg.norm(q))[0]
     i2 = oracle64.raster_forward(cam, xyz, c, op, s, 2 * q / np.linalg.norm(q))[0]
     assert np.abs(i1 - i2).max() > 1e-3
+
+
+# ---- the witnesses of the parity tests (flip attribution): thresholds moved by a hair, depth-order ties ----
+def test_thresholds_are_nominal_by_default_and_a_constructed_near_tie_is_witnessed(oracle32):
+    """One Gaussian whose alpha at one pixel sits 1e-4 (relative) above 1/255: the nominal run blends it there, the
+    'tight' run skips it, and flip_amplitudes reports a non-zero amplitude at exactly the pixels within the margin --
+    zero everywhere else, so an implementation differing anywhere else gets no allowance."""
+    W = H = 32
+    cam = synth.make_camera(W, H)
+    K = cam["K"]
+    z = 1.0
+    sigma_px = 3.0
+    s = np.full((1, 3), sigma_px * z / K[0, 0], np.float32)
+    px, py = 16.0, 16.0
+    xyz = np.array([[(px - K[0, 2]) / K[0, 0] * z, (py - K[1, 2]) / K[1, 1] * z, z]], np.float32)
+    rot = np.array([[1.0, 0, 0, 0]], np.float32)
+    col = np.array([[0.2, 0.5, 0.9]], np.float32)
+    # choose the opacity so that alpha at the pixel 5 px right of the centre is (1 + 1e-4) / 255
+    _, _, _, st = oracle32.raster_forward(cam, xyz, col, np.array([0.5], np.float32), s, rot)
+    co, c = st.conic_opacity()[0].astype(np.float64), st.xy()[0].astype(np.float64)
+    tx, ty = 21, 16  # the pixel put on the threshold
+    dx, dy = c[0] - tx, c[1] - ty
+    g_at = np.exp(-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy)
+    op = np.array([(1.0 + 1e-4) / 255.0 / g_at], np.float32)
+    dL = np.ones((3, H, W), np.float32) / (3 * H * W)
+    base = oracle32.raster_forward(cam, xyz, col, op, s, rot)
+    oracle32.set_thresholds(0)
+    again = oracle32.raster_forward(cam, xyz, col, op, s, rot)
+    assert np.array_equal(base[0], again[0])  # sign 0 = the published constants, bit for bit
+    amp, (img, dep, radii, grads, st) = oracle32.flip_amplitudes(cam, xyz, col, op, s, rot, dL, roundoff=False)
+    fragile = amp["image"].max(axis=0) > 0
+    assert fragile[ty, tx]  # on the ring alpha = 1/255 (+ at most the few other pixels within 4e-4 of it)
+    assert fragile.sum() <= 8 and not fragile[16, 16] and not fragile[16, 19] and not fragile[16, 23]
+    a = float(amp["image"][:, ty, tx].max())
+    assert 0.5 * (1 / 255.0) * 0.2 < a < 1.5 * (1 / 255.0)  # ~ alpha * |colour - background|
+    assert float(amp["colors"].max()) > 0 and float(amp["opacities"].max()) > 0
+    # the thresholds are back to nominal afterwards
+    assert np.array_equal(oracle32.raster_forward(cam, xyz, col, op, s, rot)[0], base[0])
+
+
+def test_depth_order_ties_are_found_and_swapped(oracle32):
+    """Two overlapping Gaussians whose depths differ in the last bit: find_order_ties names the pair, and the shifted
+    sort keys of set_thresholds(+-1) put them in either order (the blended depth itself is untouched)."""
+    W = H = 32
+    cam = synth.make_camera(W, H)
+    xyz, col, op, s, rot = synth.random_small_scene(6, cam, seed=5, scale_px=(4.0, 8.0))
+    xyz = xyz.astype(np.float32)
+    xyz[1] = xyz[0] + np.array([0.002, 0.0, 0.0], np.float32)
+    xyz[1, 2] = np.nextafter(xyz[0, 2], np.float32(10.0))  # one ulp behind
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    args = (cam, xyz, f(col), f(op), f(s), f(rot))
+    _, _, _, st = oracle32.raster_forward(*args)
+    h = oracle32.find_order_ties(st)
+    assert h is not None and h[0] * h[1] == -1.0 and not h[2:].any()
+    orders = []
+    try:
+        for sign in (0, 1, -1):
+            oracle32.set_thresholds(sign)
+            _, dep, _, st2 = oracle32.raster_forward(*args)
+            pl = st2.point_list().tolist()
+            orders.append(pl.index(0) < pl.index(1))
+            assert np.array_equal(st2.depth(), st.depth())
+    finally:
+        oracle32._order_h = None
+        oracle32.set_thresholds(0)
+    assert orders[0] is True and sorted(orders[1:]) == [False, True]
