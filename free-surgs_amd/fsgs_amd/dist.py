@@ -11,6 +11,16 @@ import torch.distributed as dist
 from .model import PARAM_NAMES
 
 
+# True: issue the collectives even in a 1-rank group.  Only the tests set it: a 1-rank "nccl" group on the one test GPU is
+# the closest thing to the multi-GPU run a one-GPU box offers (RCCL kernels, their streams and events are all exercised;
+# RCCL refuses two ranks on one device, so the 2-rank tests there run over gloo).
+FORCE_COLLECTIVES = False
+
+
+def _live():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for 1 rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,7 +69,7 @@ class GradBucket:
             pc.params[k].grad = self.views[k]
 
     def all_reduce(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _live():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
 
@@ -67,7 +77,7 @@ def all_reduce_compact(gc):
     """all-reduce(SUM) of the compact [P,14] gradient of fast_step.FastStepper (56 B per Gaussian instead of 236 B:
     the SH gradients are rank-1 in a rank-independent basis, see csrc/render.hip OUT_COMPACT).  16.8 MB at
     P = 300 k -- what actually has to cross the point-to-point xGMI links."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _live():
         dist.all_reduce(gc, op=dist.ReduceOp.SUM)
 
 
@@ -84,7 +94,7 @@ class PipelinedCompactReducer:
 
     def __call__(self, gc, adam_rows):
         P = int(gc.shape[0])
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not _live():
             adam_rows(0, P)
             return
         per = -(-P // self.nchunks)
@@ -143,7 +153,7 @@ class ProducerPipelinedReducer:
 
     def produced(self, gc, lo, hi):
         """rows [lo, hi) of gc are final on the current stream: start their all-reduce."""
-        live = dist.is_initialized() and dist.get_world_size() > 1
+        live = _live()
         if not gc.is_cuda:
             if live:
                 dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)

@@ -104,3 +104,55 @@ def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
         # Adam divides by sqrt(v): elements whose gradient is rounding noise can move by lr either way
         frac_off = ((a[k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
         assert frac_off < 2e-3, (k, frac_off)
+
+
+def _rccl_one_rank_worker(rank, world, port, out_dir):
+    """a ONE-rank "nccl" (= RCCL) group on the test GPU with the collectives forced on: the real backend of the
+    multi-GPU run -- RCCL kernels on their own stream, event hand-offs, barrier(device_ids) -- under every exchange route
+    of the step driver; the result must equal the step without any exchange (an all-reduce over one rank is the identity)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from fsgs_amd import dist as fdist
+    from fsgs_amd.fast_step import FastStepper
+    from fsgs_amd.model import PARAM_NAMES
+
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    fdist.FORCE_COLLECTIVES = True
+    results = {}
+    for mode in ("none", "compact", "pipelined", "producer"):
+        pc, poses, frames, (H, W) = _world("cuda:0")
+        cr = _corners(H, W, "cuda:0")
+        fs = FastStepper(pc, poses, frames)
+        red = {"none": None, "compact": fdist.all_reduce_compact, "pipelined": fdist.PipelinedCompactReducer(3),
+               "producer": fdist.ProducerPipelinedReducer(3)}[mode]
+        for step in range(3):
+            if mode == "none":
+                loss = fs.mapping_step([step % 2], reduce_compact=lambda t: None, corners=cr)  # compact route, no exchange
+            else:
+                loss = fs.mapping_step([step % 2], reduce_compact=red, corners=cr)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        results[mode] = {k: pc.params[k].detach().cpu() for k in PARAM_NAMES} | {"loss": loss.detach().cpu()}
+    # the stand-alone collective bench.py times (comm), and the densification statistics (SUM, SUM, MAX)
+    buf = torch.ones((4000 * 14,), device="cuda:0")
+    dist.all_reduce(buf)
+    assert float(buf.sum()) == 4000 * 14
+    pc.variables["xyz_gradient_accum"] += 1.0
+    fdist.sync_densification_stats(pc)
+    torch.save(results, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_every_exchange_route_runs_on_rccl_with_one_rank(tmp_path):
+    from fsgs_amd.model import PARAM_NAMES
+
+    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp_path, "rccl.pt"))
+    for mode in ("compact", "pipelined", "producer"):
+        # identity exchange: the same trajectory as without one, up to the arrival order of the backward's atomics
+        assert abs(float(r[mode]["loss"]) - float(r["none"]["loss"])) <= 1e-5 * abs(float(r["none"]["loss"])), mode
+        for k in PARAM_NAMES:
+            ref = r["none"][k]
+            frac_off = ((r[mode][k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
+            assert frac_off < 2e-3, (mode, k, frac_off)
