@@ -174,6 +174,33 @@ constexpr int ST_IN = ST_W + 2 * SS_HALO;     // 74
 constexpr int ST_NR = ST_RS + 2 * SS_HALO;    // input rows per wave
 
 // loss = (1-l) * L1mean + l * (1 - SSIMmean);  out[0] = loss, out[1] = L1 mean, out[2] = SSIM mean
+// The same reduction by ONE wave (fixed order too): the extra workgroup of the fused forward + backward entry, which
+// finishes the loss value beside the backward's row streams instead of in a launch of its own between the two.
+struct FinishArgs {
+  const float *partials;
+  int nblocks;
+  double n;
+  float *out;  // NULL: this launch has no finishing workgroup
+};
+__device__ __forceinline__ void photometric_finish_wave(const FinishArgs &f, float lambda_dssim, int lane) {
+  double a = 0.0, b = 0.0;
+  for (int i = lane; i < f.nblocks; i += 64) {
+    a += (double)f.partials[2 * i];
+    b += (double)f.partials[2 * i + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if (lane == 0) {
+    const double l1 = a / f.n, ss = b / f.n;
+    f.out[0] = (float)((1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss));
+    f.out[1] = (float)l1;
+    f.out[2] = (float)ss;
+  }
+}
+
 __global__ __launch_bounds__(256) void photometric_finish_kernel(const float *__restrict__ partials, int nblocks,
                                                                  double n, float lambda_dssim, float *out) {
   __shared__ double red[2][256];
@@ -212,9 +239,13 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
                                                              const float *__restrict__ presence,
                                                              const float *__restrict__ maps,
                                                              const float *__restrict__ upstream, float lambda_dssim,
-                                                             float *__restrict__ dimg) {
+                                                             float *__restrict__ dimg, FinishArgs fin) {
   __shared__ float row[3][ST_IN + 6];
   const int lane = threadIdx.x, ch = blockIdx.z;
+  if (fin.out && blockIdx.x == gridDim.x - 1) {  // the grid is one column wider: its first workgroup finishes the loss
+    if (blockIdx.y == 0 && blockIdx.z == 0) photometric_finish_wave(fin, lambda_dssim, lane);
+    return;
+  }
   const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_RS;
   const int gx = x0 + lane;
   const size_t plane = (size_t)H * W, cplane = (size_t)C * plane;
@@ -445,7 +476,29 @@ int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const 
   {
     ProfScope ps(PROF_LOSS_RGB_BWD, stream);
     hipLaunchKernelGGL(photometric_bwd_kernel, grid, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,
-                       upstream, lambda_dssim, dimg);
+                       upstream, lambda_dssim, dimg, FinishArgs{nullptr, 0, 1.0, nullptr});
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_photometric_loss_forward_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                           const float *presence, float lambda_dssim, float *maps, void *sums2,
+                                           float *out3, const float *upstream, float *dimg, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3 || !dimg) return FSGS_ERR_INVALID;
+  dim3 gf((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
+  const int nblocks = (int)(gf.x * gf.y * gf.z);
+  float *partials = (float *)sums2;
+  {
+    ProfScope ps(PROF_LOSS_RGB_FWD, stream);
+    hipLaunchKernelGGL(photometric_fwd_kernel, gf, dim3(256), 0, stream, C, H, W, img, gt, mask, presence, maps, partials);
+  }
+  dim3 gb((W + ST_W - 1) / ST_W + 1, (H + ST_RS - 1) / ST_RS, C);  // + 1 column: the finishing workgroup
+  {
+    ProfScope ps(PROF_LOSS_RGB_BWD, stream);
+    hipLaunchKernelGGL(photometric_bwd_kernel, gb, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,
+                       upstream, lambda_dssim, dimg, FinishArgs{partials, nblocks, (double)C * H * W, out3});
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

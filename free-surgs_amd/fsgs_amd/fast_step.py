@@ -293,13 +293,11 @@ class FastStepper:
                 side = self._side_stream(dev)
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
-                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2,
-                                                             _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out),
-                                                             stream), "fsgs_photometric_loss_forward")
-                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None,
-                                                              _lib.ptr(b.maps), _lib.ptr(b.up_rgb), 0.2,
-                                                              _lib.ptr(b.d_image), stream),
-                           "fsgs_photometric_loss_backward")
+                # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
+                _lib.check(lib.fsgs_photometric_loss_forward_backward(
+                    3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
+                    _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
+                    "fsgs_photometric_loss_forward_backward")
                 side.wait_event(fwd_done)
                 with torch.cuda.stream(side):
                     sstream = _lib.current_stream()
@@ -482,13 +480,10 @@ class FastStepper:
                     rigid_f = hit[2]
                 presence = b.depth_sil[0]
                 gt = self.frames.colors[t]
-                _lib.check(lib.fsgs_photometric_loss_forward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(rigid_f),
-                                                             _lib.ptr(presence), 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
-                                                             _lib.ptr(b.rgb_out), stream), "fsgs_photometric_loss_forward")
-                _lib.check(lib.fsgs_photometric_loss_backward(3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(rigid_f),
-                                                              _lib.ptr(presence), _lib.ptr(b.maps), None, 0.2,
-                                                              _lib.ptr(b.d_image), stream),
-                           "fsgs_photometric_loss_backward")
+                _lib.check(lib.fsgs_photometric_loss_forward_backward(
+                    3, H, W, _lib.ptr(b.image), _lib.ptr(gt), _lib.ptr(rigid_f), _lib.ptr(presence), 0.2,
+                    _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out), None, _lib.ptr(b.d_image), stream),
+                    "fsgs_photometric_loss_forward_backward")
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
                 grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)
                 torch.cuda.current_stream().wait_event(flow_done)

@@ -293,6 +293,12 @@ int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const f
 int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
                                    const float *presence, const float *maps, const float *upstream, float lambda_dssim,
                                    float *dimg, fsgs_stream_t stream);
+/* Forward and backward of the same loss in TWO launches instead of three: the reduction of the per-workgroup partial
+ * sums to out3 runs as one extra workgroup of the backward launch instead of as a launch of its own between the two.
+ * Same results as the two calls above (for callers that need dimg whatever the loss value is: the step driver). */
+int fsgs_photometric_loss_forward_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                           const float *presence, float lambda_dssim, float *maps, void *scratch,
+                                           float *out3, const float *upstream, float *dimg, fsgs_stream_t stream);
 
 /* ---- Pearson depth losses (utils/loss_utils.py:98-127) ------------------------------------------- */
 
