@@ -145,42 +145,59 @@ __device__ __forceinline__ void stage_out(float *dst, const float *lds, size_t f
   }
 }
 
+// REUSE: the colours (and clamp flags) of every Gaussian are taken from the packed records of an EARLIER forward of
+// the same cloud (`prev_rec`, `prev_flags`) instead of being evaluated: they depend on the parameters and on the frame-0
+// camera centre only (scene/gaussian_model.py:317-320), not on the pose -- the 50 tracking iterations of a frame and
+// the second view of a two-view mapping step re-read 192 B of SH coefficients per Gaussian for nothing otherwise.
+template <bool REUSE>
 __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
-                                                             uint32_t *__restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
+                                                             uint32_t *__restrict__ flags,
+                                                             const float4 *__restrict__ prev_rec,
+                                                             const uint32_t *__restrict__ prev_flags) {
+  __shared__ __attribute__((aligned(16))) float s_rest[REUSE ? 4 : RB * SH_REST_MAX];
   const int b0 = blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;  // floats of f_rest per Gaussian
   RawGaussian raw;
   float fdc[3] = {0.f, 0.f, 0.f};
+  float4 pcol = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t fl = 0;
   if (i < P) {  // issued before the staging loads and their barrier
     raw = load_raw(a, i);
-    fdc[0] = a.f_dc[3 * i]; fdc[1] = a.f_dc[3 * i + 1]; fdc[2] = a.f_dc[3 * i + 2];
+    if (REUSE) {
+      pcol = prev_rec[(size_t)i * kRecF4 + 2];
+      fl = prev_flags[i];
+    } else {
+      fdc[0] = a.f_dc[3 * i]; fdc[1] = a.f_dc[3 * i + 1]; fdc[2] = a.f_dc[3 * i + 2];
+    }
   }
-  if (a.deg > 0) {
+  if (!REUSE && a.deg > 0) {
     size_t cnt = (size_t)min(RB, P - b0) * row;
     stage_in(s_rest, a.f_rest, (size_t)b0 * row, cnt);
     __syncthreads();
   }
   if (i >= P) return;
-  const float *my_rest = s_rest + (size_t)threadIdx.x * row;
   Activated act = activate(a, raw);
-  // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
-  float dx = raw.x - a.cam_center[0], dy = raw.y - a.cam_center[1], dz = raw.z - a.cam_center[2];
-  float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-  dx *= inv_n; dy *= inv_n; dz *= inv_n;
-  float b[16];
-  sh_basis(a.deg, dx, dy, dz, b);
-  const int nk = (a.deg + 1) * (a.deg + 1);
   float rgb[3];
-  uint32_t fl = 0;
+  if (REUSE) {
+    rgb[0] = pcol.x; rgb[1] = pcol.y; rgb[2] = pcol.z;
+  } else {
+    const float *my_rest = s_rest + (size_t)threadIdx.x * row;
+    // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
+    float dx = raw.x - a.cam_center[0], dy = raw.y - a.cam_center[1], dz = raw.z - a.cam_center[2];
+    float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv_n; dy *= inv_n; dz *= inv_n;
+    float b[16];
+    sh_basis(a.deg, dx, dy, dz, b);
+    const int nk = (a.deg + 1) * (a.deg + 1);
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
-    float v = b[0] * fdc[c];
-    for (int k = 1; k < nk; k++) v = fmaf(b[k], my_rest[(k - 1) * 3 + c], v);
-    v += 0.5f;
-    if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
-    rgb[c] = v;
+    for (int c = 0; c < 3; c++) {
+      float v = b[0] * fdc[c];
+      for (int k = 1; k < nk; k++) v = fmaf(b[k], my_rest[(k - 1) * 3 + c], v);
+      v += 0.5f;
+      if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
+      rgb[c] = v;
+    }
   }
   // depth pseudo-colours: row 2 of cam.viewmatrix[0] AS STORED times [x_cam;1] (scene/gaussian_model.py:266-271)
   const float *V = cam.V;
@@ -602,9 +619,10 @@ int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, si
   return FSGS_OK;
 }
 
-int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
-                        float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
-                        size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream_) {
+static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                               float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
+                               size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream_,
+                               const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !out_image || !out_depth_sil || !state || !scratch || !num_rendered || max_pairs < 0)
     return FSGS_ERR_INVALID;
@@ -620,8 +638,16 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
     GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx};
-    hipLaunchKernelGGL(render_pre_fwd_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args), g,
-                       B.flags);
+    if (prev_state) {
+      StateLayout PL = state_layout(P, W, H, prev_max_pairs, 6);
+      if (prev_state_bytes < PL.total || prev_state == state) return FSGS_ERR_STATE;
+      const char *pb = (const char *)prev_state;
+      hipLaunchKernelGGL(render_pre_fwd_kernel<true>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args),
+                         g, B.flags, (const float4 *)(pb + PL.rec), (const uint32_t *)(pb + PL.flags));
+    } else {
+      hipLaunchKernelGGL(render_pre_fwd_kernel<false>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
+                         to_dev(args), g, B.flags, (const float4 *)nullptr, (const uint32_t *)nullptr);
+    }
   }
   FSGS_HIP(hipGetLastError());
   BinningTicket tk;
@@ -640,6 +666,23 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
   FSGS_HIP(hipGetLastError());
   // only now does the host look at R (the blend is already queued behind the binning)
   return finish_binning(cam, B, max_pairs, tk, num_rendered, stream);
+}
+
+int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                        float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
+                        size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream) {
+  return render_forward_impl(cfg, P, args, out_image, out_depth_sil, radii, state, state_bytes, scratch, scratch_bytes,
+                             max_pairs, num_rendered, stream, nullptr, 0, 0);
+}
+
+int fsgs_render_forward_reuse_colors(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                                     float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes,
+                                     void *scratch, size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered,
+                                     const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs,
+                                     fsgs_stream_t stream) {
+  if (!prev_state) return FSGS_ERR_INVALID;
+  return render_forward_impl(cfg, P, args, out_image, out_depth_sil, radii, state, state_bytes, scratch, scratch_bytes,
+                             max_pairs, num_rendered, stream, prev_state, prev_state_bytes, prev_max_pairs);
 }
 
 }  // extern "C"

@@ -118,6 +118,11 @@ _PROTOTYPES = {
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
          C.POINTER(_i64), _vp],
     ),
+    "fsgs_render_forward_reuse_colors": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
+         C.POINTER(_i64), _vp, _sz, _i64, _vp],
+    ),
     "fsgs_render_backward": (
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp, _i, _i, _i,

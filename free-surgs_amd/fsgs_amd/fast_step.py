@@ -155,6 +155,14 @@ class FastStepper:
         cap = rasterizer._capacity_for(P, W, H)
         nr = C.c_int64(0)
         stream = _lib.current_stream()
+        # The per-Gaussian colours depend on the parameters and the frame-0 camera centre only: while neither changes
+        # (the 50 tracking iterations of a frame, the second view of a two-view mapping step) a forward copies them from
+        # the previous forward's state instead of evaluating 48 SH coefficients per Gaussian again.
+        ckey = (P, W, H, pc.active_sh_degree, pc.max_sh_degree, self.poses.cam_center._version) + tuple(
+            (id(p[n]), p[n]._version) for n in PARAM_NAMES)
+        prev = self.__dict__.get("_color_src")
+        if prev is not None and (prev[0] != ckey or any(a is not b for a, b in zip(prev[4], (p[n] for n in PARAM_NAMES)))):
+            prev = None
         for _attempt in range(3):
             sz = b.sizes.get(cap)
             if sz is None:
@@ -163,9 +171,15 @@ class FastStepper:
                 sz = b.sizes[cap] = (sb.value, xb.value)
             state = torch.empty((sz[0],), dtype=torch.uint8, device=dev)
             scratch = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
-            rc = lib.fsgs_render_forward(C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil),
-                                         _lib.ptr(b.radii), _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap,
-                                         C.byref(nr), stream)
+            if prev is not None:
+                rc = lib.fsgs_render_forward_reuse_colors(
+                    C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil), _lib.ptr(b.radii),
+                    _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap, C.byref(nr), _lib.ptr(prev[1]), prev[2], prev[3],
+                    stream)
+            else:
+                rc = lib.fsgs_render_forward(C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil),
+                                             _lib.ptr(b.radii), _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap,
+                                             C.byref(nr), stream)
             if rc == _lib.FSGS_ERR_CAPACITY and nr.value > cap:
                 cap = int(nr.value * 1.25) + 1024
                 rasterizer._capacity[(P, W, H)] = cap
@@ -174,6 +188,8 @@ class FastStepper:
             break
         else:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
+        # (the tensors themselves are part of the entry: ids alone can be recycled by the allocator)
+        self._color_src = (ckey, state, sz[0], cap, tuple(p[n] for n in PARAM_NAMES))
         rasterizer.last_num_rendered = int(nr.value)
         self.pairs_total += int(nr.value)  # (bench.py reports the mean pair count of the steps it timed)
         self.forward_calls += 1

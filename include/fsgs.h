@@ -196,6 +196,17 @@ int fsgs_render_forward(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *a
                         float *out_image, float *out_depth_sil, int32_t *radii,
                         void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
                         int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream);
+/* The same forward for a cloud whose parameters have NOT changed since an earlier forward `prev_state` (made with
+ * prev_max_pairs; any pose): the per-Gaussian colours and clamp flags are copied from that state's packed records
+ * instead of being evaluated from the 48 SH coefficients -- they depend on the parameters and the frame-0 camera centre
+ * only (scene/gaussian_model.py:317-320).  For the 50 tracking iterations of a frame (train.py:166-200) and the second
+ * view of a two-view mapping step (train.py:236-259).  prev_state must stay untouched until this call's kernels ran. */
+int fsgs_render_forward_reuse_colors(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args,
+                                     float *out_image, float *out_depth_sil, int32_t *radii,
+                                     void *state, size_t state_bytes, void *scratch, size_t scratch_bytes,
+                                     int64_t max_pairs, int64_t *num_rendered,
+                                     const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs,
+                                     fsgs_stream_t stream);
 
 /* dL_dimage / dL_ddepth_sil [3,H,W] or NULL (= zero).  gs_grad / cam_grad as in render(...):
  * gs_grad routes the mean gradient to xyz, cam_grad reduces dL/dw2c.  param_grads = 0 skips the

@@ -181,3 +181,38 @@ def test_fused_transform_to_frame_equals_the_reference_golden():
     got = f.xy.cpu().numpy()[seen]
     np.testing.assert_allclose(got[:, 0], px[seen], atol=3e-4, rtol=1e-5)
     np.testing.assert_allclose(got[:, 1], py[seen], atol=3e-4, rtol=1e-5)
+
+
+def test_forward_reusing_the_colours_of_an_earlier_forward_is_bit_identical():
+    """fsgs_render_forward_reuse_colors: same cloud, another pose -- the colours copied from the earlier forward's packed
+    records are the ones a full evaluation gives (they do not depend on the pose), so images, records and the backward's
+    inputs are identical bit for bit; a state of the wrong size is refused."""
+    rng = np.random.default_rng(7)
+    W, H, P = 160, 128, 3000
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=4)
+    P = sc["_xyz"].shape[0]
+    pose_a = synth.pose_matrix((1.0, 0.01, -0.02, 0.015), (0.02, -0.01, 0.03)).astype(np.float32)
+    pose_b = synth.pose_matrix((1.0, -0.02, 0.01, 0.0), (-0.01, 0.02, 0.01)).astype(np.float32)
+    mk = lambda w2c: Fused(cam, sc["_xyz"], sc["_features_dc"], sc["_features_rest"], sc["_opacity"], sc["_scaling"],
+                           sc["_rotation"], w2c, np.zeros(3, np.float32), 3)
+    fa, fb = mk(pose_a), mk(pose_b)
+    lib = fa.lib
+    image, depth_sil = torch.empty_like(fb.image), torch.empty_like(fb.depth_sil)
+    radii = torch.empty_like(fb.radii)
+    state, scratch = torch.zeros_like(fb.state), torch.zeros_like(fb.scratch)
+    nr = C.c_int64(0)
+    call = lambda prev_bytes: lib.fsgs_render_forward_reuse_colors(
+        C.byref(fb.cfg), P, C.byref(fb.args), _lib.ptr(image), _lib.ptr(depth_sil), _lib.ptr(radii), _lib.ptr(state), fb.sb,
+        _lib.ptr(scratch), scratch.numel(), fb.cap, C.byref(nr), _lib.ptr(fa.state), prev_bytes, fa.cap, _lib.current_stream())
+    _lib.check(call(fa.sb), "fsgs_render_forward_reuse_colors")
+    torch.cuda.synchronize()
+    assert nr.value == fb.nr and torch.equal(radii, fb.radii)
+    assert torch.equal(image, fb.image) and torch.equal(depth_sil, fb.depth_sil)
+    off = (C.c_size_t * 9)()
+    _lib.check(lib.fsgs_render_state_layout(P, W, H, fb.cap, off), "layout")
+    rec = lambda st: st[off[7]:off[7] + 64 * P].view(torch.float32)
+    flg = lambda st: st[off[8]:off[8] + 4 * P].view(torch.int32)
+    assert torch.equal(rec(state), rec(fb.state)) and torch.equal(flg(state), flg(fb.state))
+    assert not torch.equal(rec(fa.state), rec(fb.state))  # (the two poses do project differently)
+    assert call(fa.sb - 64) == _lib.FSGS_ERR_STATE
