@@ -152,6 +152,23 @@ __device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], i
   return dpp_add<0xB1>(z);
 }
 
+// ... and when v[5..7] and v[13..15] are known to be zero (two Gaussians x 8 slots of which the pose-only backward uses
+// 5): three of the eight swap + add pairs of the first step only move zeros.
+__device__ __forceinline__ float wave_transpose_reduce16_5of8(const float (&v)[16], int lane) {
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int i = 0; i < 5; i++) w[i] = swap32_add(v[i], v[i + 8]);
+#pragma unroll
+  for (int i = 5; i < 8; i++) w[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) x[i] = swap16_add(w[i], w[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; i++) y[i] = fold_bit3(x[i], x[i + 2]);
+  float z = fold_bit2(y[0], y[1]);
+  z = dpp_add<0x4E>(z);
+  return dpp_add<0xB1>(z);
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ int dpp_max_i(int v) {
   int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);

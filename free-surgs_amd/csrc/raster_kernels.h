@@ -920,7 +920,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       if (!any_group) continue;  // wave-uniform: none of the GP Gaussians touched any pixel of the tile
       // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
       float tot;
-      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16(v, lane);
+      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16_5of8(v, lane);  // slots 5..7 of a Gaussian stay zero
       else if constexpr (CG <= 4) tot = wave_transpose_reduce32_12of16(v, lane);  // slots 12..15 of a Gaussian stay zero
       else tot = wave_transpose_reduce32(v, lane);
       const int j_mine = jj - my_u;
