@@ -338,7 +338,9 @@ def main():
         # HBM bytes per launch measured offline with rocprofv3 --pmc (scripts/gpu_pmc.sh: separate passes, gfx950
         # FETCH_SIZE x2 correction calibrated on the Adam kernel) and VALU instruction counts (scripts/gpu_sq.sh) for
         # exactly this workload; a missing file or kernel key is an ERROR in the JSON line, never a silent null
-        key = "blend_bwd_kernel<%d; %s; false%s>" % (C, "true" if fused else "false", "; 4" if (use_fast and C == 6) else "")
+        # template arguments <C; SPLIT; POSE_ONLY; CGRAD[; ROW]> as rocprofv3 prints them; matched as a PREFIX so that a
+        # template parameter appended later does not orphan the entry (and if nothing matches, that is an error below)
+        key = "blend_bwd_kernel<%d; %s; false%s" % (C, "true" if fused else "false", "; 4" if (use_fast and C == 6) else "")
         try:
             import glob
 
@@ -350,9 +352,12 @@ def main():
             if world != 1 or pmc.get("config") != args.config or args.scene != "default" or args.densify_every:
                 roofline["traffic_note"] = "counters in %s were collected on config %s, default scene, 1 GPU" % (src, pmc.get("config"))
             else:
-                if key not in pmc["kernels"]:
-                    raise KeyError("%s has no entry %r (kernels: %s)" % (src, key, [k for k in pmc["kernels"] if "blend" in k]))
-                ent = pmc["kernels"][key]
+                hits = [k for k in pmc["kernels"] if k.startswith(key)]
+                if len(hits) != 1:
+                    raise KeyError("%s has %d entries starting with %r (kernels: %s)" % (
+                        src, len(hits), key, [k for k in pmc["kernels"] if "blend" in k]))
+                ent = pmc["kernels"][hits[0]]
+                roofline["traffic_kernel"] = hits[0]
                 roofline["traffic"] = ent["traffic_bytes"]
                 roofline["traffic_over_algorithmic"] = ent["traffic_bytes"] / b_alg
                 roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % src
@@ -385,9 +390,11 @@ def main():
         _lib.profile_enable(list(RASTER_GROUPS), stride=1)
         stepper.pairs_total = stepper.forward_calls = 0
         n_r = 24
-        for it in range(n_r):
+        stepper.reuse_colors = False  # the parameters do not move in this loop; a training step's always have: every
+        for it in range(n_r):         # forward evaluates the SH colours, as in the timed loop above
             stepper.mapping_step([it % n_frames], step_optimizer=False)
         torch.cuda.synchronize()
+        stepper.reuse_colors = True
         pr = _lib.profile_read()
         _lib.profile_enable([])
         Rr = int(round(stepper.pairs_total / max(stepper.forward_calls, 1)))

@@ -211,7 +211,7 @@ def sync_gradients(pc, bucket=None):
 def sync_densification_stats(pc):
     """xyz_gradient_accum SUM, denom SUM, max_radii2D MAX (scene/gaussian_model.py:678-681,
     train.py:299-303) so every rank takes identical clone/split/prune decisions."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _live():
         return
     v = pc.variables
     packed = torch.cat([v["xyz_gradient_accum"].reshape(-1), v["denom"].reshape(-1)])

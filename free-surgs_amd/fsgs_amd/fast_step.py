@@ -160,7 +160,7 @@ class FastStepper:
         # the previous forward's state instead of evaluating 48 SH coefficients per Gaussian again.
         ckey = (P, W, H, pc.active_sh_degree, pc.max_sh_degree, self.poses.cam_center._version) + tuple(
             (id(p[n]), p[n]._version) for n in PARAM_NAMES)
-        prev = self.__dict__.get("_color_src")
+        prev = self.__dict__.get("_color_src") if getattr(self, "reuse_colors", True) else None
         if prev is not None and (prev[0] != ckey or any(a is not b for a, b in zip(prev[4], (p[n] for n in PARAM_NAMES)))):
             prev = None
         for _attempt in range(3):
