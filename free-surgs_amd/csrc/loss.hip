@@ -70,18 +70,34 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
   const size_t plane = (size_t)H * W;
   const float *ip = img + ch * plane, *gp = gt + ch * plane;
-  for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
-    int ly = i / SS_IN, lx = i - ly * SS_IN;
-    int gy = y0 + ly - SS_HALO, gx = x0 + lx - SS_HALO;
-    float a = 0.f, b = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {  // zero padding (F.conv2d padding=5)
-      size_t p = (size_t)gy * W + gx;
-      float m = pixel_mask(mask, presence, p);
-      a = ip[p] * m;
-      b = gp[p] * m;
+  // every global load of the (tile + halo) window is issued before the first is waited for: a rolled loop with the
+  // mask / presence branches inside waits for two memory round trips per round, 14 in a row (measured: 57 -> see DESIGN)
+  constexpr int NLD = (SS_IN * SS_IN + 255) / 256;
+  const float *mp = mask ? mask : ip, *pp = presence ? presence : ip;  // a valid address either way; unused values are dropped
+  float va[NLD], vb[NLD], vm[NLD], vp[NLD];
+  bool inb[NLD];
+#pragma unroll
+  for (int r = 0; r < NLD; r++) {
+    const int i = threadIdx.x + 256 * r;
+    const int ly = i / SS_IN, lx = i - ly * SS_IN;
+    const int gy = y0 + ly - SS_HALO, gx = x0 + lx - SS_HALO;
+    inb[r] = i < SS_IN * SS_IN && gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: zero padding (F.conv2d padding=5)
+    const size_t p = inb[r] ? (size_t)gy * W + gx : 0;
+    va[r] = ip[p];
+    vb[r] = gp[p];
+    vm[r] = mp[p];
+    vp[r] = pp[p];
+  }
+#pragma unroll
+  for (int r = 0; r < NLD; r++) {
+    const int i = threadIdx.x + 256 * r;
+    const int ly = i / SS_IN, lx = i - ly * SS_IN;
+    float m = mask ? vm[r] : 1.0f;  // pixel_mask()
+    if (presence) m = vp[r] > 0.f ? m : 0.f;
+    if (i < SS_IN * SS_IN) {
+      sx[ly][lx] = inb[r] ? va[r] * m : 0.f;
+      sy[ly][lx] = inb[r] ? vb[r] * m : 0.f;
     }
-    sx[ly][lx] = a;
-    sy[ly][lx] = b;
   }
   __syncthreads();
   // Both 11-tap passes are register-blocked: a thread produces SS_BLK consecutive outputs from SS_BLK + 10 inputs

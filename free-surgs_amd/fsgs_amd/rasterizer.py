@@ -33,14 +33,17 @@ class GaussianRasterizationSettings(NamedTuple):
 # cached) and its version counter.  A key made of (data_ptr, version, shape) alone is wrong: the caching allocator
 # hands the address of a freed camera matrix to the next one, which starts at version 0 again.
 _host_cache = {}
+_HOST_CACHE_ENTRIES = 1024  # 16 floats each
 
 
 def _host_floats(t, n):
     hit = _host_cache.get(id(t))
     if hit is None or hit[0] is not t or hit[1] != t._version:
-        if len(_host_cache) > 64:
-            _host_cache.clear()
         vals = [float(x) for x in t.detach().reshape(-1).to("cpu", torch.float32).tolist()]
+        _host_cache.pop(id(t), None)  # a stale version of the same tensor: re-inserted as the newest entry
+        while len(_host_cache) >= _HOST_CACHE_ENTRIES:
+            _host_cache.pop(next(iter(_host_cache)))  # oldest first (dicts keep insertion order): a sweep over more
+            # cameras than entries re-reads only what fell out, never the whole set at once
         hit = _host_cache[id(t)] = (t, t._version, vals)
     if len(hit[2]) < n:
         raise ValueError("camera tensor has %d elements, expected >= %d" % (len(hit[2]), n))
