@@ -624,7 +624,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
-    float *__restrict__ out_depth) {
+    float *__restrict__ out_depth, unsigned long long *__restrict__ dbg_times) {
+  // dbg_times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only; NULL otherwise):
+  // 100 MHz wall-clock stamps of this wave's start and end, to measure load balance and the kernel's tail
+  const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
   constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
   __shared__ float4 rec[64 * REC4];
@@ -731,6 +734,13 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       if (WITH_DEPTH) out_depth[pix] = D[k];
     }
   }
+  if (dbg_times && lane == 0) {
+    dbg_times[4 * blockIdx.x + 0] = dbg_t0;
+    dbg_times[4 * blockIdx.x + 1] = wall_clock64();
+    dbg_times[4 * blockIdx.x + 2] = 0;
+    dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
+                                    max(max(last[0], last[1]), max(last[2], last[3]));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,7 +786,9 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
-    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16) {
+    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16,
+    unsigned long long *__restrict__ dbg_times) {
+  const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;  // see blend_fwd_kernel
   constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;  // compile-time: shifts, no 64-bit mads
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   // 16 floats the NEXT kernel accumulates into with atomics (dL/dw2c): cleared here instead of by a separate fill
@@ -828,6 +840,7 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   }
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
+  const int dbg_walked = hi;
   // gradient component slots of one Gaussian (SL per Gaussian, GP Gaussians per transposing reduction):
   //   0..4 moments of w (mean2D x,y | conic A,B,C) | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
   //   POSE_ONLY: the five moments only
@@ -937,6 +950,12 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       }
     }
     hi = lo;
+  }
+  if (dbg_times && lane == 0) {
+    dbg_times[4 * blockIdx.x + 0] = dbg_t0;
+    dbg_times[4 * blockIdx.x + 1] = wall_clock64();
+    dbg_times[4 * blockIdx.x + 2] = 0;
+    dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
   }
 }
 
@@ -1231,8 +1250,10 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      const float4 *rec, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
   static int dbg_lds = getenv("FSGS_DBG_LDS_FWD") ? atoi(getenv("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
+  static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
+      getenv("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(getenv("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
   hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
-                     final_T, n_contrib, out_color, out_color2, out_depth);
+                     final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
   return 0;
 }
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
@@ -1241,8 +1262,10 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
                      float *clear16 = nullptr) {
   static int dbg_lds = getenv("FSGS_DBG_LDS") ? atoi(getenv("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
+  static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
+      getenv("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(getenv("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
   hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
-                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
+                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times);
   return 0;
 }
 

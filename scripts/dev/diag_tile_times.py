@@ -1,0 +1,73 @@
+"""Load balance of blend_bwd: every wave (= tile) stamps its start / end (100 MHz wall clock) into a buffer handed over
+through FSGS_DBG_TILE_TIMES.  Prints the makespan, the mean number of resident waves, the occupancy over time and how well
+the LPT key (list length) predicts a tile's duration compared with the depth actually walked (max n_contrib).
+    gpurun -- 'python scripts/dev/diag_tile_times.py'"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import bench  # noqa: E402
+os.makedirs('gpurun_out', exist_ok=True)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ntiles = 80 * 64
+    nwaves = ntiles
+    buf = torch.zeros((nwaves * 4,), dtype=torch.int64, device=dev)
+    os.environ["FSGS_DBG_TILE_TIMES_FWD" if "--fwd" in sys.argv else "FSGS_DBG_TILE_TIMES"] = str(buf.data_ptr())
+    slots = 6144 if "--fwd" in sys.argv else 4096
+    from fsgs_amd import _lib
+    from fsgs_amd.fast_step import FastStepper
+
+    _lib.load()
+    pc, poses, frames, cam, sc = bench.build_problem("C2", dev, 0, 1)
+    st = FastStepper(pc, poses, frames)
+    for it in range(12):
+        st.mapping_step([it % len(frames.colors)])
+    torch.cuda.synchronize()
+    for it in range(12, 15):
+        buf.zero_()
+        st.mapping_step([it % len(frames.colors)])
+        torch.cuda.synchronize()
+        d = buf.cpu().numpy().reshape(nwaves, 4)
+        t0, t1 = d[:, 0].astype(np.float64) * 0.01, d[:, 1].astype(np.float64) * 0.01  # us
+        ok = d[:, 1] > 0
+        lst = (d[:, 3] >> 32).astype(np.float64)
+        walked = (d[:, 3] & 0xFFFFFFFF).astype(np.float64)
+        start, end = t0[ok].min(), t1[ok].max()
+        dur = (t1 - t0)[ok]
+        print("step %d: %d waves, makespan %.1f us, busy %.0f wave-us -> mean resident waves %.0f of %d (%.1f %%)" % (
+            it, ok.sum(), end - start, dur.sum(), dur.sum() / (end - start), slots, 100 * dur.sum() / (end - start) / slots))
+        print("  tile duration us: mean %.1f  median %.1f  p90 %.1f  max %.1f;  list length mean %.0f max %.0f;  walked mean %.0f max %.0f" % (
+            dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), lst[ok].mean(), lst[ok].max(), walked[ok].mean(), walked[ok].max()))
+        print("  corr(duration, list length) %.3f   corr(duration, walked depth) %.3f" % (
+            np.corrcoef(dur, lst[ok])[0, 1], np.corrcoef(dur, walked[ok])[0, 1]))
+        np.save("gpurun_out/tile_times_%s_%d.npy" % ("fwd" if "--fwd" in sys.argv else "bwd", it),
+                np.stack([t0[ok] - start, t1[ok] - start, lst[ok], walked[ok]]))
+        for lo_, hi_ in ((0, 100), (100, 150), (150, 200), (200, 250), (250, 300), (300, 1000)):
+            sel = (lst[ok] >= lo_) & (lst[ok] < hi_)
+            if sel.any():
+                print("  list length %3d..%3d: %4d tiles, duration mean %.1f us, start mean %.1f us" % (
+                    lo_, hi_, sel.sum(), dur[sel].mean(), (t0[ok][sel] - start).mean()))
+        nb = 16
+        edges = np.linspace(start, end, nb + 1)
+        occ = []
+        for b in range(nb):
+            lo, hi = edges[b], edges[b + 1]
+            occ.append((np.clip(np.minimum(t1[ok], hi) - np.maximum(t0[ok], lo), 0, None)).sum() / (hi - lo))
+        print("  resident waves over time (%d bins): %s" % (nb, " ".join("%.0f" % o for o in occ)))
+        # start time of the k-th dispatched wave: when did the dispatcher run out of queued tiles?
+        order = np.argsort(t0[ok])
+        print("  last wave started at %.1f us of %.1f; waves started after 50 %% of the makespan: %d" % (
+            t0[ok][order[-1]] - start, end - start, int((t0[ok] - start > 0.5 * (end - start)).sum())))
+
+
+if __name__ == "__main__":
+    main()
