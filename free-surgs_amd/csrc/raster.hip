@@ -59,7 +59,7 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   if (rc != FSGS_OK) return rc;
   if (P > 0) {
     ProfScope ps(PROF_PREPROCESS_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx};
+    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx, binning_clear_words(ntiles)};
     switch (C) {  // the colours travel into the packed per-Gaussian record the blend kernels gather
       case 1: hipLaunchKernelGGL(preprocess_fwd_kernel<1>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, colors, opacities, scales, rotations, g); break;
       case 3: hipLaunchKernelGGL(preprocess_fwd_kernel<3>, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam, means3D, colors, opacities, scales, rotations, g); break;
@@ -68,7 +68,7 @@ int fsgs_raster_forward(const FsgsRasterCfg *cfg, int P, const float *means3D, c
   }
   FSGS_HIP(hipGetLastError());
   BinningTicket tk;
-  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream);
+  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream, /*cursors_cleared=*/true);  // by preprocess_fwd_kernel
   if (rc == FSGS_ERR_CAPACITY) *num_rendered = (int64_t)ntiles * BIN_SUBS * 32;  // not even one key per segment
   if (rc != FSGS_OK) return rc;
   const int2 *ranges = B.ranges;

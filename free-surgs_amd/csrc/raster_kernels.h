@@ -108,9 +108,18 @@ struct GeomOut {  // per-Gaussian arrays written by every preprocess kernel
   int32_t *radii;
   uint32_t *tiles;
   ushort4 *rect;
-  uint32_t *tile_count;  // [tiles * BIN_SUBS] histogram of the binning count pass (zeroed by the host)
+  uint32_t *tile_count;  // [tiles * BIN_SUBS] cursors of the binning pass, followed by {R, overflow report}
   int gx;
+  uint32_t clear_words;  // > 0: the preprocess kernel clears that many words of tile_count (see clear_binning_cursors)
 };
+// The binning cursors must be zero when bin_scatter_kernel starts.  Nothing in front of it reads them, so the
+// preprocess kernel -- the launch in front of it on the same stream -- clears them on the side (a few dozen words
+// per workgroup) instead of a 5 us fill kernel of its own sitting in the step's critical path.
+__device__ __forceinline__ void clear_binning_cursors(const GeomOut &g) {
+  if (g.clear_words == 0) return;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < g.clear_words; w += gridDim.x * blockDim.x)
+    g.tile_count[w] = 0u;
+}
 // Same-address atomics serialise at ~46 ns each on MI355X (profiles/r01_atomic_scope_ubench.txt): the longest tile
 // list alone would cost > 100 us per binning pass.  Every tile therefore owns BIN_SUBS counters / cursors, picked by
 // the Gaussian index, and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams ca
                                                              const float *__restrict__ opac,
                                                              const float *__restrict__ scales,
                                                              const float *__restrict__ rots, GeomOut g) {
+  clear_binning_cursors(g);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   {
@@ -1193,8 +1203,10 @@ struct BinningTicket {
   volatile uint32_t *slot = nullptr;
   uint32_t cap_sub = 0;
 };
+inline uint32_t binning_clear_words(int ntiles) { return (uint32_t)ntiles * BIN_SUBS + 4u; }
+// cursors_cleared: the preprocess kernel in front of this call was given GeomOut.clear_words = binning_clear_words()
 inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t max_pairs, BinningTicket &tk,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool cursors_cleared = false) {
   const int ntiles = cam.gx * cam.gy;
   if (ntiles > 1024 * 64) return FSGS_ERR_INVALID;
   const int64_t cap = max_pairs / ((int64_t)ntiles * BIN_SUBS);
@@ -1202,7 +1214,8 @@ inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t m
   if (tk.cap_sub == 0) return FSGS_ERR_CAPACITY;
   // cursors [tiles * 8] followed by {R, overflow report}
   // (+4 words, not +2: a size that is a multiple of 16 bytes stays ONE fill kernel)
-  FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * ((size_t)ntiles * BIN_SUBS + 4), stream));
+  if (!cursors_cleared || P <= 0)
+    FSGS_HIP(hipMemsetAsync(B.tile_count, 0, sizeof(uint32_t) * (size_t)binning_clear_words(ntiles), stream));
   if (P > 0) {
     ProfScope ps(PROF_SORT_DEPTH, stream);  // scatter pass
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, cam.gx, B.tiles, B.rect, B.xy,

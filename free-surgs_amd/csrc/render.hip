@@ -155,6 +155,7 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
                                                              const float4 *__restrict__ prev_rec,
                                                              const uint32_t *__restrict__ prev_flags) {
   __shared__ __attribute__((aligned(16))) float s_rest[REUSE ? 4 : RB * SH_REST_MAX];
+  clear_binning_cursors(g);
   const int b0 = blockIdx.x * blockDim.x;
   int i = b0 + threadIdx.x;
   const int row = (a.K - 1) * 3;  // floats of f_rest per Gaussian
@@ -637,7 +638,7 @@ static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRender
   if (rc != FSGS_OK) return rc;
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
-    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx};
+    GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx, binning_clear_words(ntiles)};
     if (prev_state) {
       StateLayout PL = state_layout(P, W, H, prev_max_pairs, 6);
       if (prev_state_bytes < PL.total || prev_state == state) return FSGS_ERR_STATE;
@@ -651,7 +652,7 @@ static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRender
   }
   FSGS_HIP(hipGetLastError());
   BinningTicket tk;
-  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream);
+  rc = enqueue_binning(cam, P, B, max_pairs, tk, stream, /*cursors_cleared=*/true);  // by render_pre_fwd_kernel
   if (rc == FSGS_ERR_CAPACITY) *num_rendered = (int64_t)ntiles * BIN_SUBS * 32;  // not even one key per segment
   if (rc != FSGS_OK) return rc;
   {
