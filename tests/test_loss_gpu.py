@@ -160,3 +160,62 @@ def test_randomised_shapes_pearson(seed):
     assert abs(la.item() - lb.item()) <= 1e-4 * abs(lb.item()) + 1e-7, (H, W, box, n)
     scale = b.grad.abs().max().item()
     assert (a.grad - b.grad).abs().max().item() <= 2e-4 * scale, (H, W, box, n)
+
+
+@pytest.mark.parametrize("shape,masked", [((3, 64, 96), False), ((3, 250, 333), True), ((3, 1024, 1280), True)])
+def test_fused_forward_backward_entry_equals_the_two_calls(shape, masked):
+    """fsgs_photometric_loss_forward_backward (what the step driver calls: forward + backward launches, the loss value
+    finished by an extra workgroup of the backward) against fsgs_photometric_loss_forward + _backward, through the raw
+    C ABI: same kernels, so loss terms and gradient must be bit-identical; with and without mask / presence plane."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+
+    lib = _lib.load()
+    Cc, H, W = shape
+    torch.manual_seed(3)
+    gt = torch.rand(shape, device=DEV)
+    img = (gt + 0.1 * torch.randn(shape, device=DEV)).clamp(0, 1).contiguous()
+    mask = (torch.rand((H, W), device=DEV) > 0.2).float().contiguous() if masked else None
+    presence = (torch.rand((H, W), device=DEV) - 0.1).contiguous() if masked else None
+    up = torch.tensor([0.7], device=DEV)
+    nb = int(lib.fsgs_photometric_scratch_bytes(Cc, H, W))
+    stream = _lib.current_stream()
+
+    def run(fused):
+        maps = torch.empty((3, Cc, H, W), device=DEV)
+        sums = torch.zeros((nb,), dtype=torch.uint8, device=DEV)
+        out3 = torch.zeros((3,), device=DEV)
+        dimg = torch.zeros(shape, device=DEV)
+        if fused:
+            _lib.check(lib.fsgs_photometric_loss_forward_backward(
+                Cc, H, W, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(mask), _lib.ptr(presence), 0.2, _lib.ptr(maps), _lib.ptr(sums),
+                _lib.ptr(out3), _lib.ptr(up), _lib.ptr(dimg), stream), "fsgs_photometric_loss_forward_backward")
+        else:
+            _lib.check(lib.fsgs_photometric_loss_forward(
+                Cc, H, W, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(mask), _lib.ptr(presence), 0.2, _lib.ptr(maps), _lib.ptr(sums),
+                _lib.ptr(out3), stream), "fsgs_photometric_loss_forward")
+            _lib.check(lib.fsgs_photometric_loss_backward(
+                Cc, H, W, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(mask), _lib.ptr(presence), _lib.ptr(maps), _lib.ptr(up), 0.2,
+                _lib.ptr(dimg), stream), "fsgs_photometric_loss_backward")
+        torch.cuda.synchronize()
+        return out3.cpu(), dimg.cpu()
+
+    a3, ad = run(False)
+    b3, bd = run(True)
+    # the finish runs as one wave (fused) or one 256-thread block (two calls): both sum the per-workgroup partials in
+    # double precision, in a different order -- the float results may differ in the last place
+    assert torch.allclose(a3, b3, rtol=2e-7, atol=0), (a3, b3)
+    assert torch.equal(ad, bd)
+    assert float(b3[0]) > 0 and bool(torch.isfinite(bd).all()) and float(bd.abs().max()) > 0
+    # and against the torch statement of the op (same check as the two-call route gets above)
+    x = img.clone().requires_grad_(True)
+    m = None if not masked else (mask * (presence > 0).float())[None]
+    ref = losses.rgb_loss_torch(x, gt, mask=m)
+    (0.7 * ref).backward()
+    assert abs(float(b3[0]) - float(ref.detach())) <= 2e-5 * abs(float(ref.detach()))
+    scale = float(x.grad.abs().max())
+    assert float((bd.to(DEV) - x.grad).abs().max()) <= 1e-4 * scale
+    # argument checks of the new entry
+    assert lib.fsgs_photometric_loss_forward_backward(0, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, None, None, None,
+                                                      None, None, stream) == _lib.FSGS_ERR_INVALID
