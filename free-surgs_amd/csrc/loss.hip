@@ -161,15 +161,18 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
       float A2 = 2.f * (e12 - m1 * m2) + SS_C2;
       float B1 = m1 * m1 + m2 * m2 + SS_C1;
       float B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + SS_C2;
-      float inv = 1.0f / (B1 * B2);
+      // v_rcp_f32 (1 ulp) instead of four IEEE divisions per output: each of those expands to ~10 instructions
+      // (div_scale, rcp, Newton steps, div_fixup) -- a fifth of this kernel's VALU work for a 24th bit the loss never sees
+      const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
+      float inv = rB1 * rB2;
       float S = A1 * A2 * inv;
       ss_acc += S;
       float a = sx[ly + SS_HALO][lx + SS_HALO], b = sy[ly + SS_HALO][lx + SS_HALO];
       l1_acc += fabsf(a - b);
       size_t p = ch * plane + (size_t)gy * W + gx;
-      maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (1.0f / B1 - 1.0f / B2);  // d/dm1
-      maps[cplane + p] = -S / B2;                                                       // d/de11
-      maps[2 * cplane + p] = 2.f * A1 * inv;                                            // d/de12
+      maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (rB1 - rB2);  // d/dm1
+      maps[cplane + p] = -S * rB2;                                         // d/de11
+      maps[2 * cplane + p] = 2.f * A1 * inv;                               // d/de12
     }
   }
   float t1 = block_sum_256(l1_acc, red);
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
   const float k_l1 = up * (1.0f - lambda_dssim) * invN, k_ss = -up * lambda_dssim * invN;
   float ring[11][3];
   float n0[3], n1[3];
+  float nx = 0.f, ny = 0.f, nm = 1.f, np_ = 1.f;  // next output row's pixel (first output row: iteration 2 * SS_HALO)
   fetch_row(y0 - SS_HALO, n0, n1);
   for (int r0 = 0; r0 < ST_NR; r0 += 11) {
 #pragma unroll
@@ -301,6 +305,21 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
       }
       __syncthreads();
       if (r + 1 < ST_NR) fetch_row(y0 - SS_HALO + r + 1, n0, n1);
+      // The output row's own pixel (image, target, mask, presence) was requested one ROW ITERATION ago, like the map rows:
+      // at the point of use the loads cost one exposed memory round trip per output row.  Branch-free (clamped address,
+      // every load issued, unused values dropped): a load inside a conditional block is waited for at the block's end.
+      const int oy = y0 + r - 2 * SS_HALO;
+      const bool out_ok = r >= 2 * SS_HALO && oy < H && gx < W;
+      const float ex = nx, ey = ny, em = nm, ep = np_;
+      {
+        const int oy1 = oy + 1;
+        const bool ok1 = r + 1 >= 2 * SS_HALO && r + 1 < ST_NR && oy1 < H && gx < W;
+        const size_t epp = ok1 ? (size_t)oy1 * W + gx : 0;
+        nx = img[ch * plane + epp];
+        ny = gt[ch * plane + epp];
+        nm = (mask ? mask : img)[epp];
+        np_ = (presence ? presence : img)[epp];
+      }
 #pragma unroll
       for (int m = 0; m < 3; m++) {
         float acc = 0.f;
@@ -317,11 +336,11 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
         for (int k = 0; k < 11; k++) acc = fmaf(kGauss[k], ring[(q + 1 + k) % 11][m], acc);
         f[m] = acc;
       }
-      const int oy = y0 + r - 2 * SS_HALO;
-      if (oy < H && gx < W) {
-        const size_t pp = (size_t)oy * W + gx, p = ch * plane + pp;
-        const float mk = pixel_mask(mask, presence, pp);
-        const float x = img[p] * mk, y = gt[p] * mk;
+      if (out_ok) {
+        const size_t p = ch * plane + (size_t)oy * W + gx;
+        float mk = mask ? em : 1.0f;  // pixel_mask()
+        if (presence) mk = ep > 0.f ? mk : 0.f;
+        const float x = ex * mk, y = ey * mk;
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         dimg[p] = mk * (k_l1 * sgn + k_ss * (f[0] + 2.f * x * f[1] + y * f[2]));
