@@ -209,8 +209,9 @@ struct SplatEval {
   float alpha;  // min(0.99, a)
 };
 __device__ __forceinline__ float splat_exponent(float ca, float cb, float cc, float dx, float dy) {
-  const float q = __fmaf_rn(__fmul_rn(cc, dy), dy, __fmul_rn(__fmul_rn(ca, dx), dx));
-  return __fmaf_rn(__fmul_rn(cb, dx), dy, q);
+  // dx (a dx + b dy) + c dy^2: five instructions (the term-by-term form needs six)
+  const float q = __fmul_rn(__fmaf_rn(cb, dy, __fmul_rn(ca, dx)), dx);
+  return __fmaf_rn(__fmul_rn(cc, dy), dy, q);
 }
 __device__ __forceinline__ bool splat_alpha(float gx, float gy, float ca, float cb, float cc, float o, float px,
                                             float py, SplatEval &e) {
