@@ -332,9 +332,27 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
   while (m < n) m <<= 1;
   unsigned long long *gk = keys + base;
   if (n <= SORT_LDS_KEYS) {
+    // the eight sub-lists are staged as ONE flat range [0, n): a loop per sub-list is eight dependent load -> LDS-store
+    // round trips in a row (most sub-lists are shorter than the workgroup), this is one (two beyond 256 keys)
+    for (int i0 = 0; i0 < n; i0 += 2 * (int)blockDim.x) {
+      unsigned long long kv[2];
+      int at[2];
 #pragma unroll
-    for (int s = 0; s < BIN_SUBS; s++)
-      for (uint32_t i = threadIdx.x; i < cnt[s]; i += blockDim.x) lds[off[s] + i] = gk[(size_t)s * cap_sub + i];
+      for (int u = 0; u < 2; u++) {
+        at[u] = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+        const uint32_t i = (uint32_t)min(at[u], n - 1);
+        int sseg = 0;
+#pragma unroll
+        for (int q = 1; q < BIN_SUBS; q++) sseg += (i >= off[q]) ? 1 : 0;  // off[] ascends; empty sub-lists are skipped over
+        uint32_t o = off[0];
+#pragma unroll
+        for (int q = 1; q < BIN_SUBS; q++) o = (sseg >= q) ? off[q] : o;
+        kv[u] = gk[(size_t)sseg * cap_sub + (i - o)];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (at[u] < n) lds[at[u]] = kv[u];
+    }
     if (n <= SORT_RANK_KEYS) {
       // Short lists (most tiles: mean 214 at C2): RANK sort.  Keys are unique (the Gaussian index sits in the low
       // word), so a key's final position is the number of keys below it; thread t counts that for key t against
