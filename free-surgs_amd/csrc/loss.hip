@@ -372,12 +372,32 @@ __global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int bo
   if (begin >= n) return;
   const int end = min(n, begin + PE_CHUNK);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-  for (int i = begin + threadIdx.x; i < end; i += 256) {
-    int y = i / rw, x = i - y * rw;
-    size_t p = (size_t)(ry + y) * W + (rx + x);
-    float s = src[p], t = tgt[p];
-    a0 += s; a1 += t;
-    a2 = fmaf(s, s, a2); a3 = fmaf(t, t, a3); a4 = fmaf(s, t, a4);
+  // a thread's 16 pixels (i = begin + t + 256 k) in two batches of eight: all loads of a batch are issued before the
+  // first is used (one pixel per loop iteration is 16 dependent memory round trips); the sums still grow in the order
+  // k = 0, 1, ..  Row / column of consecutive k follow by increments, one division per thread.
+  constexpr int PB = 8;
+  const int dq = 256 / rw, dr = 256 % rw;
+  int i = begin + (int)threadIdx.x;
+  int y = i / rw, x = i - y * rw;
+  for (; i < end; i += 256 * PB) {
+    float sv[PB], tv[PB];
+#pragma unroll
+    for (int k = 0; k < PB; k++) {
+      const bool ok = i + 256 * k < end;
+      const size_t p = ok ? (size_t)(ry + y) * W + (rx + x) : 0;
+      sv[k] = src[p];
+      tv[k] = tgt[p];
+      x += dr;
+      y += dq;
+      if (x >= rw) { x -= rw; y++; }
+    }
+#pragma unroll
+    for (int k = 0; k < PB; k++)
+      if (i + 256 * k < end) {
+        const float s_ = sv[k], t_ = tv[k];
+        a0 += s_; a1 += t_;
+        a2 = fmaf(s_, s_, a2); a3 = fmaf(t_, t_, a3); a4 = fmaf(s_, t_, a4);
+      }
   }
   float t0 = block_sum_256(a0, red), t1 = block_sum_256(a1, red), t2 = block_sum_256(a2, red);
   float t3 = block_sum_256(a3, red), t4 = block_sum_256(a4, red);
@@ -393,46 +413,50 @@ __global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int bo
 //   co = cov / ((sd_s+eps)(sd_t+eps)), cov = E[st]-E[s]E[t] (biased, mean()), sd unbiased
 //   coef[r] = {mean_s, mean_t, 1/(N*D), cov/(D*(sd_t+eps)*(N-1)*sd_t), cov/(D*(sd_s+eps)*(N-1)*sd_s), loss}
 // one 64-thread workgroup per region
-__global__ __launch_bounds__(64) void pearson_finish_kernel(int H, int W, int box, int nregions,
-                                                            const double *__restrict__ partials, int n0, int nb,
-                                                            float *__restrict__ coef, float *__restrict__ out) {
-  const int r = blockIdx.x;
-  const int cnt = r == 0 ? n0 : nb;
-  const double *base = partials + 5 * (size_t)(r == 0 ? 0 : n0 + (r - 1) * nb);
-  double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = threadIdx.x; i < cnt; i += 64)
+// ONE workgroup of 16 waves: wave w finishes regions w, w + 16, ..; after a barrier wave 0 adds the patch losses in the
+// order of the reference's python loop.  (Two launches -- one workgroup per region, then the mean -- cost 12 us of launch
+// latency on the side stream for microseconds of work.)
+__global__ __launch_bounds__(1024) void pearson_finish_kernel(int H, int W, int box, int nregions,
+                                                              const double *__restrict__ partials, int n0, int nb,
+                                                              float *__restrict__ coef, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < nregions; r += 16) {
+    const int cnt = r == 0 ? n0 : nb;
+    const double *base = partials + 5 * (size_t)(r == 0 ? 0 : n0 + (r - 1) * nb);
+    double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = lane; i < cnt; i += 64)
 #pragma unroll
-    for (int q = 0; q < 5; q++) st[q] += base[5 * i + q];
+      for (int q = 0; q < 5; q++) st[q] += base[5 * i + q];
 #pragma unroll
-  for (int q = 0; q < 5; q++)
+    for (int q = 0; q < 5; q++)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) st[q] += __shfl_xor(st[q], off, 64);
-  if (threadIdx.x == 0) {
-    double N = r == 0 ? (double)H * W : (double)box * box;
-    double ms = st[0] / N, mt = st[1] / N;
-    double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
-    vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
-    double sds = sqrt(vs), sdt = sqrt(vt);
-    double cov = st[4] / N - ms * mt;
-    double D = (sds + 1e-6) * (sdt + 1e-6);
-    float *c = coef + 8 * r;
-    c[0] = (float)ms; c[1] = (float)mt; c[2] = (float)(1.0 / (N * D));
-    c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
-    c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
-    c[5] = (float)(1.0 - cov / D);
-    if (r == 0) out[0] = c[5];  // global loss
+      for (int off = 32; off > 0; off >>= 1) st[q] += __shfl_xor(st[q], off, 64);
+    if (lane == 0) {
+      double N = r == 0 ? (double)H * W : (double)box * box;
+      double ms = st[0] / N, mt = st[1] / N;
+      double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
+      vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
+      double sds = sqrt(vs), sdt = sqrt(vt);
+      double cov = st[4] / N - ms * mt;
+      double D = (sds + 1e-6) * (sdt + 1e-6);
+      float *c = coef + 8 * r;
+      c[0] = (float)ms; c[1] = (float)mt; c[2] = (float)(1.0 / (N * D));
+      c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
+      c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
+      c[5] = (float)(1.0 - cov / D);
+      if (r == 0) out[0] = c[5];  // global loss
+    }
   }
-}
-__global__ void pearson_local_mean_kernel(int nregions, const float *__restrict__ coef, float *__restrict__ out) {
-  // one wave: lane r fetches region r's loss (parallel loads), lane 0 then adds them in the order of the
-  // reference's python loop (nregions <= 65)
-  const int lane = threadIdx.x;
-  const float mine = (lane >= 1 && lane < nregions) ? coef[8 * lane + 5] : 0.f;
-  const float last = nregions > 64 ? coef[8 * 64 + 5] : 0.f;
-  float acc = 0.f;
-  for (int r = 1; r < nregions && r < 64; r++) acc += readlane(mine, r);
-  if (nregions > 64) acc += last;
-  if (lane == 0) out[1] = nregions > 1 ? acc / (float)(nregions - 1) : 0.f;
+  __syncthreads();  // (the coefficient rows were written to global memory by this workgroup: visible after the barrier)
+  if (wave == 0) {
+    // lane r fetches region r's loss (parallel loads), lane 0 then adds them in the reference's order (nregions <= 65)
+    const float mine = (lane >= 1 && lane < nregions) ? coef[8 * lane + 5] : 0.f;
+    const float last = nregions > 64 ? coef[8 * 64 + 5] : 0.f;
+    float acc = 0.f;
+    for (int r = 1; r < nregions && r < 64; r++) acc += readlane(mine, r);
+    if (nregions > 64) acc += last;
+    if (lane == 0) out[1] = nregions > 1 ? acc / (float)(nregions - 1) : 0.f;
+  }
 }
 
 // d(loss_r)/d tgt_i = -(s_i-ms)/(N D) + cov/(D (sd_t+eps) (N-1) sd_t) (t_i - mt), weighted by weight[r]
@@ -453,24 +477,55 @@ __global__ __launch_bounds__(256) void pearson_bwd_kernel(int H, int W, int box,
   }
   __syncthreads();
   const size_t n = (size_t)H * W;
-  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (size_t)gridDim.x * 256) {
-    int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    float s = src[p], t = tgt[p];
-    float g = 0.f;
-    {
-      const float *c = s_coef[0];
-      float a = s - c[0], b = t - c[1];
-      g += wrt_src ? (-b * c[2] + c[4] * a) : (-a * c[2] + c[3] * b);
+  // A chunk of 256 consecutive pixels meets only a few of the patches (~1.5 of 40 at C2): the workgroup first lists, in
+  // ascending order, the patches whose rectangle touches the chunk's rows and columns at all, and every pixel then tests
+  // that short list instead of all of them (40 rectangle tests per pixel were 90 % of this kernel's instructions).  The
+  // terms of a pixel are still added in ascending region order.
+  __shared__ int s_list[65];
+  __shared__ int s_nlist;
+  for (size_t c0 = (size_t)blockIdx.x * 256; c0 < n; c0 += (size_t)gridDim.x * 256) {
+    const size_t c1 = min(n, c0 + 256) - 1;  // last pixel of the chunk
+    const int ya = (int)(c0 / W), yb = (int)(c1 / W);
+    const int xa = ya == yb ? (int)(c0 - (size_t)ya * W) : 0, xb = ya == yb ? (int)(c1 - (size_t)yb * W) : W - 1;
+    __syncthreads();  // the previous chunk's list is no longer read
+    if (threadIdx.x < 64) {  // one wave builds the list: lanes test regions l + 1 and l + 65 - 64 .. (nregions <= 65)
+      int cnt = 0;
+      for (int r0 = 1; r0 < nregions; r0 += 64) {
+        const int r = r0 + (int)threadIdx.x;
+        bool hit = false;
+        if (r < nregions) {
+          const int py = s_rect[r][0], px_ = s_rect[r][1];
+          hit = py <= yb && py + box > ya && px_ <= xb && px_ + box > xa;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) s_list[cnt + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = r;
+        cnt += __popcll(m);
+      }
+      if (threadIdx.x == 0) s_nlist = cnt;
     }
-    for (int r = 1; r < nregions; r++) {
-      int dy = y - s_rect[r][0], dx = x - s_rect[r][1];
-      if ((unsigned)dy < (unsigned)box && (unsigned)dx < (unsigned)box) {
-        const float *c = s_coef[r];
-        float a = s - c[0], b = t - c[1];
+    __syncthreads();
+    const size_t p = c0 + threadIdx.x;
+    if (p < n) {
+      const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+      const float s_ = src[p], t = tgt[p];
+      float g = 0.f;
+      {
+        const float *c = s_coef[0];
+        float a = s_ - c[0], b = t - c[1];
         g += wrt_src ? (-b * c[2] + c[4] * a) : (-a * c[2] + c[3] * b);
       }
+      const int nl = s_nlist;
+      for (int q = 0; q < nl; q++) {
+        const int r = s_list[q];
+        int dy = y - s_rect[r][0], dx = x - s_rect[r][1];
+        if ((unsigned)dy < (unsigned)box && (unsigned)dx < (unsigned)box) {
+          const float *c = s_coef[r];
+          float a = s_ - c[0], b = t - c[1];
+          g += wrt_src ? (-b * c[2] + c[4] * a) : (-a * c[2] + c[3] * b);
+        }
+      }
+      grad[p] = g;
     }
-    grad[p] = g;
   }
 }
 
@@ -561,9 +616,8 @@ int fsgs_pearson_forward(int H, int W, int n_patches, int box, const int64_t *pa
     dim3 grid(n0 > nb ? n0 : nb, nreg);
     hipLaunchKernelGGL(pearson_stats_kernel, grid, dim3(256), 0, stream, H, W, box, patch_row0, patch_col0, src, tgt,
                        partials, n0, nb);
-    hipLaunchKernelGGL(pearson_finish_kernel, dim3(nreg), dim3(64), 0, stream, H, W, box, nreg, partials, n0, nb, coef,
+    hipLaunchKernelGGL(pearson_finish_kernel, dim3(1), dim3(1024), 0, stream, H, W, box, nreg, partials, n0, nb, coef,
                        out2);
-    hipLaunchKernelGGL(pearson_local_mean_kernel, dim3(1), dim3(64), 0, stream, nreg, coef, out2);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

@@ -302,11 +302,21 @@ class FastStepper:
             for k, ts in enumerate(timesteps):
                 w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
                        else self.poses.get_pose(ts).detach().contiguous())
+                # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound) are independent
+                # until the render backward: they run on two HIP streams.  What the side stream can do without the render
+                # -- the two randint launches of the patch corners (same position in the RNG sequence as at loss time:
+                # nothing else draws in between) and the clear of the backward's accumulators (free since the previous
+                # backward, which is in front of `begun` on the main stream) -- is queued before the forward, so that the
+                # chain behind the forward is the three Pearson launches only.
+                side = self._side_stream(dev)
+                begun = torch.cuda.Event()
+                begun.record()
+                side.wait_event(begun)
+                with torch.cuda.stream(side):
+                    cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+                    b.bwd_scratch.zero_()
                 args, state, sbytes, cap, nr = self._render_forward(w2c, b)
                 gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
-                # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound, plus the
-                # two randint launches) are independent until the render backward: they run on two HIP streams.
-                side = self._side_stream(dev)
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
                 # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
@@ -317,7 +327,6 @@ class FastStepper:
                 side.wait_event(fwd_done)
                 with torch.cuda.stream(side):
                     sstream = _lib.current_stream()
-                    cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
                     dep = b.depth_sil[0]
                     _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
                                                         _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
@@ -325,7 +334,6 @@ class FastStepper:
                     _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
                                                          _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
                                                          0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
-                    b.bwd_scratch.zero_()  # the backward's accumulators, cleared here instead of in front of the blend
                     side_done = torch.cuda.Event()
                     side_done.record()
                     for t_ in cr:  # drawn on the side stream, last used there
