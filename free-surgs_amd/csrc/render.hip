@@ -12,6 +12,8 @@
 //   backward: their adjoints, including the camera-pose gradient
 //             dL/dw2c[:3,:4] = sum_i g_i [x_i;1]^T reduced in-kernel (wave DPP + one atomic per block).
 // `viewspace_points.grad` is the RGB pass's own mean2D gradient (blend_bwd SPLIT slots 6,7).
+#include <algorithm>
+
 #include "raster_kernels.h"
 
 namespace {
@@ -537,6 +539,58 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   }
 }
 
+// The tracking step's per-Gaussian backward (gs_grad = False, no parameter gradients): the only output is dL/dw2c =
+// sum_i dL/dx_cam,i [x_i; 1]^T, twelve sums over ALL Gaussians.  render_pre_bwd_kernel<OUT_GRADS> ends every 256-Gaussian
+// workgroup with one atomic per component: 1172 same-address atomics per component at C2, ~20 ns each -- a third of
+// that launch.  Here at most 512 workgroups walk the row blocks, keep the twelve partial sums in registers and add
+// them to the result once; no SH block, no LDS staging, no gradient sink.
+__global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParams cam, RenderDev a,
+                                                                  const int32_t *__restrict__ radii,
+                                                                  const float4 *__restrict__ conic_op,
+                                                                  const float *__restrict__ grad_acc,
+                                                                  float *__restrict__ dw2c) {
+  __shared__ float red[12][RB / 64];
+  float part[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) part[q] = 0.f;
+  for (int i = blockIdx.x * RB + threadIdx.x; i < P; i += gridDim.x * RB) {
+    const int rad = radii[i];
+    const RawGaussian raw = load_raw(a, i);
+    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kFusedRow);  // moments | colour sums (dc[3], dc[5]: depth)
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    const float2 a3 = *(const float2 *)(ap + 3);
+    const float4 co = conic_op[i];
+    if (rad <= 0) continue;
+    const float acc[kAccStride] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    Activated act = activate(a, raw);
+    float ga[8];
+    unpack_moments(acc, co, ga);
+    GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
+    const float *V = cam.V;
+    const float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
+    const float dzq = a2.w + 2.f * zq * a3.y;  // dL/d(depth colour) + 2 z dL/d(depth^2 colour): zero in the tracking step
+    const float gxc[3] = {gg.dm[0] + V[8] * dzq, gg.dm[1] + V[9] * dzq, gg.dm[2] + V[10] * dzq};
+    const float x4[4] = {raw.x, raw.y, raw.z, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) part[4 * r + c] = fmaf(gxc[r], x4[c], part[4 * r + c]);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    const float t = wave_sum(part[q]);
+    if (lane == 0) red[q][wid] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < RB / 64; w++) t += red[threadIdx.x][w];
+    if (t != 0.f) atomicAdd(dw2c + threadIdx.x, t);
+  }
+}
+
 // Adam step of all six groups from the compact per-Gaussian gradient (see OUT_COMPACT): the SH gradients
 // basis_k x gcol_c are formed here, in LDS, and never exist in HBM.  The basis uses the position BEFORE this
 // step's update, i.e. the one the forward pass saw.
@@ -731,7 +785,9 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
     return FSGS_OK;
   }
   if (!args_ok(args, P) || !radii || !scratch) return FSGS_ERR_INVALID;
-  if (!grads->means2D && !adam && !compact) return FSGS_ERR_INVALID;  // the autograd-facing form always has a holder
+  // the autograd-facing form always has a holder for dL/dmeans2D; only the pose-only call (gs_grad = param_grads = 0:
+  // the reference's viewspace_points carries no gradient then) may leave it out
+  if (!grads->means2D && !adam && !compact && (gs_grad || param_grads || !cam_grad)) return FSGS_ERR_INVALID;
   if (cam_grad && !grads->w2c) return FSGS_ERR_INVALID;
   if (!adam && !compact) {
     if ((gs_grad || param_grads) && !grads->xyz) return FSGS_ERR_INVALID;
@@ -818,6 +874,10 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
+    else if (mode == MODE_CAM_GRAD && !out.means2D && !td.accum && !td.total && row_lo == 0 && row_hi == P && out.w2c)
+      // the tracking step: dL/dw2c and nothing else
+      hipLaunchKernelGGL(render_pre_bwd_pose_kernel, dim3(std::min((P + RB - 1) / RB, 512)), dim3(RB), 0, stream, P, cam,
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, out.w2c);
     else
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,

@@ -256,7 +256,7 @@ class FastStepper:
         g = _lib.FsgsRenderGrads()
         (g.xyz, g.features_dc, g.features_rest, g.opacity, g.scaling, g.rotation) = [
             None if t is None else t.data_ptr() for t in tensors]
-        g.means2D = means2D.data_ptr()
+        g.means2D = None if means2D is None else means2D.data_ptr()
         g.w2c = None if w2c is None else w2c.data_ptr()
         return g
 
@@ -470,8 +470,10 @@ class FastStepper:
                 b = self._buffers(pc.num_points, H, W, int(P_CORR * (H // BOX) * (W // BOX)), dev)
                 stream = _lib.current_stream()
                 wd = w2c.detach().contiguous()
-                # flow loss forward + backward in ONE pass, on a second stream: it only needs the pose, so it runs
-                # beside the render's preprocess and binning kernels (dflow = w_flow * dloss/dw2c)
+                # flow loss forward + backward in ONE pass, on a second stream (dflow = w_flow * dloss/dw2c).  It only needs the
+                # pose, but it is ENQUEUED behind the render forward call: that call returns when the pair count arrives,
+                # i.e. as the forward blend starts, and the bandwidth-bound flow kernels then share the GPU with the
+                # issue-bound blend instead of with the latency-bound binning kernels (which they slowed by ~10 us)
                 side = self._side_stream(dev)
                 pose_ready = torch.cuda.Event()
                 pose_ready.record()
@@ -480,6 +482,7 @@ class FastStepper:
                 need = int(lib.fsgs_flow_scratch_bytes(M))
                 if b.flow_scratch is None or b.flow_scratch.numel() < need:
                     b.flow_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
+                args, state, sbytes, cap, nr = self._render_forward(wd, b, tracking=True)
                 with torch.cuda.stream(side):
                     _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
                                                              targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
@@ -491,7 +494,6 @@ class FastStepper:
                     flow_done = torch.cuda.Event()
                     flow_done.record()
                     wd.record_stream(side)
-                args, state, sbytes, cap, nr = self._render_forward(wd, b, tracking=True)
                 # mask = [rendered depth > 0] * rigid mask (train.py:176-178): the presence test is evaluated inside the
                 # loss kernels from the depth plane; the rigid mask (None = every pixel rigid) is handed over as floats,
                 # converted once per mask object -- a frame's 50 iterations share it
@@ -509,7 +511,8 @@ class FastStepper:
                     _lib.ptr(b.maps), _lib.ptr(b.sums), _lib.ptr(b.rgb_out), None, _lib.ptr(b.d_image), stream),
                     "fsgs_photometric_loss_forward_backward")
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
-                grads = self._grad_struct([None] * 6, b.means2D_grad, d_total)
+                # (no dL/dmeans2D: with gs_grad = False the reference's viewspace_points carries no gradient either)
+                grads = self._grad_struct([None] * 6, None, d_total)
                 torch.cuda.current_stream().wait_event(flow_done)
                 self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False,
                                       zeroed=True)

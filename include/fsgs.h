@@ -174,7 +174,8 @@ typedef struct FsgsRenderArgs {
 } FsgsRenderArgs;
 
 /* Gradient outputs of fsgs_render_backward, same layouts as FsgsRenderArgs; overwritten.
- * means2D [P,3] = the RGB pass's NDC-scaled screen gradient (`viewspace_points.grad`).
+ * means2D [P,3] = the RGB pass's NDC-scaled screen gradient (`viewspace_points.grad`); may be NULL in the pose-only call
+ * (gs_grad = param_grads = 0, cam_grad = 1: the tracking step), whose per-Gaussian pass then reduces straight to dL/dw2c.
  * w2c [4,4]: rows 0..2 = dL/dw2c, row 3 = 0. */
 typedef struct FsgsRenderGrads {
   float *xyz, *features_dc, *features_rest, *opacity, *scaling, *rotation, *means2D, *w2c;
