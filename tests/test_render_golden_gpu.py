@@ -216,3 +216,40 @@ def test_forward_reusing_the_colours_of_an_earlier_forward_is_bit_identical():
     assert torch.equal(rec(state), rec(fb.state)) and torch.equal(flg(state), flg(fb.state))
     assert not torch.equal(rec(fa.state), rec(fb.state))  # (the two poses do project differently)
     assert call(fa.sb - 64) == _lib.FSGS_ERR_STATE
+
+
+def test_pose_only_backward_without_a_means2D_holder_gives_the_same_pose_gradient():
+    """fsgs_render_backward(gs_grad=0, cam_grad=1, param_grads=0): with grads.means2D = NULL (the tracking step) the
+    per-Gaussian pass is the dedicated reduction kernel, with a holder it is the general one -- the twelve sums of
+    dL/dw2c must agree (different summation trees: 1e-5 of the matrix's inf-norm), row 3 stays zero, and the call
+    without a holder is still refused when any per-Gaussian gradient is asked for."""
+    rng = np.random.default_rng(11)
+    W, H, P = 320, 256, 6000
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=5)
+    P = sc["_xyz"].shape[0]
+    w2c = synth.pose_matrix((1.0, 0.012, -0.02, 0.01), (0.015, -0.01, 0.02)).astype(np.float32)
+    f = Fused(cam, sc["_xyz"], sc["_features_dc"], sc["_features_rest"], sc["_opacity"], sc["_scaling"], sc["_rotation"],
+              w2c, np.zeros(3, np.float32), 2)
+    di = T(rng.normal(0, 1e-3, (3, H, W)).astype(np.float32))
+    common = (C.byref(f.cfg), P, C.byref(f.args), _lib.ptr(f.radii), _lib.ptr(f.state), f.sb, f.cap, f.nr, _lib.ptr(di), None)
+
+    def run(with_holder, gs_grad=0, param_grads=0):
+        gs = _lib.FsgsRenderGrads()
+        m2 = torch.zeros((P, 3), device=DEV)
+        dw = torch.full((4, 4), 7.0, device=DEV)  # must be overwritten, not accumulated into
+        gs.means2D = m2.data_ptr() if with_holder else None
+        gs.w2c = dw.data_ptr()
+        rc = f.lib.fsgs_render_backward(*common, gs_grad, 1, param_grads, C.byref(gs), _lib.ptr(f.scratch), f.scratch.numel(),
+                                        _lib.current_stream())
+        torch.cuda.synchronize()
+        return rc, dw.cpu().numpy().astype(np.float64), m2
+
+    rc_a, a, m2 = run(True)
+    rc_b, b, _ = run(False)
+    assert rc_a == _lib.FSGS_OK and rc_b == _lib.FSGS_OK
+    assert np.abs(a[:3]).max() > 0
+    assert float(m2.abs().max()) == 0  # gs_grad = False: no screen-space gradient either way (as in the reference)
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), (a, b)
+    assert np.all(a[3] == 0) and np.all(b[3] == 0)
+    assert run(False, gs_grad=1)[0] == _lib.FSGS_ERR_INVALID
