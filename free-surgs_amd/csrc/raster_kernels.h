@@ -1181,7 +1181,7 @@ int scratch_layout(int P, int W, int H, int64_t cap, ScratchLayout &L) {
   size_t ntiles = (size_t)((W + FSGS_TILE - 1) / FSGS_TILE) * ((H + FSGS_TILE - 1) / FSGS_TILE);
   L.tiles = c.take(4 * Pn);
   L.rect = c.take(8 * Pn);
-  // cursors [tiles * 8] directly followed by {R, overflow report}: one memset clears both
+  // cursors [tiles * 8] directly followed by {R, overflow report}: cleared together (clear_binning_cursors)
   L.tile_count = c.take(4 * (size_t)ntiles * BIN_SUBS + 16);
   L.total = L.tile_count + 4 * (size_t)ntiles * BIN_SUBS;
   L.keys = c.take(8 * Rn);
@@ -1213,7 +1213,7 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   return FSGS_OK;
 }
 // Everything between the preprocess kernel and the blend: scatter, per-tile sort, dispatch order -- three
-// launches (+ one memset), all enqueued without knowing R.  The caller enqueues the forward blend right behind
+// launches (the cursors were cleared by the preprocess kernel in front), all enqueued without knowing R.  The caller enqueues the forward blend right behind
 // them and only then calls finish_binning(), which polls the mailbox: the GPU never waits for the host.  If a
 // list segment overflowed, the blend ran on truncated (in-bounds) lists and its output is garbage; the call then
 // reports FSGS_ERR_CAPACITY with *num_rendered = the max_pairs that would have sufficed.

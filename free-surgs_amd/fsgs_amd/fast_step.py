@@ -1,6 +1,6 @@
 """Autograd-free mapping / tracking iterations: the same arithmetic as trainer.mapping_step /
 tracking_step (train.py:166-200,236-272), but every stage is ONE C-ABI call into libfsgs_hip.so and the
-chain rule between stages is written out by hand, so a step costs ~21 kernel launches on two streams and no
+chain rule between stages is written out by hand, so a step costs ~15 kernel launches on two streams and no
 autograd graph (the torch-autograd path spends ~0.5 ms/step of pure host time in ~100 tiny kernels).
 
     mapping :  render fwd -> [rgb loss fwd, bwd (x5)  ||  patch draws, pearson(global + patches) fwd, bwd (x0.05, x0.15/n)]
