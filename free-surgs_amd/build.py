@@ -19,6 +19,10 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
     "-ffp-contract=on", "-Wno-unused-result", "-DNDEBUG",
 ]
+# FSGS_DIAG=1: the diagnostics hooks of csrc/raster_kernels.h (diag_env) -- experiments only, objects kept apart
+DIAG = os.environ.get("FSGS_DIAG") == "1"
+if DIAG:
+    FLAGS.append("-DFSGS_DIAG_HOOKS")
 
 
 def sources():
@@ -40,7 +44,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", ".o"))
+    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", ".diag.o" if DIAG else ".o"))
     if _stale(obj, [src] + headers()):
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -59,11 +63,15 @@ def build(force=False, verbose=False):
                 os.remove(os.path.join(OUT_DIR, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, sources()))
-    if _stale(LIB, objs):
+    stamp, flavour = LIB + ".flavour", "diag" if DIAG else "product"
+    linked_as = open(stamp).read().strip() if os.path.exists(stamp) else "product"
+    if _stale(LIB, objs) or linked_as != flavour:  # (the two flavours keep separate objects but share the library name)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        with open(stamp, "w") as f:
+            f.write(flavour + "\n")
     if verbose:
         print("built", LIB)
     return LIB

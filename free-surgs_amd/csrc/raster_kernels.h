@@ -20,6 +20,18 @@ using namespace fsgs;
 // ------------------------------------------------------------------------------------------------
 // device-side parameter block (passed by value)
 // ------------------------------------------------------------------------------------------------
+// Diagnostics hooks of the blend launches (occupancy throttle by dynamic LDS, per-wave start / end stamps into a buffer
+// whose ADDRESS comes from the environment): compiled in only by `FSGS_DIAG=1 python free-surgs_amd/build.py`, which
+// scripts/dev/diag_tile_times.py and the occupancy experiments ask for.  The product build never reads these variables.
+inline const char *diag_env(const char *name) {
+#ifdef FSGS_DIAG_HOOKS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 struct CamParams {
   int W, H, gx, gy, flags;
   float tanfovx, tanfovy, fx, fy, scale_modifier;
@@ -1280,9 +1292,9 @@ template <int C, bool WITH_DEPTH = true>
 int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
                      const float4 *rec, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
-  static int dbg_lds = getenv("FSGS_DBG_LDS_FWD") ? atoi(getenv("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
+  static int dbg_lds = diag_env("FSGS_DBG_LDS_FWD") ? atoi(diag_env("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
-      getenv("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(getenv("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
+      diag_env("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
   hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
                      final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
   return 0;
@@ -1292,9 +1304,9 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
                      float *clear16 = nullptr) {
-  static int dbg_lds = getenv("FSGS_DBG_LDS") ? atoi(getenv("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
+  static int dbg_lds = diag_env("FSGS_DBG_LDS") ? atoi(diag_env("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
-      getenv("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(getenv("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
+      diag_env("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
   hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
                      final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times);
   return 0;

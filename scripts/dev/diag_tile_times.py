@@ -1,7 +1,8 @@
 """Load balance of blend_bwd: every wave (= tile) stamps its start / end (100 MHz wall clock) into a buffer handed over
 through FSGS_DBG_TILE_TIMES.  Prints the makespan, the mean number of resident waves, the occupancy over time and how well
 the LPT key (list length) predicts a tile's duration compared with the depth actually walked (max n_contrib).
-    gpurun -- 'python scripts/dev/diag_tile_times.py'"""
+    gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && python scripts/dev/diag_tile_times.py [--fwd]'
+(the stamps are a diagnostics hook: only a library built with FSGS_DIAG=1 looks at the environment variable)"""
 import os
 import sys
 
