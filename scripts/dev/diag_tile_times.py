@@ -40,6 +40,8 @@ def main():
         d = buf.cpu().numpy().reshape(nwaves, 4)
         t0, t1 = d[:, 0].astype(np.float64) * 0.01, d[:, 1].astype(np.float64) * 0.01  # us
         ok = d[:, 1] > 0
+        if not ok.any():
+            sys.exit("no stamps: the library was built without FSGS_DIAG=1 (FSGS_DIAG=1 python free-surgs_amd/build.py)")
         lst = (d[:, 3] >> 32).astype(np.float64)
         walked = (d[:, 3] & 0xFFFFFFFF).astype(np.float64)
         start, end = t0[ok].min(), t1[ok].max()
