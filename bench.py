@@ -459,6 +459,22 @@ def main():
         tracking = {"iters_per_sec": nt / (time.perf_counter() - t1), "ms_per_iter": (time.perf_counter() - t1) / nt * 1e3,
                     "what": "render(gs_grad=False, cam_grad=True) + masked rgb loss + flow loss + pose Adam"}
 
+    # ---- extra: the TWO-VIEW mapping iteration of progressive_run (train.py:214-259: a random keyframe + the current
+    # frame, summed loss, one Adam step) on the same scene, N = 1 ----
+    two_view = None
+    if use_fast and world == 1 and not args.no_extras and not args.densify_every:
+        for it in range(6):
+            stepper.mapping_step([it % n_frames, (it + 3) % n_frames], collect_stats=not args.no_stats)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n2 = 40
+        for it in range(n2):
+            stepper.mapping_step([it % n_frames, (it + 3) % n_frames], collect_stats=not args.no_stats)
+        torch.cuda.synchronize()
+        two_view = {"ms_per_iter": (time.perf_counter() - t2) / n2 * 1e3, "iters_per_sec": n2 / (time.perf_counter() - t2),
+                    "what": "2 views x (fused render fwd + losses + render bwd into the compact [P,14] gradient; the second view "
+                            "reuses the first view's per-Gaussian colours) + Adam from the summed gradient"}
+
     # ---- extra: the same mapping step on the DENSE scene (upstream pair count ~ SURVEY s8d's nominal) ----
     dense = None
     if use_fast and world == 1 and not args.no_extras and args.scene == "default" and args.config in ("C2", "C4") \
@@ -552,7 +568,7 @@ def main():
                 "parallelism": "dp%d" % world, "loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
             "raster_fwd_bwd_ms": None if raster is None else raster["raster_fwd_bwd_ms"], "raster": raster,
-            "tracking_step": tracking, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
+            "tracking_step": tracking, "two_view_mapping_step": two_view, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
             "comm_pipelined": pipelined,
         }
         print(json.dumps(out), flush=True)
