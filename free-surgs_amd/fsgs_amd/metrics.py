@@ -13,6 +13,36 @@ def psnr(gts, preds):
     return float((-10.0 * np.log10(mse)).mean())
 
 
+def ssim(gts, preds, win_size=7, K1=0.01, K2=0.03, data_range=1.0):
+    """The SSIM `rgb_evaluation` reports (utils/general_utils.py:36-48): skimage.metrics.structural_similarity with its
+    defaults for a channel-last colour image -- 7x7 UNIFORM window, sample covariance (factor N/(N-1), N = 49),
+    C1 = (K1 R)^2, C2 = (K2 R)^2, the window-radius border cropped before averaging, mean over pixels and channels --
+    averaged over the images.  scikit-image (0.2x, unpinned in the reference's requirements) is not in this image: the
+    definition is restated from its documentation and pinned by closed-form cases in tests/test_golden_host.py
+    (identical images -> 1, a constant offset d on a flat image -> (2 m (m+d) + C1) / (m^2 + (m+d)^2 + C1)).
+    NOT the Gaussian-window SSIM of the training loss (losses.ssim_torch).  inputs [N,3,H,W] in [0,1]."""
+    from scipy.ndimage import uniform_filter
+
+    g = np.asarray(gts, np.float64)
+    p = np.asarray(preds, np.float64)
+    npx = float(win_size * win_size)
+    cov_norm = npx / (npx - 1.0)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    pad = (win_size - 1) // 2
+    vals = []
+    for n in range(g.shape[0]):
+        per_channel = []
+        for c in range(g.shape[1]):
+            x, y = g[n, c], p[n, c]
+            ux, uy = uniform_filter(x, size=win_size), uniform_filter(y, size=win_size)
+            uxx, uyy, uxy = uniform_filter(x * x, size=win_size), uniform_filter(y * y, size=win_size), uniform_filter(x * y, size=win_size)
+            vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+            S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
+            per_channel.append(S[pad:S.shape[0] - pad, pad:S.shape[1] - pad].mean())
+        vals.append(np.mean(per_channel))
+    return float(np.mean(vals))
+
+
 def umeyama_sim3(model, data):
     """s, R, t minimising || model - (s R data + t) ||  (Umeyama 1991)."""
     model = np.asarray(model, np.float64)

@@ -439,7 +439,12 @@ class Runner:
                 pkg = (render if self.fused else render_two_pass)(self.poses, int(i), self.pc, False, False)
                 preds.append(pkg["render"].detach().cpu().numpy())
                 gts.append(self.frames.colors[int(i)].detach().cpu().numpy())
-        return metrics.psnr(np.stack(gts), np.stack(preds)) if preds else float("nan")
+        self.last_validation = ({"psnr": metrics.psnr(np.stack(gts), np.stack(preds)),
+                                 "ssim": metrics.ssim(np.clip(np.stack(gts), 0, 1), np.clip(np.stack(preds), 0, 1))}
+                                if preds else {"psnr": float("nan"), "ssim": float("nan")})
+        # (rgb_evaluation also prints LPIPS: it needs the pretrained AlexNet weights of the `lpips` package, which cannot
+        # be fetched here -- not reported)
+        return self.last_validation["psnr"]
 
     def eval_pose(self):
         from . import metrics

@@ -434,3 +434,29 @@ def test_eval_pose_aligns_every_run_on_its_own_and_global_run_starts_at_iteratio
     deg0 = pc.active_sh_degree
     run.global_run(3)
     assert len(seen) == 4 and pc.active_sh_degree == deg0 + 1  # iterations 0..3; 0 % 1000 == 0 raises the SH degree
+
+
+def test_validation_ssim_is_the_uniform_window_definition():
+    """metrics.ssim = the metric rgb_evaluation prints (skimage defaults: 7x7 uniform window, sample covariance, cropped
+    border), pinned by closed forms: identical images -> 1; a flat image against the same image plus a constant d ->
+    luminance term only; and against a direct per-window evaluation at one pixel of a random pair."""
+    from fsgs_amd import metrics
+
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1, (2, 3, 24, 31))
+    assert abs(metrics.ssim(a, a) - 1.0) < 1e-12
+    m, d = 0.4, 0.25
+    flat = np.full((1, 3, 20, 20), m)
+    C1 = 0.01 ** 2
+    want = (2 * m * (m + d) + C1) / (m * m + (m + d) ** 2 + C1)  # variances and covariance are zero: the C2 factors cancel
+    assert abs(metrics.ssim(flat, flat + d) - want) < 1e-12
+    b = np.clip(a + rng.normal(0, 0.1, a.shape), 0, 1)
+    # one image, one channel, window centred at (10, 12): direct evaluation of the definition
+    x, y = a[0, 1, 7:14, 9:16], b[0, 1, 7:14, 9:16]
+    ux, uy = x.mean(), y.mean()
+    vx, vy, vxy = x.var(ddof=1), y.var(ddof=1), ((x - ux) * (y - uy)).sum() / 48.0
+    s_direct = ((2 * ux * uy + C1) * (2 * vxy + 0.03 ** 2)) / ((ux * ux + uy * uy + C1) * (vx + vy + 0.03 ** 2))
+    single = np.zeros((1, 1, 7, 7))
+    got = metrics.ssim(a[:1, 1:2, 7:14, 9:16], b[:1, 1:2, 7:14, 9:16])  # a 7x7 image: exactly one uncropped window
+    assert abs(got - s_direct) < 1e-9, (got, s_direct)
+    assert 0.0 < metrics.ssim(a, b) < 1.0

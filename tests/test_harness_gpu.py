@@ -39,6 +39,7 @@ def test_progressive_then_global_run_on_a_synthetic_sequence():
     assert ate < 0.25 * step
     psnr0 = run.validation()
     assert psnr0 > 35.0, psnr0
+    assert run.last_validation["psnr"] == psnr0 and 0.9 < run.last_validation["ssim"] <= 1.0, run.last_validation
     P0 = pc.num_points
     run.iteration = 290  # next mapping iterations cross a densification boundary (iteration % 300 == 0)
     run.global_run(40)
