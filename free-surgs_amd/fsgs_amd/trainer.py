@@ -418,17 +418,29 @@ class Runner:
             return d[0].expand(self.h, self.w).contiguous()
         return d.contiguous()
 
-    def global_run(self, iterations, first_iter=0):
-        """train.py:378-393: `for iter in range(self.first_iter, iterations + 1)` -- first_iter is 0 unless a checkpoint
+    def global_run(self, iterations, first_iter=0, eval_every=5000, model_path=None, save_every=5000):
+        """train.py:378-443: `for iter in range(self.first_iter, iterations + 1)` -- first_iter is 0 unless a checkpoint
         was loaded, so iteration 0 runs too (iterations + 1 mapping steps) and, 0 being a multiple of 1000, raises the SH
-        degree at the very start of the global phase."""
+        degree at the very start of the global phase.  Every `eval_every` iterations (iter % 5000 == 0, so also at
+        iteration 0) the test frames are evaluated as train.py:401-432 does (PSNR / SSIM into self.eval_log; the
+        reference also writes comparison images and LPIPS: not reproduced); with a `model_path`, chkpnt{iter}.pth and
+        poses{iter}.pth are written at iter % save_every == save_every - 1 in the reference's tuple layouts
+        (train.py:437-443, checkpoint.py)."""
         self.pc.initialize_optimizer()
+        self.eval_log = getattr(self, "eval_log", [])
         for it in range(int(first_iter), iterations + 1):
             ts = int(self.rng.choice(list(self.frames.i_train)))
             if it % 1000 == 0:
                 self.pc.oneupSHdegree()
             self.pc.update_learning_rate(it)
             self.mapping(ts, 1, progressive=False)
+            if eval_every and it % eval_every == 0 and len(self.frames.i_test):
+                self.validation()
+                self.eval_log.append((it, dict(self.last_validation)))
+            if model_path and save_every and it % save_every == save_every - 1:
+                from . import checkpoint
+
+                checkpoint.save(model_path, it, self.pc, self.poses, np.asarray(self.frames.K, np.float32))
 
     def validation(self):
         from . import metrics

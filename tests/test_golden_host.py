@@ -432,7 +432,7 @@ def test_eval_pose_aligns_every_run_on_its_own_and_global_run_starts_at_iteratio
     pc.training_setup(fused=False)
     pc.initialize_optimizer = lambda fused=True: None
     deg0 = pc.active_sh_degree
-    run.global_run(3)
+    run.global_run(3, eval_every=0)  # (the periodic test-frame evaluation renders: GPU only, tests/test_harness_gpu.py)
     assert len(seen) == 4 and pc.active_sh_degree == deg0 + 1  # iterations 0..3; 0 % 1000 == 0 raises the SH degree
 
 

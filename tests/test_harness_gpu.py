@@ -2,6 +2,8 @@
 SCARED-like sequence rendered by the HIP path: tracking must recover the camera motion, mapping must
 raise PSNR, densification must keep the cloud consistent.  (The reference's own PSNR/ATE need the real
 dataset and its CUDA rasteriser; neither exists here -- SURVEY.md s6.)"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -42,7 +44,15 @@ def test_progressive_then_global_run_on_a_synthetic_sequence():
     assert run.last_validation["psnr"] == psnr0 and 0.9 < run.last_validation["ssim"] <= 1.0, run.last_validation
     P0 = pc.num_points
     run.iteration = 290  # next mapping iterations cross a densification boundary (iteration % 300 == 0)
-    run.global_run(40)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as ckpt_dir:
+        run.global_run(40, eval_every=20, model_path=ckpt_dir, save_every=16)
+        # train.py:401-443: test-frame evaluation at iter % eval_every == 0, checkpoints at iter % save_every == save_every - 1
+        assert [it for it, _ in run.eval_log] == [0, 20, 40] and all(m["psnr"] > 25 and m["ssim"] > 0.8 for _, m in run.eval_log)
+        assert sorted(os.listdir(ckpt_dir)) == ["chkpnt15.pth", "chkpnt31.pth", "poses15.pth", "poses31.pth"]
+        (model_args, it_saved) = torch.load(os.path.join(ckpt_dir, "chkpnt31.pth"), weights_only=False)
+        assert it_saved == 31 and len(model_args) == 12  # GaussianModel.capture()'s tuple (scene/gaussian_model.py:86-98)
     assert pc.num_points != P0 and pc.num_points > 0
     for k, v in pc.params.items():
         assert torch.isfinite(v).all(), k
