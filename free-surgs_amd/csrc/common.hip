@@ -140,6 +140,24 @@ __global__ void selftest_transpose_reduce_n_kernel(const float *in, float *out) 
   if (N == 32) out[lane] = fsgs::wave_transpose_reduce32(reinterpret_cast<const float(&)[32]>(v), lane);
   if (N == 16) out[lane] = fsgs::wave_transpose_reduce16(reinterpret_cast<const float(&)[16]>(v), lane);
 }
+// the reductions blend_bwd actually uses: slots 12..15 of either Gaussian (width 3212) / 5..7 (width 1605) are ZERO on
+// entry and are not reduced; out[64 + lane] = the slot this lane ends up owning
+__global__ void selftest_transpose_reduce_sparse_kernel(const float *in, float *out, int width) {
+  const int lane = threadIdx.x & 63;
+  if (width == 3212) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = (i & 15) < 12 ? in[lane * 64 + i] : 0.f;
+    out[lane] = fsgs::wave_transpose_reduce32_12of16_cheap_first(v, lane);
+    out[64 + lane] = (float)fsgs::transpose12_slot(lane);
+  } else {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = (i & 7) < 5 ? in[lane * 64 + i] : 0.f;
+    out[lane] = fsgs::wave_transpose_reduce16_5of8_cheap_first(v, lane);
+    out[64 + lane] = (float)fsgs::transpose5_slot(lane);
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -150,6 +168,8 @@ int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int wid
     hipLaunchKernelGGL(selftest_transpose_reduce_n_kernel<32>, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);
   else if (width == 16)
     hipLaunchKernelGGL(selftest_transpose_reduce_n_kernel<16>, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64);
+  else if (width == 3212 || width == 1605)  // the sparse variants of the backward blend: out64 must hold 128 floats
+    hipLaunchKernelGGL(selftest_transpose_reduce_sparse_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in64x64, out64, width);
   else
     return FSGS_ERR_INVALID;
   FSGS_HIP(hipGetLastError());

@@ -137,6 +137,70 @@ __device__ __forceinline__ float wave_transpose_reduce32_12of16(const float (&v)
   return dpp_add<0xB1>(u);
 }
 
+// ---- the 12-of-16 reduction with the CHEAP exchanges first ---------------------------------------------------------
+// A transposing step costs (values it leaves) x (price of that lane distance): a bank-masked DPP fold (lane bits 3, 2)
+// two plain instructions per value, a select-based fold (bits 1, 0) three, a permlane swap + add (bits 4, 5) ~3.5 (the
+// swap issues at ~2.5x).  The order above spends the swaps where MOST values are left (12 + 8 of them); this one folds
+// lane bits 3, 2, 1 first (16, 8, 4 values left), then one permlane16 swap pair (2 left), one permlane32 swap (1) and a
+// plain quad-perm add: ~64 issue slots for the two Gaussians instead of ~86.  Pairs whose second value is one of the
+// unused slots 12..15 take ONE instruction in the first step (the banks that would hold the unused sum keep garbage,
+// which only ever flows into lanes that own unused slots).
+// out: lane l holds the total of v[transpose12_slot(l)]; lanes l and l ^ 1 the same value.
+__host__ __device__ __forceinline__ int transpose12_slot(int lane) {
+  return 16 * ((lane >> 5) & 1) + 8 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 4) & 1);
+}
+// One Gaussian's first two steps as two assembly blocks: every DPP source is an INPUT of its block, so one s_nop 1 per
+// block covers the "VALU write -> DPP read" wait states of all its instructions (a fold at a time needs one each).
+//   fold3: slots k and k + 8 -> a[k] (k = 0..3 both halves, k = 4..7 the lower banks only: slot k + 8 is unused)
+//   fold2: a[k] and a[k + 4] -> b[k]
+__device__ __forceinline__ void fold3_block(const float *x, float (&a)[8]) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %0, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+               "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %1, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+               "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %2, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+               "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %3, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+               "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3"
+               : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                 "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]));
+}
+__device__ __forceinline__ void fold2_block(const float (&a)[8], float (&b)[4]) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+               "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+               "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+               "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa"
+               : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+}
+__device__ __forceinline__ float wave_transpose_reduce32_12of16_cheap_first(const float (&v)[32], int lane) {
+  float a0[8], a1[8], b0[4], b1_[4], c[4], d[2];
+  fold3_block(&v[0], a0);   // lane bit 3 <-> slot bit 3, Gaussian 0
+  fold3_block(&v[16], a1);  //                           Gaussian 1
+  fold2_block(a0, b0);      // lane bit 2 <-> slot bit 2
+  fold2_block(a1, b1_);
+  const bool b1 = lane & 2;
+  c[0] = fold_dpp<0x4E>(b0[0], b0[2], b1);  // lane bit 1 <-> slot bit 1
+  c[1] = fold_dpp<0x4E>(b0[1], b0[3], b1);
+  c[2] = fold_dpp<0x4E>(b1_[0], b1_[2], b1);
+  c[3] = fold_dpp<0x4E>(b1_[1], b1_[3], b1);
+  d[0] = swap16_add(c[0], c[1]);  // lane bit 4 <-> slot bit 0
+  d[1] = swap16_add(c[2], c[3]);
+  const float e = swap32_add(d[0], d[1]);  // lane bit 5 <-> Gaussian
+  return dpp_add<0xB1>(e);                 // lanes l, l ^ 1: plain sum
+}
+
 // 16-value variant: lane l ends with the total of v[l >> 2] (four lanes hold the same value); ~40 VALU.
 __device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], int lane) {
   float w[8], x[4], y[2];
@@ -167,6 +231,42 @@ __device__ __forceinline__ float wave_transpose_reduce16_5of8(const float (&v)[1
   float z = fold_bit2(y[0], y[1]);
   z = dpp_add<0x4E>(z);
   return dpp_add<0xB1>(z);
+}
+
+// The pose-only backward's 5-of-8 reduction (two Gaussians x 8 slots, 5 used) in the same cheap-first order: lane bits 3,
+// 2, 1 take slot bits 2, 1, 0 (five + four + three DPP / select instructions per Gaussian instead of five + four swap
+// pairs for both), lane bit 4 the Gaussian (one permlane16 swap pair); lane bits 5 and 0 are plain sums.
+// out: lane l holds the total of v[transpose5_slot(l)]; lanes differing in bits 5 or 0 only hold the same value.
+__host__ __device__ __forceinline__ int transpose5_slot(int lane) {
+  return 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+}
+__device__ __forceinline__ void fold32_block5(const float *x, float (&b)[2]) {  // x[0..4] -> b[slot bit 0]
+  float a0, a1, a2, a3;
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+               "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+               "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3"
+               : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]));
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+               "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+               "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa"
+               : "=&v"(b[0]), "=&v"(b[1])
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+__device__ __forceinline__ float wave_transpose_reduce16_5of8_cheap_first(const float (&v)[16], int lane) {
+  float b0[2], b1[2];
+  fold32_block5(&v[0], b0);
+  fold32_block5(&v[8], b1);
+  const bool bit1 = lane & 2;
+  const float c0 = fold_dpp<0x4E>(b0[0], b0[1], bit1), c1 = fold_dpp<0x4E>(b1[0], b1[1], bit1);
+  const float d = swap16_add(c0, c1);  // lane bit 4 <-> Gaussian
+  const float e = swap32_add(d, d);    // lane bit 5: plain sum (both halves end with the total)
+  return dpp_add<0xB1>(e);             // lane bit 0: plain sum
 }
 
 template <int CTRL, int ROW_MASK = 0xF>

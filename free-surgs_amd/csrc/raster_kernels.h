@@ -885,8 +885,13 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
   //   0..4 moments of w (mean2D x,y | conic A,B,C) | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
   //   POSE_ONLY: the five moments only
   // after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
-  const int my_u = (lane / REP) / SL, my_c = (lane / REP) % SL;
-  const bool c_used = !(lane & (REP - 1)) && (POSE_ONLY ? my_c < 5
+  // (the 12-of-16 reduction folds the cheap lane bits first and leaves its totals in another lane order: transpose12_slot)
+  constexpr bool CHEAP_FIRST = !POSE_ONLY && CG <= 4;
+  const int my_slot = POSE_ONLY ? transpose5_slot(lane) : CHEAP_FIRST ? transpose12_slot(lane) : lane / REP;
+  const int my_u = my_slot / SL, my_c = my_slot % SL;
+  // one lane of those that hold the same total issues the atomic
+  const bool owner = POSE_ONLY ? !(lane & 0x21) : !(lane & (REP - 1));
+  const bool c_used = owner && (POSE_ONLY ? my_c < 5
                                                 : (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + CG)));
   while (hi > 0) {
     const int lo = max(0, hi - 64);
@@ -973,8 +978,8 @@ __global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
       if (!any_group) continue;  // wave-uniform: none of the GP Gaussians touched any pixel of the tile
       // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
       float tot;
-      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16_5of8(v, lane);  // slots 5..7 of a Gaussian stay zero
-      else if constexpr (CG <= 4) tot = wave_transpose_reduce32_12of16(v, lane);  // slots 12..15 of a Gaussian stay zero
+      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16_5of8_cheap_first(v, lane);  // slots 5..7 stay zero
+      else if constexpr (CG <= 4) tot = wave_transpose_reduce32_12of16_cheap_first(v, lane);  // slots 12..15 stay zero
       else tot = wave_transpose_reduce32(v, lane);
       const int j_mine = jj - my_u;
       uint32_t gsel = readlane(gid, jj);

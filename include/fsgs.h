@@ -96,7 +96,9 @@ const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP
  * in[lane*64 + i] (64 lanes x 64 values) -> out[l] = sum over lanes of in[lane*64 + l]. */
 int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stream_t stream);
 /* The narrower variants: width = 64, 32 or 16 values per lane (the first `width` columns of in); lane l
- * receives the total of column l / (64 / width). */
+ * receives the total of column l / (64 / width).  width = 3212 / 1605: the sparse variants the backward blend uses
+ * (two Gaussians x 16 slots of which 12 are reduced / x 8 of which 5; the other columns are taken as zero): out64 must
+ * then hold 128 floats, out[l] = the lane's total and out[64 + l] = the column (slot) that lane ends up owning. */
 int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int width, fsgs_stream_t stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launching stream.

@@ -313,6 +313,20 @@ def test_wave_transposing_reduction_selftest():
                    "selftest")
         want = m.astype(np.float64).sum(0)[np.arange(64) // (64 // width)]
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # the sparse variants blend_bwd runs (two Gaussians x 16 slots / x 8 slots, of which 12 / 5 are reduced): every used
+    # slot must end up, with its column total, in at least one lane; lanes owning an unused slot are ignored
+    out2 = torch.zeros(128, device=DEV)
+    for width, slots, used in ((3212, 32, 12), (1605, 16, 5)):
+        _lib.check(lib.fsgs_selftest_transpose_reduce_n(_lib.ptr(a), _lib.ptr(out2), width, _lib.current_stream()), "selftest")
+        o = out2.cpu().numpy()
+        tot, slot = o[:64], o[64:].astype(int)
+        per = slots // 2
+        live = (slot % per) < used
+        assert set(slot[live]) == {s_ for s_ in range(slots) if s_ % per < used}, sorted(set(slot[live]))
+        np.testing.assert_allclose(tot[live], m.astype(np.float64).sum(0)[slot[live]], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(slot[0::2], slot[1::2])  # lanes l and l ^ 1 own the same slot (the kernel uses the even one)
+        if width == 1605:  # ... and so do lanes l and l ^ 32
+            assert np.array_equal(slot[:32], slot[32:]) and np.allclose(tot[:32][live[:32]], tot[32:][live[32:]])
 
 
 def test_heavy_tile_takes_the_global_memory_sort_path(oracle32):
