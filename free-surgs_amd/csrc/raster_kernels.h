@@ -822,7 +822,7 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // ROW: floats per accumulator row when moments and colour sums share one row per Gaussian (kFusedRow, the fused
 // render); 0 = the operator boundary's layout (moments [P,8] in scratch, colour sums straight into dcolors [P,C]).
 template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
-__global__ __launch_bounds__(64, 4) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
