@@ -989,9 +989,16 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_b
         gsel = my_u == u ? gu : gsel;
       }
       if (j_mine >= 0 && c_used && tot != 0.f) {
-        float *dst = (POSE_ONLY || my_c < 8) ? grad_acc + (size_t)gsel * acc_stride + my_c
-                                             : dcolors + (size_t)gsel * col_stride + (my_c - 8);
-        atomicAdd(dst, tot);
+        if constexpr (ROW != 0) {
+          // one row per Gaussian holds moments AND colour sums (dcolors = grad_acc + 8, stride ROW: launch_blend_bwd checks
+          // it), so slot c of either kind is float c of the row: uniform base + a 32-bit offset, no 64-bit address pair
+          // to compute and select per lane
+          atomicAdd(grad_acc + (gsel * (uint32_t)ROW + (uint32_t)my_c), tot);
+        } else {
+          float *dst = (POSE_ONLY || my_c < 8) ? grad_acc + (size_t)gsel * acc_stride + my_c
+                                               : dcolors + (size_t)gsel * col_stride + (my_c - 8);
+          atomicAdd(dst, tot);
+        }
       }
     }
     hi = lo;
@@ -1309,6 +1316,7 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
                      float *clear16 = nullptr) {
+  if (ROW != 0 && dcolors != grad_acc + 8) return FSGS_ERR_INVALID;  // the one-row layout the kernel's addressing assumes
   static int dbg_lds = diag_env("FSGS_DBG_LDS") ? atoi(diag_env("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
       diag_env("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
