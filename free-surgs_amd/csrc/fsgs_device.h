@@ -119,7 +119,8 @@ __device__ __forceinline__ float wave_transpose_reduce32(const float (&v)[32], i
 }
 
 // The same when v[12..15] and v[28..31] are known to be ZERO (two Gaussians x 16 slots of which 12 are used): the
-// first halving step pairs v[i] with v[i + 16], so four of its sixteen swap + add pairs only move zeros.
+// first halving step pairs v[i] with v[i + 16], so four of its sixteen swap + add pairs only move zeros.  (The swap-first
+// order blend_bwd used until the cheap-first one below replaced it; scripts/ubench/mfma_reduce.hip still times it.)
 __device__ __forceinline__ float wave_transpose_reduce32_12of16(const float (&v)[32], int lane) {
   float w[16], x[8], y[4], z[2];
 #pragma unroll
@@ -213,23 +214,6 @@ __device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], i
   for (int i = 0; i < 2; i++) y[i] = fold_bit3(x[i], x[i + 2]);  // lane bit 3 <-> index bit 1
   float z = fold_bit2(y[0], y[1]);                                // lane bit 2 <-> index bit 0
   z = dpp_add<0x4E>(z);                                                     // lanes l, l^2, l^1, l^3: plain sum
-  return dpp_add<0xB1>(z);
-}
-
-// ... and when v[5..7] and v[13..15] are known to be zero (two Gaussians x 8 slots of which the pose-only backward uses
-// 5): three of the eight swap + add pairs of the first step only move zeros.
-__device__ __forceinline__ float wave_transpose_reduce16_5of8(const float (&v)[16], int lane) {
-  float w[8], x[4], y[2];
-#pragma unroll
-  for (int i = 0; i < 5; i++) w[i] = swap32_add(v[i], v[i + 8]);
-#pragma unroll
-  for (int i = 5; i < 8; i++) w[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) x[i] = swap16_add(w[i], w[i + 4]);
-#pragma unroll
-  for (int i = 0; i < 2; i++) y[i] = fold_bit3(x[i], x[i + 2]);
-  float z = fold_bit2(y[0], y[1]);
-  z = dpp_add<0x4E>(z);
   return dpp_add<0xB1>(z);
 }
 
