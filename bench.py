@@ -96,31 +96,12 @@ def upstream_pairs(stepper, W, H):
     return int(area[vis].sum().item())
 
 
-def usable_cores():
-    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose
-    256 logical CPUs under a 16-core quota; 256 OpenMP threads there run 5x slower than 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(np.ceil(float(quota) / float(period)))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, -(-q // pr)))
-        except Exception:
-            pass
-    return n
-
-
 def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
     """The oracle (kind "port": the reference has no CPU path and its rasteriser source is absent) timed on
     the host cores: rasteriser fwd + bwd of the RGB pass and of the depth/silhouette pass = the
     rasteriser part of ONE step (losses and Adam are left out, which only flatters the CPU)."""
     from fsgs_amd import synth
-    from oracle.fsgs_oracle import Oracle
+    from oracle.fsgs_oracle import Oracle, usable_cores
 
     o = Oracle(np.float32)
     cores = min(usable_cores(), o.max_threads())

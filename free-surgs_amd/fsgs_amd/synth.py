@@ -43,8 +43,13 @@ def make_camera(W, H, w2c=None, K=None, near=0.01, far=100.0, bg=(1.0, 1.0, 1.0)
             [0.0, 0.0, 1.0, 0.0],
         ]
     )
-    view_t = w2c.T
-    full_proj = view_t @ opengl_proj.T
+    # the reference forms the product in fp32 (`w2c.bmm(opengl_proj)` on .float() tensors, :617-618): fp32 operands
+    # and a k-ordered fp32 accumulation reproduce its matrix bit for bit (tests/golden/camera.npz)
+    view_t = w2c.T.astype(np.float32)
+    proj_t = opengl_proj.T.astype(np.float32)
+    full_proj = np.zeros((4, 4), np.float32)
+    for k in range(4):
+        full_proj = full_proj + np.outer(view_t[:, k], proj_t[k, :])
     return {
         "image_height": int(H),
         "image_width": int(W),
@@ -52,8 +57,8 @@ def make_camera(W, H, w2c=None, K=None, near=0.01, far=100.0, bg=(1.0, 1.0, 1.0)
         "tanfovy": H / (2 * fy),
         "bg": np.asarray(bg, dtype=np.float32),
         "scale_modifier": 1.0,
-        "viewmatrix": view_t.astype(np.float32),
-        "projmatrix": full_proj.astype(np.float32),
+        "viewmatrix": view_t,
+        "projmatrix": full_proj,
         "sh_degree": 0,
         "campos": np.linalg.inv(w2c)[:3, 3].astype(np.float32),
         "prefiltered": False,

@@ -14,6 +14,25 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MAXC = 8
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose
+    256 logical CPUs under a 16-core quota; 256 OpenMP threads there run 5x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(float(quota) / float(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // pr)))
+        except Exception:
+            pass
+    return n
+
+
 def build(force=False):
     """Compile liboracle_f32.so / liboracle_f64.so with gcc (oracle/Makefile)."""
     libs = [os.path.join(_HERE, n) for n in ("liboracle_f32.so", "liboracle_f64.so")]
@@ -69,6 +88,7 @@ class Oracle:
             ("oracle_state_xy", rp),
             ("oracle_state_conic_op", rp),
             ("oracle_state_depth", rp),
+            ("oracle_state_cov3D", rp),
             ("oracle_state_final_T", rp),
             ("oracle_state_n_contrib", ip),
             ("oracle_state_tiles", ip),
@@ -353,6 +373,10 @@ class OracleState:
 
     def depth(self):
         return self._arr("oracle_state_depth", (self.P,), self.oracle.dtype)
+
+    def cov3D(self):
+        """[P,6] = (xx, xy, xz, yy, yz, zz) of Sigma; zero rows for Gaussians behind the near plane."""
+        return self._arr("oracle_state_cov3D", (self.P, 6), self.oracle.dtype)
 
     def tiles_touched(self):
         return self._arr("oracle_state_tiles", (self.P,), np.int32)

@@ -207,6 +207,10 @@ int64_t oracle_state_num_rendered(const OracleState *st) { return st->R; }
 const real *oracle_state_xy(const OracleState *st) { return st->xy; }
 const real *oracle_state_conic_op(const OracleState *st) { return st->conic_op; }
 const real *oracle_state_depth(const OracleState *st) { return st->depth; }
+/* [P,6] upper triangle (xx, xy, xz, yy, yz, zz) of Sigma = R S^2 R^T for every Gaussian in front of the near plane --
+ * the order strip_symmetric keeps (utils/general_utils.py:191-202); pinned against the reference's own
+ * build_covariance_from_scaling_rotation (scene/gaussian_model.py:32-36) by tests/golden/covariance.npz */
+const real *oracle_state_cov3D(const OracleState *st) { return st->cov3D; }
 const real *oracle_state_final_T(const OracleState *st) { return st->final_T; }
 const int *oracle_state_n_contrib(const OracleState *st) { return st->n_contrib; }
 const int *oracle_state_tiles(const OracleState *st) { return st->tiles; }

@@ -27,10 +27,10 @@ def scene(W, H, P, trained):
 
 def run(tag, W, H, P, trained, threads, reps):
     o = Oracle(np.float32)
-    if not threads:  # "all cores" = what the cgroup quota really grants (bench.usable_cores)
-        import bench
+    if not threads:  # "all cores" = what the cgroup quota really grants
+        from oracle.fsgs_oracle import usable_cores
 
-        threads = min(bench.usable_cores(), o.max_threads())
+        threads = min(usable_cores(), o.max_threads())
     o.set_threads(threads)
     sc = scene(W, H, P, trained)
     cam = synth.make_camera(W, H)

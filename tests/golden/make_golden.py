@@ -431,6 +431,66 @@ def main():
             pm.restore(pp)
             assert torch.equal(pm.pose_param_net.r, pt.r) and torch.equal(pm.pose_param_net.t, pt.t)
             assert np.allclose(pm.record_data["pred_w2c"][3], npy(pt.pred_w2c[3])) and not pm.record_data["pred_w2c"][4].any()
+        # ---------------- PoseModel.setup_camera (scene/pose_optimizer.py:600-633) ----------------
+        # the 12 keyword arguments it hands to GaussianRasterizationSettings (stubbed here: a MagicMock records them),
+        # for the record_data route (intrinsics as the loader rescales them, :413-414) and the visualize_data route
+        PM = pose_optimizer.PoseModel
+        out = {}
+        cases = [
+            ("c2_identity", 1280, 1024, np.eye(4), None),
+            ("c1_posed", 640, 512, None, None),
+            ("vis_posed", 1920, 1080, None, "vis"),
+        ]
+        seed_all(31)
+        for tag, W_, H_, w2c_, route in cases:
+            KL_ = np.array([[1035.3, 0.0, 596.5], [0.0, 1035.1, 520.4], [0.0, 0.0, 1.0]])
+            K_ = KL_.copy()
+            K_[0, :] = K_[0, :] * W_ / 1280
+            K_[1, :] = K_[1, :] * H_ / 1024
+            if w2c_ is None:
+                from scipy.spatial.transform import Rotation as Rot
+
+                w2c_ = np.eye(4)
+                w2c_[:3, :3] = Rot.from_rotvec(np.random.randn(3) * 0.05).as_matrix()
+                w2c_[:3, 3] = np.random.randn(3) * 0.05
+            w2c_ = w2c_.astype(np.float32)
+            pm_ = PM.__new__(PM)
+            pm_.record_data = {"intrinsic": K_, "image_width": W_, "image_height": H_}
+            pose_optimizer.Camera.reset_mock()
+            if route == "vis":
+                pm_.record_data = {}
+                pm_.setup_camera(w2c_, visualize_data={"K": K_, "W": W_, "H": H_}, near=0.05, far=20)
+            else:
+                pm_.setup_camera(w2c_)
+            kw = pose_optimizer.Camera.call_args.kwargs
+            assert sorted(kw) == sorted(["image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                                         "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug"])
+            out[tag + "_K"] = K_
+            out[tag + "_w2c"] = w2c_
+            out[tag + "_near_far"] = np.array([0.05, 20.0] if route == "vis" else [0.01, 100.0])
+            for k, v in kw.items():
+                out["%s_%s" % (tag, k)] = npy(v) if torch.is_tensor(v) else np.asarray(v)
+            out[tag + "_cam_center"] = npy(pm_.cam_center)
+        out["cases"] = np.array([c[0] for c in cases])
+        np.savez_compressed(os.path.join(OUT, "camera.npz"), **out)
+
+        # ---------------- Sigma = R S S^T R^T (scene/gaussian_model.py:32-36, utils/general_utils.py:191-236) --------
+        # GaussianModel.get_covariance's activation on raw (un-normalised) quaternions and activated scales: the six
+        # upper-triangular entries (xx, xy, xz, yy, yz, zz) strip_symmetric keeps
+        seed_all(32)
+        GM = gaussian_model.GaussianModel
+        gmc = GM.__new__(GM)
+        gmc.setup_functions()
+        n = 48
+        scaling = torch.exp(torch.randn(n, 3) * 0.7 - 3.0)
+        rotq = torch.randn(n, 4)
+        rotq[0] = torch.tensor([1.0, 0, 0, 0])
+        rotq[1] = torch.tensor([0.0, 0, 0, 2.0])      # 180 deg about z, un-normalised
+        cov6 = gmc.covariance_activation(scaling, 1.0, rotq)
+        cov6_m = gmc.covariance_activation(scaling, 1.7, rotq)
+        np.savez_compressed(os.path.join(OUT, "covariance.npz"), scaling=npy(scaling), rotation_raw=npy(rotq),
+                            rotation_normalised=npy(torch.nn.functional.normalize(rotq)), cov6=npy(cov6),
+                            cov6_modifier_1p7=npy(cov6_m))
     print("golden fixtures written to", OUT)
 
 

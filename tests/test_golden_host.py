@@ -460,3 +460,69 @@ def test_validation_ssim_is_the_uniform_window_definition():
     got = metrics.ssim(a[:1, 1:2, 7:14, 9:16], b[:1, 1:2, 7:14, 9:16])  # a 7x7 image: exactly one uncropped window
     assert abs(got - s_direct) < 1e-9, (got, s_direct)
     assert 0.0 < metrics.ssim(a, b) < 1.0
+
+
+@pytest.mark.parametrize("tag", ["c2_identity", "c1_posed", "vis_posed"])
+def test_setup_camera_settings_match_the_reference(tag):
+    """PoseModel.setup_camera (scene/pose_optimizer.py:600-633) -> the 12 GaussianRasterizationSettings fields, captured
+    from the imported reference (tests/golden/camera.npz), against the three places the build states them:
+    synth.make_camera, dataset.camera_from_frames and trainer.settings_from_cam.  tanfov, the transposed view matrix
+    and projmatrix = w2c^T . opengl_proj^T (an fp32 product in the reference) bit for bit; campos = inverse(w2c)[:3,3]
+    (an fp32 LAPACK / cuSOLVER inverse there, never read by the rasteriser when colours are precomputed) to an ulp."""
+    from fsgs_amd import dataset, synth
+    from fsgs_amd.trainer import settings_from_cam
+
+    g = _load("camera.npz")
+    f = lambda k: g["%s_%s" % (tag, k)]
+    W, H = int(f("image_width")), int(f("image_height"))
+    near, far = f("near_far")
+    cams = [synth.make_camera(W, H, w2c=f("w2c"), K=f("K"), near=near, far=far)]
+    if tag == "c2_identity":  # the route a loaded sequence takes (identity raster camera, default planes)
+        class Frames:
+            pass
+
+        fr = Frames()
+        fr.W, fr.H, fr.K = W, H, f("K")
+        cams.append(dataset.camera_from_frames(fr))
+    for cam in cams:
+        assert cam["image_height"] == H and cam["image_width"] == W
+        assert float(cam["tanfovx"]) == float(f("tanfovx")) and float(cam["tanfovy"]) == float(f("tanfovy"))
+        assert np.array_equal(cam["viewmatrix"], f("viewmatrix").reshape(4, 4))
+        assert np.array_equal(cam["projmatrix"], f("projmatrix").reshape(4, 4))
+        assert cam["viewmatrix"].dtype == np.float32 and cam["projmatrix"].dtype == np.float32
+        np.testing.assert_allclose(cam["campos"], f("campos"), rtol=0, atol=2e-7)
+        np.testing.assert_allclose(cam["campos"], f("cam_center"), rtol=0, atol=2e-7)
+        assert np.array_equal(cam["bg"], f("bg")) and float(cam["scale_modifier"]) == float(f("scale_modifier"))
+        assert int(cam["sh_degree"]) == int(f("sh_degree")) and bool(cam["prefiltered"]) == bool(f("prefiltered"))
+        assert bool(cam["debug"]) == bool(f("debug"))
+        s = settings_from_cam(cam, "cpu")
+        assert s.viewmatrix.shape == (1, 4, 4) == tuple(f("viewmatrix").shape) and s.projmatrix.shape == (1, 4, 4)
+        assert np.array_equal(s.viewmatrix.numpy(), f("viewmatrix")) and np.array_equal(s.projmatrix.numpy(), f("projmatrix"))
+        assert s.tanfovx == float(f("tanfovx")) and s.tanfovy == float(f("tanfovy")) and s.image_height == H
+        assert np.array_equal(s.bg.numpy(), f("bg")) and s.scale_modifier == 1.0 and s.sh_degree == 0
+        assert s.prefiltered is False and s.debug is False
+    if tag == "c2_identity":
+        assert np.array_equal(cams[0]["campos"], np.zeros(3, np.float32))
+
+
+def test_covariance_matches_the_reference_and_the_oracle_follows_it(oracle32):
+    """Sigma = R S S^T R^T as the reference's own Python states it (build_covariance_from_scaling_rotation,
+    scene/gaussian_model.py:32-36; strip_symmetric order xx, xy, xz, yy, yz, zz) -- the one in-tree statement of the
+    rasteriser's cov3D -- against the oracle's preprocess (raster_oracle.c cov3d_from_scale_rot; fed the
+    normalised quaternion, as get_rotation hands it over) for scale_modifier 1 and 1.7."""
+    from fsgs_amd import synth
+
+    g = _load("covariance.npz")
+    n = len(g["scaling"])
+    cam = synth.make_camera(64, 48)
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 2] = 1.0
+    col = np.zeros((n, 3), np.float32)
+    for key, mod in (("cov6", 1.0), ("cov6_modifier_1p7", 1.7)):
+        c = dict(cam, scale_modifier=mod)
+        st = oracle32.raster_forward(c, xyz, col, np.full(n, 0.5, np.float32), g["scaling"], g["rotation_normalised"])[3]
+        want = g[key]
+        np.testing.assert_allclose(st.cov3D(), want, rtol=2e-5, atol=2e-6 * float(np.abs(want).max()))
+    # the reference normalises inside build_rotation: raw and normalised quaternions give the same Sigma there
+    q = g["rotation_raw"].astype(np.float64)
+    assert np.allclose(q / np.linalg.norm(q, axis=1, keepdims=True), g["rotation_normalised"], atol=1e-6)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from fsgs_amd import synth
-from tests.util import assert_close_attributed, c1_poses, sh0_colors, to_camera_frame
+from tests.util import ATTRIBUTION_LOG, assert_close_attributed, c1_poses, sh0_colors, sign_balance, to_camera_frame
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -40,7 +40,7 @@ def _run_hip(cam, xyz, col, op, sc, rot, dL):
     return n(img), n(depth)[0], n(radii), {k: n(v) for k, v in g.items()}
 
 
-def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False):
+def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False, tag=None):
     """HIP vs the fp32 oracle on the same inputs.  Tolerances per SURVEY.md s8d (1e-4 of the tensor's inf-norm; radii
     and visibility exact).  Every element beyond the tolerance needs a WITNESS: the oracle's own value there must move
     by a comparable amount when the decision thresholds shift by a rounding-sized hair
@@ -63,22 +63,24 @@ def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False):
         assert int(((radii > 0) != (orad > 0)).sum()) == 0, "visibility filter differs"
         stats = {}
         # colours live in [0,1]: abs 1e-4 of full scale
-        stats["image"] = assert_close_attributed(img, oi, zero(oi) if amp is None else amp["image"], "image", floor=1.0)
-        stats["depth"] = assert_close_attributed(dep, od, zero(od) if amp is None else amp["depth"], "depth", floor=1.0)
+        stats["image"] = assert_close_attributed(img, oi, zero(oi) if amp is None else amp["image"], "image", floor=1.0, tag=tag)
+        stats["depth"] = assert_close_attributed(dep, od, zero(od) if amp is None else amp["depth"], "depth", floor=1.0, tag=tag)
         # an analytically-zero gradient (d/drotation of an isotropic Gaussian) is cancellation round-off of
         # terms of size ~|dL/dscale|*|scale| in both implementations: floor each norm at 1e-3 of the largest
         # gradient tensor, i.e. an absolute tolerance of 1e-7 of that for such tensors
         floor = 1e-3 * max(float(np.abs(v).max()) for v in og.values())
         for k in ("means3D", "means2D", "colors", "opacities", "scales", "rotations"):
             a, b = g[k].reshape(P, -1), og[k].reshape(P, -1)
-            stats[k] = assert_close_attributed(a, b, zero(b) if amp is None else amp[k], k, floor=floor)
+            stats[k] = assert_close_attributed(a, b, zero(b) if amp is None else amp[k], k, floor=floor, tag=tag)
         return stats
 
+    n_log = len(ATTRIBUTION_LOG)
     try:  # most cases agree everywhere: the allowances (3 threshold settings x 4 pixel classes + fp64) are only
         return R, check(None, oi, od, orad, og)  # computed when some element is beyond the plain tolerance
     except AssertionError:
         if strict:
             raise
+        del ATTRIBUTION_LOG[n_log:]  # (the records of the tensors that passed before the first outlier)
     amp, (oi, od, orad, og, st) = oracle.flip_amplitudes(cam, xyz, col, op, sc, rot, dL)
     return R, check(amp, oi, od, orad, og)
 
@@ -93,7 +95,7 @@ def test_c1_init_scene_eight_poses(oracle32):
     col = sh0_colors(sc)
     for i, w2c in enumerate(c1_poses()):
         xyz = to_camera_frame(sc["_xyz"], w2c)
-        R, stats = _compare(oracle32, cam, xyz, col, o.reshape(-1), s, r, seed=i)
+        R, stats = _compare(oracle32, cam, xyz, col, o.reshape(-1), s, r, seed=i, tag="c1/%d" % i)
         assert R > P
         # the witnessed outliers are a handful, and so is the set of fragile pixels the allowance applies to
         assert stats["image"][0] <= 40 and stats["depth"][0] <= 40, stats
@@ -119,7 +121,7 @@ def test_six_channel_fused_layout(oracle32):
              r.astype(np.float32), seed=3, strict=True)
 
 
-@pytest.mark.parametrize("scene", ["c1_init", "trained"])
+@pytest.mark.parametrize("scene", ["c1_init", "trained", "c2_trained"])
 def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
     """The image state kept for the backward: final_T per pixel, and n_contrib.  The HIP lists are the oracle's lists
     minus unreachable pairs, so the POSITION of the last contributor differs while the Gaussian it names must not:
@@ -128,12 +130,19 @@ def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
     from fsgs_amd import rasterizer
     from fsgs_amd.trainer import settings_from_cam
 
-    oracle32.set_threads(0)
+    from oracle.fsgs_oracle import usable_cores
+
     if scene == "c1_init":
         W, H, P = 640, 512, 20000
         sc = synth.init_scene(W, H, P, seed=0)
         xyz = to_camera_frame(sc["_xyz"], c1_poses()[1])
         col = sh0_colors(sc)
+    elif scene == "c2_trained":  # BASELINE.json configs[1] size: 5120 tiles, lists of 200-400 entries
+        W, H, P = 1280, 1024, 300_000
+        sc = synth.trained_like_scene(W, H, P, seed=0)
+        xyz = to_camera_frame(sc["_xyz"], c1_poses()[1])
+        col = sh0_colors(sc)
+        oracle32.set_threads(min(usable_cores(), oracle32.max_threads()))
     else:
         W, H, P = 320, 256, 6000
         sc = synth.trained_like_scene(W, H, P, seed=2, base_ratio=0.02)
@@ -162,12 +171,20 @@ def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
     rogue = (mine != ref) & ~fragile
     assert not rogue.any(), "last contributor differs at %d pixels without a near-tie, e.g. %s" % (
         int(rogue.sum()), np.argwhere(rogue)[:4].tolist())
-    assert int((mine != ref).sum()) <= 60 and int(fragile.sum()) < 0.02 * H * W, (int((mine != ref).sum()), int(fragile.sum()))
+    oracle32.set_threads(1)
+    assert int((mine != ref).sum()) <= max(60, 1e-4 * H * W) and int(fragile.sum()) < 0.02 * H * W, (
+        int((mine != ref).sum()), int(fragile.sum()))
     # positions: never beyond the tile's list, and a pixel nobody reached has none
     lens = (v["ranges"][:, 1] - v["ranges"][:, 0])[tile]
     assert (v["n_contrib"].reshape(H, W) <= lens).all()
-    assert_close_attributed(v["final_T"].reshape(-1), ost.final_T().reshape(-1), amp["final_T"].reshape(-1), "final_T",
-                            floor=1.0)
+    res = assert_close_attributed(v["final_T"].reshape(-1), ost.final_T().reshape(-1), amp["final_T"].reshape(-1), "final_T",
+                                  floor=1.0, tag="final_T/" + scene)
+    # the sharpest view of a one-sided path: final_T below the oracle's = this side blended a pair the oracle skipped
+    # (alpha >= 1/255 or T >= 1e-4 decided the other way), above = the reverse; over a frame neither may dominate
+    pos, neg, z = sign_balance([res._asdict()])
+    print("final_T %s: %d witnessed outliers of %d pixels (%d above, %d below the oracle, z = %.2f); last contributor "
+          "differs at %d pixels" % (scene, res.outliers, res.size, pos, neg, z, int((mine != ref).sum())))
+    assert abs(z) <= 4.0, (scene, pos, neg, z)
 
 
 def test_edge_cases_empty_ragged_and_culled(oracle32):
@@ -207,9 +224,9 @@ def test_thresholds_alpha_clamp_and_termination(oracle32):
 # BASELINE.json C2, C4, and 4x C4's cloud (the largest the densification schedule has been seen to reach is ~1.6 M)
 @pytest.mark.parametrize("W,H,P", [(1280, 1024, 300_000), (1920, 1080, 1_000_000), (1920, 1080, 4_000_000)])
 def test_full_size_properties(W, H, P):
-    """full benchmark sizes (too slow for the scalar oracle in CI): size-independent
-    properties instead -- silhouette identity (bg = 1: sum(alpha T) + T_final = 1), linearity of
-    the image in the colours, and the gradient of a constant-one silhouette plane being zero."""
+    """full benchmark sizes, size-independent properties (the oracle itself meets C2 and C4 in
+    tests/test_full_size_oracle_gpu.py; it does not reach 4 M): silhouette identity (bg = 1: sum(alpha T) + T_final
+    = 1), linearity of the image in the colours, and linearity of every gradient in dL/dpixel."""
     from diff_gaussian_rasterization import GaussianRasterizer
     from simple_knn._C import distCUDA2
 
@@ -412,7 +429,35 @@ def test_randomised_small_scenes_match_oracle(oracle32, seed):
     f = lambda a: np.ascontiguousarray(a, np.float32)
     # (the sweep also creates and drops a camera per case: the allocator hands the old matrices' addresses to the new
     # ones, which is how a pointer-keyed host cache of the camera matrices was caught serving stale values)
-    _compare(oracle32, cam, f(xyz), f(col), f(op), f(s), f(r), seed=seed)
+    _compare(oracle32, cam, f(xyz), f(col), f(op), f(s), f(r), seed=seed, tag="sweep/%d" % seed)
+
+
+def test_witnessed_outliers_of_c1_and_the_sweep_are_few_and_unsigned():
+    """element by element an outlier only needs a witness, so a path that lost (or won) EVERY
+    near-tie would still pass.  Over what the C1 poses and the 40-seed sweep above left in ATTRIBUTION_LOG (run in this
+    process, in file order): the witnessed outliers are a vanishing fraction of each tensor's elements, and the sign of
+    got - want over them is that of a fair coin (a biased exp / a one-sided threshold would pile them on one side)."""
+    from tests.util import MAX_OUTLIER_FRACTION, dump_attribution_log
+
+    recs = [r for r in ATTRIBUTION_LOG if r["tag"] and r["tag"].split("/")[0] in ("c1", "sweep")]
+    if not recs:
+        pytest.skip("runs after test_c1_init_scene_eight_poses / the randomised sweep in the same process")
+    summary = {}
+    for group in ("c1", "sweep"):
+        for what in ("image", "depth", "means3D", "means2D", "colors", "opacities", "scales", "rotations"):
+            rs = [r for r in recs if r["tag"].startswith(group + "/") and r["what"] == what]
+            if not rs:
+                continue
+            out, size = sum(r["outliers"] for r in rs), sum(r["size"] for r in rs)
+            summary["%s/%s" % (group, what)] = dict(cases=len(rs), outliers=out, elements=size, fraction=out / size,
+                                                    pos=sum(r["pos"] for r in rs), neg=sum(r["neg"] for r in rs))
+            if group == "c1":  # full-size tensors: the fraction itself (the sweep's tiny tensors are bounded per call)
+                assert out <= MAX_OUTLIER_FRACTION * size, (group, what, out, size)
+    pos, neg, z = sign_balance(recs)
+    summary["sign_balance"] = dict(pos=pos, neg=neg, z=z)
+    print(summary)
+    dump_attribution_log("r03_outlier_statistics", summary)
+    assert abs(z) <= 4.0, (pos, neg, z)
 
 
 def test_unsupported_channel_count_is_an_error_not_a_wrong_image():

@@ -253,3 +253,96 @@ def test_pose_only_backward_without_a_means2D_holder_gives_the_same_pose_gradien
     assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), (a, b)
     assert np.all(a[3] == 0) and np.all(b[3] == 0)
     assert run(False, gs_grad=1)[0] == _lib.FSGS_ERR_INVALID
+
+
+# axis permutations (proper rotations) as raster view matrices: together their upper-left 2x2 blocks of W Sigma W^T
+# visit all six entries of Sigma; entry names index strip_symmetric's order (xx, xy, xz, yy, yz, zz)
+_PERMS = {
+    "identity": (np.eye(3), np.array([0.0, 0.0, 1.0]), (0, 1, 3)),                                   # xx xy yy
+    "yzx": (np.array([[0.0, 1, 0], [0, 0, 1], [1, 0, 0]]), np.array([1.0, 0.0, 0.0]), (3, 4, 5)),    # yy yz zz
+    "zxy": (np.array([[0.0, 0, 1], [1, 0, 0], [0, 1, 0]]), np.array([0.0, 1.0, 0.0]), (5, 2, 0)),    # zz zx xx
+}
+
+
+def _sigma_2x2_from_conic(A, B, Cc, fx, fy, z):
+    """the HIP preprocess stores the conic = inverse of (J W Sigma W^T J^T + 0.3 I); on the optical axis
+    J = diag(fx / z, fy / z), so the block of W Sigma W^T it projected comes back in closed form."""
+    det = A * Cc - B * B
+    a, b, c = Cc / det, -B / det, A / det
+    return (a - 0.3) * z * z / (fx * fx), b * z * z / (fx * fy), (c - 0.3) * z * z / (fy * fy)
+
+
+@pytest.mark.parametrize("perm", sorted(_PERMS))
+@pytest.mark.parametrize("route", ["operator", "fused"])
+def test_hip_preprocess_covariance_equals_the_reference_golden(perm, route):
+    """tests/golden/covariance.npz = build_covariance_from_scaling_rotation of the imported reference
+    (scene/gaussian_model.py:32-36), the in-tree statement of the rasteriser's Sigma = R S^2 R^T.  Each fixture
+    Gaussian is put on the optical axis of an axis-permuting raster camera and the conic the HIP preprocess stored
+    (operator boundary: fsgs_raster_state_layout; fused render: the packed records of fsgs_render_state_layout, fed the
+    RAW scaling / rotation so that exp and normalize run in-kernel) is inverted back to the projected block of Sigma."""
+    g = np.load(os.path.join(G, "covariance.npz"))
+    Wv, axis, entries = _PERMS[perm]
+    n = len(g["scaling"])
+    W, H, f = 96, 80, 40.0
+    K = np.array([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1.0]])
+    w2c = np.eye(4)
+    w2c[:3, :3] = Wv
+    cam = synth.make_camera(W, H, w2c=w2c, K=K)
+    z = np.linspace(0.6, 1.8, n)
+    xyz = (axis[None, :] * z[:, None]).astype(np.float32)
+    if route == "operator":
+        cfg = rasterizer.make_cfg(settings_from_cam(cam, DEV), 3)
+        _, _, radii, st = rasterizer.raster_forward(cfg, T(xyz), T(np.full((n, 3), 0.5)), T(np.full(n, 0.5)), T(g["scaling"]),
+                                                    T(g["rotation_normalised"]))
+        co = rasterizer.state_views(st)["conic_opacity"].cpu().numpy().astype(np.float64)
+        A, B, Cc = co[:, 0], co[:, 1], co[:, 2]
+    else:
+        fz = Fused(cam, xyz, np.zeros((n, 1, 3), np.float32), np.zeros((n, 15, 3), np.float32), np.zeros((n, 1), np.float32),
+                   np.log(g["scaling"]), g["rotation_raw"], np.eye(4, dtype=np.float32), np.zeros(3, np.float32), 0)
+        radii = fz.radii
+        off = (C.c_size_t * 9)()
+        _lib.check(fz.lib.fsgs_render_state_layout(n, W, H, fz.cap, off), "layout")
+        rec = fz.state[off[7]:off[7] + 64 * n].view(torch.float32).reshape(n, 16).cpu().numpy().astype(np.float64)
+        A, B, Cc = rec[:, 2], rec[:, 3], rec[:, 4]
+    assert int((radii > 0).sum()) == n
+    got = _sigma_2x2_from_conic(A, B, Cc, f, f, z)
+    want = g["cov6"].astype(np.float64)
+    scale = np.abs(want).max(axis=1)
+    for v, e in zip(got, entries):
+        assert np.max(np.abs(v - want[:, e]) / scale) <= 2e-5, (perm, route, e, np.max(np.abs(v - want[:, e]) / scale))
+
+
+def test_rasteriser_consumes_the_settings_the_reference_builds(oracle32):
+    """The 12 fields PoseModel.setup_camera handed to GaussianRasterizationSettings in the imported reference
+    (tests/golden/camera.npz, a POSED camera at C1 size) go into the drop-in as they are -- shapes [1,4,4], transposed
+    storage -- and the result is the oracle's on the same matrices."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    from tests.util import assert_close_attributed
+
+    g = np.load(os.path.join(G, "camera.npz"))
+    f = lambda k: g["c1_posed_" + k]
+    W, H = int(f("image_width")), int(f("image_height"))
+    s = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=float(f("tanfovx")), tanfovy=float(f("tanfovy")), bg=T(f("bg")),
+        scale_modifier=float(f("scale_modifier")), viewmatrix=T(f("viewmatrix")), projmatrix=T(f("projmatrix")),
+        sh_degree=int(f("sh_degree")), campos=T(f("campos")), prefiltered=bool(f("prefiltered")), debug=bool(f("debug")))
+    assert tuple(s.viewmatrix.shape) == (1, 4, 4)
+    cam = dict(image_height=H, image_width=W, tanfovx=float(f("tanfovx")), tanfovy=float(f("tanfovy")), bg=f("bg"),
+               viewmatrix=f("viewmatrix").reshape(4, 4), projmatrix=f("projmatrix").reshape(4, 4), K=f("K"))
+    P = 4000
+    xyz, col, op, sc, rot = synth.random_small_scene(P, cam, seed=3)
+    w2c = f("w2c").astype(np.float64)   # random_small_scene places points in the camera frame: move them to the world
+    xyz = (np.linalg.inv(w2c) @ np.concatenate([xyz, np.ones((P, 1))], 1).T).T[:, :3]
+    a32 = lambda a: np.ascontiguousarray(a, np.float32)
+    xyz, col, op, sc, rot = a32(xyz), a32(col), a32(op), a32(sc), a32(rot)
+    m3 = T(xyz).requires_grad_(True)
+    img, radii, depth = GaussianRasterizer(raster_settings=s)(means3D=m3, means2D=torch.zeros_like(m3), opacities=T(op).reshape(-1, 1),
+                                                              colors_precomp=T(col), scales=T(sc), rotations=T(rot))
+    dL = (np.random.default_rng(0).uniform(-1, 1, (3, H, W)) / (3 * H * W)).astype(np.float32)
+    (img * T(dL)).sum().backward()
+    amp, (oi, od, orad, og, ost) = oracle32.flip_amplitudes(cam, xyz, col, op, sc, rot, dL)
+    assert int(((radii.cpu().numpy() > 0) != (orad > 0)).sum()) == 0 and int((orad > 0).sum()) > P // 2
+    assert_close_attributed(img.detach().cpu().numpy(), oi, amp["image"], "image", floor=1.0)
+    floor = 1e-3 * max(float(np.abs(v).max()) for v in og.values())
+    assert_close_attributed(m3.grad.cpu().numpy(), og["means3D"], amp["means3D"], "means3D", floor=floor)

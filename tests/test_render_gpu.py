@@ -12,7 +12,7 @@ from fsgs_amd.model import PARAM_NAMES, GaussianCloud
 from fsgs_amd.render import render, render_two_pass
 from fsgs_amd.trainer import PoseTrack, settings_from_cam
 from tests import ref_cpu
-from tests.util import assert_close_attributed
+from tests.util import ATTRIBUTION_LOG, assert_close_attributed
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -60,6 +60,7 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
 
     def check(ref_o, ref_g, amp_o, amp_g):
         z = lambda ref, amp, k: np.zeros(np.shape(ref[k])) if amp is None else amp[k]
+        stats = {}
         for fn, (got_o, got_g) in runs:
             tag = lambda k: "%s:%s %s" % (fn.__name__, k, ctx or "")
             rogue_r = got_o["radii"] != ref_o["radii"]
@@ -68,7 +69,7 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
             assert not rogue_r.any(), tag("radii")
             assert (got_o["vis"] != ref_o["vis"]).sum() == 0, tag("vis")
             for k in outputs:
-                assert_close_attributed(got_o[k], ref_o[k], z(ref_o, amp_o, k), tag(k), floor=1.0)
+                stats[tag(k)] = assert_close_attributed(got_o[k], ref_o[k], z(ref_o, amp_o, k), tag(k), floor=1.0, tag=ctx)
             rogue_p = got_o["presence"] != ref_o["presence"]
             if amp_o is not None:
                 rogue_p &= ~amp_o["presence"]
@@ -77,14 +78,15 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
                 # dL/dpose = sum over the cloud of g_i [x_i; 1]^T pulled back through LearnPose: P-term fp32 sums in
                 # three different orders (torch on CPU, torch on GPU, DPP + atomics): a few 1e-6 of cancellation on top
                 for k in ("r", "t"):
-                    assert_close_attributed(got_g[k], ref_g[k], z(ref_g, amp_g, k), tag(k), tol=2e-4)
+                    stats[tag(k)] = assert_close_attributed(got_g[k], ref_g[k], z(ref_g, amp_g, k), tag(k), tol=2e-4, tag=ctx)
             else:
                 assert got_g["r"] is None or not np.any(got_g["r"]), tag("r")
             if gs_grad:
                 floor = 1e-3 * max(float(np.abs(ref_g[k]).max()) for k in PARAM_NAMES)
                 for k in PARAM_NAMES + ("viewspace",):
-                    assert_close_attributed(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1),
-                                            z(ref_g, amp_g, k).reshape(P, -1), tag(k), floor=floor)
+                    stats[tag(k)] = assert_close_attributed(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1),
+                                                            z(ref_g, amp_g, k).reshape(P, -1), tag(k), floor=floor, tag=ctx)
+        return stats
 
     # the plain tolerance first, against one pass of the CPU reference; the allowances (3 threshold settings x 4 pixel
     # classes + an fp64 pass of the whole sequence) are only computed when some element is beyond it
@@ -93,11 +95,12 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
     c, p = ref_cpu.cpu_cloud(pc), ref_cpu.cpu_poses(poses)
     with ref_cpu.oracle_backend(oracle):
         ref_o, ref_g = ref_cpu.run_render(two_pass_cpu, c, p, 1, gs_grad, cam_grad, wi.cpu(), wd.cpu(), ws.cpu())
+    n_log = len(ATTRIBUTION_LOG)
     try:
         return check(ref_o, ref_g, None, None)
     except AssertionError:
-        pass
-    check(*ref_cpu.reference_render_with_amplitudes(oracle, pc, poses, 1, gs_grad, cam_grad, wi, wd, ws))
+        del ATTRIBUTION_LOG[n_log:]
+    return check(*ref_cpu.reference_render_with_amplitudes(oracle, pc, poses, 1, gs_grad, cam_grad, wi, wd, ws))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
