@@ -39,6 +39,12 @@ CONFIGS = {
     "C4x4": (1920, 1080, 4_000_000, "trained"),  # size stress only (tests); not a BASELINE.json configuration
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_SIMDS, VALU_CYCLES_PER_WAVE_INST, VALU_CLOCK_HZ = 1024, 2.0, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md
+
+
+def valu_frac(wave_insts, kernel_seconds):
+    """fraction of the spec VALU issue rate: (wave-instructions per SIMD x 2 cycles / 2.4 GHz) / kernel time"""
+    return (wave_insts / VALU_SIMDS) * VALU_CYCLES_PER_WAVE_INST / VALU_CLOCK_HZ / kernel_seconds
 
 
 def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default"):
@@ -158,6 +164,47 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def rccl_diagnostics_env():
+    """N > 1: have RCCL write what it decided at communicator INIT (topology graph, rings / trees, channels, the
+    transport of every peer connection: P2P over xGMI or not) to a per-rank file that rank 0 folds into the bench line's
+    `comm.rccl_info`, so that a poor scaling point can be attributed.  Init-time subsystems only: nothing
+    is logged per collective, the timed loop is not touched.  FSGS_RCCL_TUNING_LOG=1 adds the TUNING subsystem (the
+    algorithm / protocol chosen per call -- one log line per collective, a diagnostic run, not a measurement).
+    Variables the user already set win."""
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    subsys = "INIT,GRAPH,ENV" + (",TUNING" if os.environ.get("FSGS_RCCL_TUNING_LOG") == "1" else "")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", subsys)
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fsgs_rccl.%h.%p.log")
+
+
+def rccl_info_lines(limit=40):
+    """the lines of this rank's RCCL INFO log that name the topology, channels, transports, algorithm / protocol"""
+    import glob
+    import re
+
+    pat = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not pat:
+        return None
+    files = glob.glob(pat.replace("%h", "*").replace("%p", str(os.getpid())))
+    keep = re.compile(r"(RCCL version|NCCL version|nRanks|Channel \d+/\d+\s*:|Ring \d+|Trees|channels|via P2P|via SHM|via NET|"
+                      r"xGMI|XGMI|Algo|[Pp]rotocol|proto |threshold|NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set|Connected all)")
+    out = []
+    for f in files:
+        try:
+            for line in open(f, errors="replace"):
+                if keep.search(line):
+                    out.append(re.sub(r"^\S+:\d+:\d+ \[\d+\] ", "", line.strip())[:200])
+        except OSError:
+            pass
+    seen, uniq = set(), []
+    for l in out:  # channel lines repeat per peer: one of each shape is enough
+        key = re.sub(r"\d+", "#", l)
+        if key not in seen:
+            seen.add(key)
+            uniq.append(l)
+    return uniq[:limit]
+
+
 EXTRAS_DEADLINE_S = int(os.environ.get("FSGS_BENCH_EXTRAS_DEADLINE", "300"))  # N > 1: what the reporting / extras behind the timed loop may take before the line is printed without them
 
 
@@ -203,6 +250,8 @@ def main():
     from fsgs_amd import _lib, dist as fdist
     from fsgs_amd.trainer import mapping_step
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rccl_diagnostics_env()
     rank, world, local = fdist.init_from_env()
     if args.gpus != world:
         # a launcher started a different number of ranks than --gpus names: refuse, a mislabelled line is worse than none
@@ -317,6 +366,9 @@ def main():
                     "config": {"workload": "%s: mapping iteration, %dx%d, %d Gaussians (%s scene), 1 camera/rank" % (
                         args.config, W, H, P, CONFIGS[args.config][3]), "parallelism": "dp%d" % world},
                     "roofline": None, "cpu_baseline": None,
+                    # machine-readable: the timed loop (barrier + synchronize on both sides) completed on every rank, what
+                    # was abandoned is the reporting phase behind it -- a scaling record can flag the run on this field
+                    "extras_incomplete": True,
                     "note": "the untimed extras behind the timed loop did not finish within %d s and were abandoned" % EXTRAS_DEADLINE_S,
                 }), flush=True)
             os._exit(0)
@@ -376,12 +428,30 @@ def main():
                     # profiles/r02_inst_cost_ubench.txt): a SIMD retires one plain VALU wave-instruction per ~2.0 ns
                     # at 4 waves/SIMD and per ~1.4 ns at 8 (one wave alone: 3.8 ns) -- issue is paced per wave.
                     per_simd = avg_s * 1e9 / (wi / 1024.0)
+                    # roofline.valu_frac: the fraction of the SPEC VALU issue rate -- one wave-instruction per SIMD per 2
+                    # cycles (a wave64 op on a 32-wide datapath) at 2.4 GHz over 1024 SIMDs -- this kernel's instruction
+                    # stream reaches: (SQ_INSTS_VALU / 1024 x 2 / 2.4 GHz) / avg kernel time.  The roof these kernels
+                    # actually have (north_star declares HBM; `frac` above stays the mandated HBM fraction).
+                    roofline["valu_frac"] = valu_frac(wi, avg_s)
                     roofline["valu"] = {"wave_insts": wi, "salu_wave_insts": ent.get("salu_wave_insts"),
                                         "ns_per_valu_inst_per_simd": per_simd,
                                         "ubench_ns_per_fma_at_4_and_8_waves": [2.02, 1.38],
                                         "waves_per_simd": ent.get("waves_per_simd"),
                                         "active_valu_cycles_per_inst": ent.get("active_valu_cycles_per_inst"),
                                         "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU in %s" % src}
+                # the second issue-bound kernel, same definitions: blend_fwd (HIP events of this run; counters offline)
+                fms, fl = prof.get("blend_fwd", (0.0, 0))
+                fhits = [k for k in pmc["kernels"] if k.startswith("blend_fwd_kernel<%d" % C)]
+                if fl and len(fhits) == 1:
+                    fent = pmc["kernels"][fhits[0]]
+                    f_alg = R * (4 + 24 + 4 * C) + H * W * (4 * C + 4 + 8)
+                    f_s = fms / fl / 1e3
+                    roofline["blend_fwd"] = {
+                        "kernel": fhits[0], "avg_kernel_ms": fms / fl, "algorithmic_bytes": f_alg,
+                        "achieved": f_alg / f_s / 1e9, "frac": f_alg / f_s / 1e9 / HBM_PEAK_GBS,
+                        "traffic": fent.get("traffic_bytes"),
+                        "valu_frac": valu_frac(fent["valu_wave_insts"], f_s) if fent.get("valu_wave_insts") else None,
+                        "valu_wave_insts": fent.get("valu_wave_insts")}
         except Exception as e:  # noqa: BLE001
             roofline["traffic_error"] = "%s: %s" % (type(e).__name__, e)
             sys.stderr.write("bench.py: roofline.traffic unavailable -- %s\n" % roofline["traffic_error"])
@@ -502,6 +572,31 @@ def main():
                 "backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                 "devices": torch.cuda.device_count(), "one_gpu_smoke": os.environ.get("FSGS_DIST_ONE_GPU") == "1"}
 
+        def timed(fn, reps=10):
+            for _ in range(2):
+                fn()
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / reps * 1e3
+
+        # the same bytes as 4 row chunks back to back (what --ar-chunks 4 issues; chunk bounds = multiples of 256 rows) and
+        # one tiny message: latency vs bandwidth of this fabric, so that t(one collective) = a + bytes / b can be read off
+        rows = nfloat // (14 if use_fast else 59)
+        per = max(256, -(-(-(-rows // 4)) // 256) * 256)
+        width = nfloat // rows
+        chunks = [buf[lo * width:min(rows, lo + per) * width] for lo in range(0, rows, per)]
+        comm["chunks4_ms"] = timed(lambda: [torch.distributed.all_reduce(c) for c in chunks])
+        tiny = torch.zeros((1024,), dtype=torch.float32, device=device)
+        comm["latency_4KB_ms"] = timed(lambda: torch.distributed.all_reduce(tiny), reps=50)
+        comm["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMP_NUM"))}
+        try:
+            comm["rccl_info"] = rccl_info_lines()
+        except Exception as e:  # noqa: BLE001  (diagnostics must never cost the measurement)
+            comm["rccl_info"] = "unavailable: %s" % e
+
     # ---- extra (N > 1): the same step with the exchange pipelined on the producer side, so that the scaling record
     # shows what hiding the collective behind the per-Gaussian backward and Adam is worth on this fabric ----
     pipelined = None
@@ -551,6 +646,7 @@ def main():
             "raster_fwd_bwd_ms": None if raster is None else raster["raster_fwd_bwd_ms"], "raster": raster,
             "tracking_step": tracking, "two_view_mapping_step": two_view, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
             "comm_pipelined": pipelined,
+            "extras_incomplete": False,
         }
         print(json.dumps(out), flush=True)
     if watchdog is not None:

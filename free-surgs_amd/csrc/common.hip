@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "fsgs_device.h"
+#include "selftest_reductions.h"  // reductions only the selftest below calls
 #include "fsgs_host.h"
 
 namespace fsgs {

@@ -319,12 +319,91 @@ __device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
   __syncthreads();
 }
 
+// The dispatch order of the blend kernels (longest list first, see tile_order_kernel below), R and the mailbox word
+// depend on the segment fill counts ALONE -- list length of a tile = sum of its eight clamped cursors -- which the
+// scatter kernel has finished before the sort kernel starts.  So they need neither a launch of their own behind the
+// sort nor its results: ONE extra workgroup of the sort launch (block 0, dispatched first) forms them while the other
+// workgroups sort.  That removes a kernel boundary and a single-workgroup kernel (7 us at C2 on a 256-CU chip) from
+// the forward's critical path, and the host -- which polls the mailbox before it can hand the blend's launch over --
+// hears R a whole sort kernel earlier.  ntiles <= 8192.
+// 256 bins of four list lengths each (lists of 1020 entries and more share the first bin: they start first either way);
+// the tiles' bins are parked in LDS as bytes, so this path costs the sort kernel no registers (as one more launch-wide
+// register array it took the whole kernel from 8 to 5 waves per SIMD).
+constexpr int ORDER_BINS_FUSED = 256;
+__device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 KB + 8 KB of LDS */, int ntiles,
+                                                        const uint32_t *__restrict__ cursors, uint32_t cap_sub,
+                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ total_out,
+                                                        uint32_t *host_word) {
+  __shared__ uint32_t wave_tot[4], wave_len[4], wave_worst[4];
+  uint32_t *hist = smem;                                             // [256]
+  uint8_t *bins = reinterpret_cast<uint8_t *>(smem + ORDER_BINS_FUSED);  // [ntiles <= 8192]
+  uint32_t mine = 0, worst = 0;
+  hist[threadIdx.x] = 0;
+#pragma unroll 4
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) {  // strided ownership: coalesced 32-byte rows
+    const uint4 a = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS);
+    const uint4 b = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS + 4);
+    worst = max(worst, max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
+    const uint32_t n = min(a.x, cap_sub) + min(a.y, cap_sub) + min(a.z, cap_sub) + min(a.w, cap_sub) +
+                       min(b.x, cap_sub) + min(b.y, cap_sub) + min(b.z, cap_sub) + min(b.w, cap_sub);
+    mine += n;
+    bins[i] = (uint8_t)(ORDER_BINS_FUSED - 1 - (int)min(n >> 2, (uint32_t)(ORDER_BINS_FUSED - 1)));  // bin 0 = longest
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    uint32_t sm = mine, wm = worst;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sm += (uint32_t)__shfl_xor((int)sm, off, 64);
+      wm = max(wm, (uint32_t)__shfl_xor((int)wm, off, 64));
+    }
+    if (lane == 0) { wave_len[wv] = sm; wave_worst[wv] = wm; }
+  }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) atomicAdd(&hist[bins[i]], 1u);
+  if (threadIdx.x == 0) {
+    const uint32_t R = wave_len[0] + wave_len[1] + wave_len[2] + wave_len[3];
+    const uint32_t w = max(max(wave_worst[0], wave_worst[1]), max(wave_worst[2], wave_worst[3]));
+    const uint32_t need = w > cap_sub ? w : 0u;  // a segment overflowed: the capacity that would have sufficed
+    total_out[0] = R;
+    total_out[1] = need;
+    if (host_word)
+      __hip_atomic_store(host_word, need ? (0x80000000u | need) : R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  // exclusive scan of the 256 bins, one per thread
+  const uint32_t c = hist[threadIdx.x];
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    if (w < wv) before += wave_tot[w];
+  hist[threadIdx.x] = before + incl - c;
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) order[atomicAdd(&hist[bins[i]], 1u)] = (uint32_t)i;
+}
+
+// order != nullptr: the launch has ntiles + 1 workgroups, block 0 forms the dispatch order / R / mailbox word (above) and
+// reports overflows itself; otherwise block b sorts tile b and overflows go to *overflow_need (read by tile_order_kernel).
 __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint32_t *__restrict__ cursors,
                                                          unsigned long long *__restrict__ keys,
                                                          uint32_t *__restrict__ plist, int2 *__restrict__ ranges,
-                                                         uint32_t cap_sub, uint32_t *__restrict__ overflow_need) {
+                                                         uint32_t cap_sub, uint32_t *__restrict__ overflow_need,
+                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ total_out,
+                                                         uint32_t *host_word) {
   __shared__ __attribute__((aligned(16))) unsigned long long lds[SORT_LDS_KEYS + 2];
-  const int tile = blockIdx.x;
+  if (order != nullptr && blockIdx.x == 0) {
+    tile_order_from_cursors(reinterpret_cast<uint32_t *>(lds), ntiles, cursors, cap_sub, order, total_out, host_word);
+    return;
+  }
+  const int tile = order != nullptr ? (int)blockIdx.x - 1 : (int)blockIdx.x;
   // the eight segment fill counts (wave-uniform loads); a count above the capacity = dropped keys
   uint32_t cnt[BIN_SUBS], off[BIN_SUBS + 1], worst = 0;
   off[0] = 0;
@@ -335,7 +414,7 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
     cnt[s] = min(c, cap_sub);
     off[s + 1] = off[s] + cnt[s];
   }
-  if (worst > cap_sub && threadIdx.x == 0) atomicMax(overflow_need, worst);
+  if (order == nullptr && worst > cap_sub && threadIdx.x == 0) atomicMax(overflow_need, worst);
   const int n = (int)off[BIN_SUBS];
   const size_t base = (size_t)tile * BIN_SUBS * cap_sub;  // of the tile's keys AND of its plist slice
   if (threadIdx.x == 0) ranges[tile] = make_int2((int)base, (int)base + n);
@@ -557,73 +636,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int ntiles, int nbands
       pos += min(rank, sz) + ((b2 < band && sz > rank) ? 1u : 0u);
     }
     order[pos] = (uint32_t)i;
-  }
-}
-
-// The default order (one band): the same job with the list lengths kept in registers (ntiles <= 8192), one
-// 1024-bin histogram and one bin per thread in the scan -- half the latency chain of the general kernel.
-__global__ __launch_bounds__(1024) void tile_order_lpt_kernel(int ntiles, const int2 *__restrict__ ranges,
-                                                              uint32_t *__restrict__ order,
-                                                              uint32_t *__restrict__ total_out,
-                                                              const uint32_t *__restrict__ overflow_need,
-                                                              uint32_t *host_word) {
-  __shared__ uint32_t hist[ORDER_BINS];
-  __shared__ uint32_t wave_tot[16], wave_len[16];
-  constexpr int PER = 8;
-  int len[PER];
-  uint32_t mine = 0;
-#pragma unroll
-  for (int q = 0; q < PER; q++) {  // strided ownership: coalesced loads
-    const int i = threadIdx.x + 1024 * q;
-    len[q] = 0;
-    if (i < ntiles) {
-      const int2 rg = ranges[i];
-      len[q] = rg.y - rg.x;
-    }
-    mine += (uint32_t)len[q];
-  }
-  hist[threadIdx.x] = 0;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  {
-    uint32_t s = mine;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off, 64);
-    if (lane == 0) wave_len[wv] = s;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < PER; q++)
-    if (threadIdx.x + 1024 * q < ntiles) atomicAdd(&hist[ORDER_BINS - 1 - min(len[q], ORDER_BINS - 1)], 1u);  // bin 0 = longest
-  if (threadIdx.x == 0) {
-    uint32_t R = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) R += wave_len[w];
-    *total_out = R;
-    const uint32_t need = *overflow_need;
-    if (host_word)
-      __hip_atomic_store(host_word, need ? (0x80000000u | need) : R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __syncthreads();
-  // exclusive scan of the 1024 bins, one per thread
-  const uint32_t c = hist[threadIdx.x];
-  uint32_t incl = c;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-    if (lane >= off) incl += up;
-  }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-#pragma unroll
-  for (int w = 0; w < 16; w++)
-    if (w < wv) before += wave_tot[w];
-  hist[threadIdx.x] = before + incl - c;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < PER; q++) {
-    const int i = threadIdx.x + 1024 * q;
-    if (i < ntiles) order[atomicAdd(&hist[ORDER_BINS - 1 - min(len[q], ORDER_BINS - 1)], 1u)] = (uint32_t)i;
   }
 }
 
@@ -887,6 +899,13 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_b
   // after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
   // (the 12-of-16 reduction folds the cheap lane bits first and leaves its totals in another lane order: transpose12_slot)
   constexpr bool CHEAP_FIRST = !POSE_ONLY && CG <= 4;
+  // The cheap-first reductions leave the DPP banks of their UNUSED slots (12..15 of 16, 5..7 of 8) unwritten: those lanes
+  // hold undefined register contents, possibly NaN.  That is safe only while `c_used` below masks exactly those slots out
+  // of the atomics -- tie the slot map to the variants, so a change of SL / CG / GP cannot let garbage through
+  // (fsgs_selftest_transpose_reduce_n widths 3212 / 1605 check the used slots, tests/test_raster_gpu.py).
+  static_assert(GP == 2, "both cheap-first reductions transpose two Gaussians at a time");
+  static_assert(!CHEAP_FIRST || (SL == 16 && 8 + CG <= 12), "12-of-16 reduction: slots 12..15 must be unused");
+  static_assert(!POSE_ONLY || SL == 8, "5-of-8 reduction: slots 5..7 must be unused");
   const int my_slot = POSE_ONLY ? transpose5_slot(lane) : CHEAP_FIRST ? transpose12_slot(lane) : lane / REP;
   const int my_u = my_slot / SL, my_c = my_slot % SL;
   // one lane of those that hold the same total issues the atomic
@@ -1236,7 +1255,7 @@ int bind_forward_buffers(int P, int W, int H, int64_t max_pairs, int keep_channe
   B.keys = (unsigned long long *)(xb + XL.keys);
   return FSGS_OK;
 }
-// Everything between the preprocess kernel and the blend: scatter, per-tile sort, dispatch order -- three
+// Everything between the preprocess kernel and the blend: scatter, per-tile sort + dispatch order -- two
 // launches (the cursors were cleared by the preprocess kernel in front), all enqueued without knowing R.  The caller enqueues the forward blend right behind
 // them and only then calls finish_binning(), which polls the mailbox: the GPU never waits for the host.  If a
 // list segment overflowed, the blend ran on truncated (in-bounds) lists and its output is garbage; the call then
@@ -1266,15 +1285,17 @@ inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t m
   tk.slot = mailbox_acquire();
   {
     ProfScope ps(PROF_SORT_TILE, stream);
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
-                       B.ranges, tk.cap_sub, B.total + 1);
-    if (!(cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) && ntiles <= 8 * 1024)
-      hipLaunchKernelGGL(tile_order_lpt_kernel, dim3(1), dim3(1024), 0, stream, ntiles, B.ranges, B.order, B.total,
-                         B.total + 1, (uint32_t *)tk.slot);
-    else
+    if (!(cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) && ntiles <= 8 * 1024) {
+      // the default: dispatch order, R and the mailbox word come from workgroup 0 of the sort launch itself
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles + 1), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
+                         B.ranges, tk.cap_sub, B.total + 1, B.order, B.total, (uint32_t *)tk.slot);
+    } else {
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
+                         B.ranges, tk.cap_sub, B.total + 1, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, ntiles,
                          (cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) ? ORDER_XCD : 1, B.ranges, B.order, B.total,
                          B.total + 1, (uint32_t *)tk.slot);
+    }
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

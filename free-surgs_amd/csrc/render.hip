@@ -507,11 +507,17 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   }
   if (i < P) {
     if (out.means2D) { out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f; }
+    // max_radii2D is raised with an integer atomic max (non-negative floats order like their bit patterns): the views
+    // of a multi-view step run their backwards on different streams and may meet on the same Gaussian
     if (tail.accum && rad > 0) {  // add_densification_stats of train.py:298-303 (the holder's z component is 0)
       const float gz = 0.f;
-      tail.max_radii2D[i] = fmaxf(st_mr, (float)rad);
+      if ((float)rad > st_mr) atomicMax((int *)(tail.max_radii2D + i), __float_as_int((float)rad));
       tail.accum[i] = st_acc + sqrtf(m2x * m2x + m2y * m2y + gz * gz);
       tail.denom[i] = st_den + 1.0f;
+    } else if (!tail.accum && tail.max_radii2D && rad > 0) {
+      // a further view of the step: render() raises max_radii2D for EVERY rendered view
+      // (gaussian_renderer/__init__.py:79), the gradient statistic is view 0's alone (train.py:260-263)
+      atomicMax((int *)(tail.max_radii2D + i), __float_as_int((float)rad));
     }
     if (OUT != OUT_GRADS || out.xyz) {
       sink.put(0, i, 0, dxyz[0]);
@@ -594,7 +600,8 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParam
 // Adam step of all six groups from the compact per-Gaussian gradient (see OUT_COMPACT): the SH gradients
 // basis_k x gcol_c are formed here, in LDS, and never exist in HBM.  The basis uses the position BEFORE this
 // step's update, i.e. the one the forward pass saw.
-__global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc, AdamDev ad) {
+__global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, const float *__restrict__ gc,
+                                                           const float *__restrict__ gc2, AdamDev ad) {
   __shared__ __attribute__((aligned(16))) float s_rest[RB * SH_REST_MAX];
   const RenderGradsDev none{};
   GradSink<OUT_ADAM> sink{none, a, ad};
@@ -604,7 +611,19 @@ __global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, co
   const size_t stage_cnt = (size_t)min(RB, P - b0) * row;
   if (i < P) {
     sink.prefetch(i);
-    const float *g = gc + (size_t)i * COMPACT_ROW;
+    // the step's gradient = the sum over its views: a second view's rows are added here instead of by a launch of
+    // their own (the two views' backwards run on two streams and write two buffers)
+    float g[COMPACT_ROW];
+    {
+      const float *g1 = gc + (size_t)i * COMPACT_ROW;
+#pragma unroll
+      for (int c = 0; c < COMPACT_ROW; c++) g[c] = g1[c];
+      if (gc2) {
+        const float *g2 = gc2 + (size_t)i * COMPACT_ROW;
+#pragma unroll
+        for (int c = 0; c < COMPACT_ROW; c++) g[c] += g2[c];
+      }
+    }
     const float vx = a.xyz[3 * i] - a.cam_center[0], vy = a.xyz[3 * i + 1] - a.cam_center[1],
                 vz = a.xyz[3 * i + 2] - a.cam_center[2];
     const float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
@@ -855,7 +874,10 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   StepTailDev td{};
   if (tail) {
     if (tail->xyz_gradient_accum || tail->denom || tail->max_radii2D) {
-      if (!(tail->xyz_gradient_accum && tail->denom && tail->max_radii2D)) return FSGS_ERR_INVALID;
+      // all three (view 0 of a step) or max_radii2D alone (a further view: the radius side effect only)
+      const bool all3 = tail->xyz_gradient_accum && tail->denom && tail->max_radii2D;
+      const bool radii_only = tail->max_radii2D && !tail->xyz_gradient_accum && !tail->denom;
+      if (!all3 && !radii_only) return FSGS_ERR_INVALID;
       td.max_radii2D = tail->max_radii2D; td.accum = tail->xyz_gradient_accum; td.denom = tail->denom;
     }
     if (tail->loss_total) {
@@ -942,6 +964,11 @@ int fsgs_render_backward_compact_rows(const FsgsRasterCfg *cfg, int P, const Fsg
 
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,
                            fsgs_stream_t stream_) {
+  return fsgs_adam_step_compact_sum(P, args, gcompact, nullptr, adam, stream_);
+}
+
+int fsgs_adam_step_compact_sum(int P, const FsgsRenderArgs *args, const float *gcompact, const float *gcompact2,
+                               const FsgsFusedAdam *adam, fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (P < 0 || !adam) return FSGS_ERR_INVALID;
   if (P == 0) return FSGS_OK;
@@ -954,7 +981,8 @@ int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcomp
   if (fill_adam(adam, args->max_sh_degree, ad) != FSGS_OK) return FSGS_ERR_INVALID;
   {
     ProfScope ps(PROF_ADAM, stream);
-    hipLaunchKernelGGL(adam_compact_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, to_dev(args), gcompact, ad);
+    hipLaunchKernelGGL(adam_compact_kernel, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, to_dev(args), gcompact,
+                       gcompact2, ad);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

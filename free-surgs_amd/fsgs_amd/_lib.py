@@ -139,6 +139,7 @@ _PROTOTYPES = {
          C.POINTER(FsgsStepTail), _vp, _sz, _i, _i, _i, _vp],
     ),
     "fsgs_adam_step_compact": (_i, [_i, C.POINTER(FsgsRenderArgs), _vp, C.POINTER(FsgsFusedAdam), _vp]),
+    "fsgs_adam_step_compact_sum": (_i, [_i, C.POINTER(FsgsRenderArgs), _vp, _vp, C.POINTER(FsgsFusedAdam), _vp]),
     "fsgs_render_backward_adam": (
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _sz, _i64, _i64, _vp, _vp,

@@ -147,14 +147,22 @@ class ProducerPipelinedReducer:
         self._pending = []
 
     def bounds(self, P):
-        per = -(-int(P) // self.nchunks)
+        """Row chunks of this step's production.  Called once at the start of a step's production: whatever an aborted
+        earlier step left queued (an exception between produced() and finish()) is dropped here -- its rows may lie past
+        the cloud's new size after a densification.  An empty cloud still gets ONE (0, 0) chunk, so that the backward
+        call that also writes the step's scalar loss is made."""
+        self._pending = []
+        P = int(P)
+        if P <= 0:
+            return [(0, 0)]
+        per = -(-P // self.nchunks)
         per = max(256, -(-per // 256) * 256)
-        return [(lo, min(int(P), lo + per)) for lo in range(0, int(P), per)]
+        return [(lo, min(P, lo + per)) for lo in range(0, P, per)]
 
     def produced(self, gc, lo, hi):
         """rows [lo, hi) of gc are final on the current stream: start their all-reduce."""
-        live = _live()
-        if not gc.is_cuda:
+        live = _live() and hi > lo
+        if not gc.is_cuda or hi <= lo:
             if live:
                 dist.all_reduce(gc[lo:hi], op=dist.ReduceOp.SUM)
             self._pending.append((lo, hi, None))
@@ -179,7 +187,8 @@ class ProducerPipelinedReducer:
         for lo, hi, done in pending:
             if done is not None:
                 torch.cuda.current_stream().wait_event(done)
-            adam_rows(lo, hi)
+            if hi > lo:
+                adam_rows(lo, hi)
 
     def __call__(self, gc, adam_rows):
         """consumer-side fallback (several views per step: the gradient is only final after the last view)."""

@@ -13,6 +13,7 @@ autograd graph (the torch-autograd path spends ~0.5 ms/step of pure host time in
 Equivalence with the autograd path is asserted in tests/test_fast_step_gpu.py.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -60,7 +61,7 @@ class _Buffers:
         self.flow_out = self.terms[5:7]  # {flow loss, #valid points}
         self.flow_scratch = None
         self.d_flow = f(4, 4)
-        self.gc = self.gc_view = None  # compact gradient [P,14] (lazily: only multi-view / multi-rank steps)
+        self.gc = None  # this view's compact gradient [P,14] (lazily: only multi-view / multi-rank steps)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
         self.bwd_scratch = torch.empty((P * 64 + 512,), dtype=torch.uint8, device=dev)
@@ -80,6 +81,7 @@ class FastStepper:
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
         self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
+        self.overlap_views = True  # multi-view mapping steps: views >= 1 on their own streams beside view 0
 
     def _check_frames(self):
         """the per-frame targets are handed to the kernels as raw pointers: float32, contiguous, on the cloud's device,
@@ -99,11 +101,19 @@ class FastStepper:
                         name, i, lead + (hw or ("H", "W")), dev))
 
     # ---- helpers -----------------------------------------------------------------------------------------
-    def _buffers(self, P, H, W, n_patches, dev):
+    def _buffers(self, P, H, W, n_patches, dev, view=0):
+        """buffer set of view `view` of a step (view 0 = self.buf; the further views of a multi-view step own theirs,
+        so that their pipelines can run beside view 0's on another stream)"""
         key = (P, H, W, n_patches, str(dev))
-        if self.buf is None or self.buf.key != key:
-            self.buf = _Buffers(P, H, W, n_patches, dev)
-        return self.buf
+        if view == 0:
+            if self.buf is None or self.buf.key != key:
+                self.buf = _Buffers(P, H, W, n_patches, dev)
+            return self.buf
+        extra = self.__dict__.setdefault("_view_bufs", {})
+        b = extra.get(view)
+        if b is None or b.key != key:
+            b = extra[view] = _Buffers(P, H, W, n_patches, dev)
+        return b
 
     def _cfg(self):
         cam = self.pc.cam
@@ -160,8 +170,10 @@ class FastStepper:
         # the previous forward's state instead of evaluating 48 SH coefficients per Gaussian again.
         ckey = (P, W, H, pc.active_sh_degree, pc.max_sh_degree, self.poses.cam_center._version) + tuple(
             (id(p[n]), p[n]._version) for n in PARAM_NAMES)
+        # (the tensors themselves are part of the entry: ids alone can be recycled by the allocator)
+        owners = tuple(p[n] for n in PARAM_NAMES) + (self.poses.cam_center,)
         prev = self.__dict__.get("_color_src") if getattr(self, "reuse_colors", True) else None
-        if prev is not None and (prev[0] != ckey or any(a is not b for a, b in zip(prev[4], (p[n] for n in PARAM_NAMES)))):
+        if prev is not None and (prev[0] != ckey or len(prev[4]) != len(owners) or any(a is not b for a, b in zip(prev[4], owners))):
             prev = None
         for _attempt in range(3):
             sz = b.sizes.get(cap)
@@ -172,6 +184,8 @@ class FastStepper:
             state = torch.empty((sz[0],), dtype=torch.uint8, device=dev)
             scratch = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
             if prev is not None:
+                # (the source state may belong to another stream's pool: view 0's forward, read by view 1's on its own)
+                prev[1].record_stream(torch.cuda.current_stream())
                 rc = lib.fsgs_render_forward_reuse_colors(
                     C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil), _lib.ptr(b.radii),
                     _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap, C.byref(nr), _lib.ptr(prev[1]), prev[2], prev[3],
@@ -188,12 +202,35 @@ class FastStepper:
             break
         else:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
-        # (the tensors themselves are part of the entry: ids alone can be recycled by the allocator)
-        self._color_src = (ckey, state, sz[0], cap, tuple(p[n] for n in PARAM_NAMES))
+        if prev is not None and os.environ.get("FSGS_CHECK_REUSE") == "1":
+            self._check_reused_colors(cfg, P, W, H, args, state, sz, cap, b)
+        self._color_src = (ckey, state, sz[0], cap, owners)
         rasterizer.last_num_rendered = int(nr.value)
         self.pairs_total += int(nr.value)  # (bench.py reports the mean pair count of the steps it timed)
         self.forward_calls += 1
         return args, state, sz[0], cap, int(nr.value)
+
+    def _check_reused_colors(self, cfg, P, W, H, args, state, sz, cap, b):
+        """FSGS_CHECK_REUSE=1 (debugging): the reuse above rests on every raw-pointer writer bumping the version
+        counters (optim.mark_updated); here the colours are evaluated afresh into a throw-away state and compared with
+        the ones the forward just copied -- a writer that forgot the bump shows up as a mismatch instead of as a
+        silently stale image."""
+        lib = self.lib
+        dev = state.device
+        st2 = torch.empty_like(state)
+        scr = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
+        img, ds, rad = torch.empty_like(b.image), torch.empty_like(b.depth_sil), torch.empty_like(b.radii)
+        nr = C.c_int64(0)
+        _lib.check(lib.fsgs_render_forward(C.byref(cfg), P, C.byref(args), _lib.ptr(img), _lib.ptr(ds), _lib.ptr(rad),
+                                           _lib.ptr(st2), sz[0], _lib.ptr(scr), sz[1], cap, C.byref(nr),
+                                           _lib.current_stream()), "fsgs_render_forward (FSGS_CHECK_REUSE)")
+        off = (C.c_size_t * 9)()
+        _lib.check(lib.fsgs_render_state_layout(P, W, H, cap, off), "fsgs_render_state_layout")
+        rec = lambda s_: s_[off[7]:off[7] + 64 * P].view(torch.float32).reshape(P, 16)[:, 8:14]
+        vis = rad > 0
+        if not torch.equal(rec(state)[vis], rec(st2)[vis]):
+            raise RuntimeError("FSGS_CHECK_REUSE: the per-Gaussian colours copied from the previous forward differ from "
+                               "freshly evaluated ones -- a parameter or cam_center was written without a version bump")
 
     def _fused_adam_struct(self):
         """FsgsFusedAdam for the six groups of pc.optimizer (state created on first use, step counters advanced:
@@ -236,10 +273,20 @@ class FastStepper:
                 ad2.exp_avg_sq[g] = adam.exp_avg_sq[g] + 4 * r * lo
         return a2, ad2
 
-    def _side_stream(self, dev):
-        st = getattr(self, "_side", None)
+    def _side_stream(self, dev, view=0):
+        """the second stream of a view's pipeline (Pearson chain / flow loss beside the photometric kernels)"""
+        pool = self.__dict__.setdefault("_sides", {})
+        st = pool.get(view)
         if st is None or st.device != torch.device(dev):
-            st = self._side = torch.cuda.Stream(device=dev)
+            st = pool[view] = torch.cuda.Stream(device=dev)
+        return st
+
+    def _view_stream(self, dev, view):
+        """the stream the whole pipeline of view `view` >= 1 of a multi-view step runs on"""
+        pool = self.__dict__.setdefault("_view_streams", {})
+        st = pool.get(view)
+        if st is None or st.device != torch.device(dev):
+            st = pool[view] = torch.cuda.Stream(device=dev)
         return st
 
     def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
@@ -275,18 +322,71 @@ class FastStepper:
             for k in ("max_radii2D", "xyz_gradient_accum", "denom"):
                 if not (v[k].is_contiguous() and v[k].dtype == torch.float32):
                     v[k] = v[k].contiguous().float()
-            t.max_radii2D, t.xyz_gradient_accum, t.denom = (v["max_radii2D"].data_ptr(),
-                                                           v["xyz_gradient_accum"].data_ptr(), v["denom"].data_ptr())
-            keep = [v["max_radii2D"], v["xyz_gradient_accum"], v["denom"]]
+            t.max_radii2D = v["max_radii2D"].data_ptr()
+            keep = [v["max_radii2D"]]
+            if with_stats != "radii":  # "radii": a further view of the step raises max_radii2D only (FsgsStepTail)
+                t.xyz_gradient_accum, t.denom = v["xyz_gradient_accum"].data_ptr(), v["denom"].data_ptr()
+                keep += [v["xyz_gradient_accum"], v["denom"]]
         return t, total, keep
 
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
+    def _view_forward_and_losses(self, b, ts, corners, dev, H, W, n_patches, view):
+        """Front half of one view's pipeline on the CURRENT stream (+ the view's side stream): render forward, L1+SSIM
+        forward / backward, patch draws + Pearson forward / backward.  Leaves dL/dimage in b.d_image, dL/ddepth in
+        b.d_depth_sil[0], the loss terms in b.terms.  -> (args, state, sbytes, cap, nr, event behind the forward)"""
+        lib = self.lib
+        stream = _lib.current_stream()
+        w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
+               else self.poses.get_pose(ts).detach().contiguous())
+        # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound) are independent
+        # until the render backward: they run on two HIP streams.  What the side stream can do without the render
+        # -- the two randint launches of the patch corners (same position in the RNG sequence as at loss time:
+        # nothing else draws in between) and the clear of the backward's accumulators (free since the previous
+        # backward, which is in front of `begun` on this stream) -- is queued before the forward, so that the
+        # chain behind the forward is the three Pearson launches only.
+        side = self._side_stream(dev, view)
+        begun = torch.cuda.Event()
+        begun.record()
+        side.wait_event(begun)
+        with torch.cuda.stream(side):
+            cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+            b.bwd_scratch.zero_()
+        args, state, sbytes, cap, nr = self._render_forward(w2c, b)
+        gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
+        fwd_done = torch.cuda.Event()
+        fwd_done.record()
+        # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
+        _lib.check(lib.fsgs_photometric_loss_forward_backward(
+            3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
+            _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
+            "fsgs_photometric_loss_forward_backward")
+        side.wait_event(fwd_done)
+        with torch.cuda.stream(side):
+            sstream = _lib.current_stream()
+            dep = b.depth_sil[0]
+            _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
+                                                _lib.ptr(b.pe_out), sstream), "fsgs_pearson_forward")
+            _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                                 _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
+                                                 0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
+            side_done = torch.cuda.Event()
+            side_done.record()
+            for t_ in cr:  # drawn on the side stream, last used there
+                t_.record_stream(side)
+        torch.cuda.current_stream().wait_event(side_done)
+        return args, state, sbytes, cap, nr, fwd_done
+
     def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None,
                      collect_stats=True):
         """One mapping iteration over `timesteps` (summed loss).  Gradient routes:
           * one view, no reduction, optimizer stepped here  -> Adam inside the render backward (no gradient tensors);
-          * several views and / or `reduce_compact(tensor)` (the data-parallel all-reduce) -> the compact [P,14]
-            gradient is summed / reduced and consumed by fsgs_adam_step_compact;
+          * several views and / or `reduce_compact(tensor)` (the data-parallel all-reduce) -> one compact [P,14]
+            gradient per view; fsgs_adam_step_compact_sum consumes the sum of two views' directly, an exchange gets
+            their sum in one buffer.  The views' pipelines (forward -> losses -> backward) are independent until Adam:
+            view k >= 1 runs on a stream of its own with its own buffers (`overlap_views`), its latency-bound
+            preprocess / binning kernels and the tails of its blend kernels filling the SIMDs beside view 0's
+            issue-bound blend kernels (train.py:236-259 runs them one after the other);
           * step_optimizer=False or the legacy `grad_sync(pc)` -> full gradients in the parameters' .grad.
         collect_stats=False (only with the first two routes): the densification statistics are not accumulated --
         for iterations past the last densification (train.py:305: `iteration < 15000`), where nothing reads them."""
@@ -299,160 +399,162 @@ class FastStepper:
         with torch.no_grad(), torch.cuda.device(dev):
             b = self._buffers(pc.num_points, H, W, n_patches, dev)
             stream = _lib.current_stream()
-            for k, ts in enumerate(timesteps):
-                w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
-                       else self.poses.get_pose(ts).detach().contiguous())
-                # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound) are independent
-                # until the render backward: they run on two HIP streams.  What the side stream can do without the render
-                # -- the two randint launches of the patch corners (same position in the RNG sequence as at loss time:
-                # nothing else draws in between) and the clear of the backward's accumulators (free since the previous
-                # backward, which is in front of `begun` on the main stream) -- is queued before the forward, so that the
-                # chain behind the forward is the three Pearson launches only.
-                side = self._side_stream(dev)
-                begun = torch.cuda.Event()
-                begun.record()
-                side.wait_event(begun)
-                with torch.cuda.stream(side):
-                    cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
-                    b.bwd_scratch.zero_()
-                args, state, sbytes, cap, nr = self._render_forward(w2c, b)
-                gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
-                fwd_done = torch.cuda.Event()
-                fwd_done.record()
-                # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
-                _lib.check(lib.fsgs_photometric_loss_forward_backward(
-                    3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
-                    _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
-                    "fsgs_photometric_loss_forward_backward")
-                side.wait_event(fwd_done)
-                with torch.cuda.stream(side):
-                    sstream = _lib.current_stream()
-                    dep = b.depth_sil[0]
-                    _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                        _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
-                                                        _lib.ptr(b.pe_out), sstream), "fsgs_pearson_forward")
-                    _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                         _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
-                                                         0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
-                    side_done = torch.cuda.Event()
-                    side_done.record()
-                    for t_ in cr:  # drawn on the side stream, last used there
-                        t_.record_stream(side)
-                torch.cuda.current_stream().wait_event(side_done)
-                fused_ok = step_optimizer and grad_sync is None and isinstance(pc.optimizer, optim.FusedAdam)
-                # single view, single rank: the backward feeds Adam directly (no gradient tensors at all)
-                fuse_adam = self.fuse_adam and fused_ok and len(timesteps) == 1 and reduce_compact is None
-                if fuse_adam:
-                    adam = self._fused_adam_struct()
-                    cfg = self._cfg_zeroed()
-                    # statistics and the scalar loss ride in the same launch (no densify_stats / dot kernels)
-                    tail, total, _keep = self._step_tail(b, b.term_w, collect_stats)
-                    _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
-                                                             _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
-                                                             _lib.ptr(b.d_depth_sil), C.byref(adam),
-                                                             _lib.ptr(b.means2D_grad) if collect_stats else None,
-                                                             C.byref(tail), _lib.ptr(b.bwd_scratch),
-                                                             b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
-                    optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
-                    step_optimizer = False  # done
-                    stats_done = True
-                    radii0 = b.radii
-                    break
-                if self.compact and fused_ok:
+            fused_ok = step_optimizer and grad_sync is None and isinstance(pc.optimizer, optim.FusedAdam)
+            # single view, single rank: the backward feeds Adam directly (no gradient tensors at all)
+            fuse_adam = self.fuse_adam and fused_ok and len(timesteps) == 1 and reduce_compact is None
+            if fuse_adam:
+                ts = timesteps[0]
+                args, state, sbytes, cap, nr, _ = self._view_forward_and_losses(b, ts, corners, dev, H, W, n_patches, 0)
+                adam = self._fused_adam_struct()
+                cfg = self._cfg_zeroed()
+                # statistics and the scalar loss ride in the same launch (no densify_stats / dot kernels)
+                tail, total, _keep = self._step_tail(b, b.term_w, collect_stats)
+                _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
+                                                         _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
+                                                         _lib.ptr(b.d_depth_sil), C.byref(adam),
+                                                         _lib.ptr(b.means2D_grad) if collect_stats else None,
+                                                         C.byref(tail), _lib.ptr(b.bwd_scratch),
+                                                         b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
+                optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
+                step_optimizer = False  # done
+                stats_done = True
+                radii0, last_b = b.radii, b
+            elif self.compact and fused_ok:
+                radii0, last_b, state, cap = self._mapping_compact(timesteps, corners, reduce_compact, collect_stats,
+                                                                   dev, H, W, n_patches)
+                total = self._compact_total
+                stats_done = collect_stats
+                step_optimizer = False  # done
+            else:
+                for k, ts in enumerate(timesteps):
+                    args, state, sbytes, cap, nr, _ = self._view_forward_and_losses(b, ts, corners, dev, H, W, n_patches, 0)
+                    # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
                     first = k == 0
-                    if b.gc is None:
-                        b.gc = torch.empty((pc.num_points, 14), dtype=torch.float32, device=dev)
-                        b.gc_view = torch.empty_like(b.gc)
-                    tgt_gc = b.gc if first else b.gc_view
-                    # the densification statistic comes from view 0 only (train.py:260-263): later views skip its terms
-                    m2 = b.means2D_grad if (first and collect_stats) else None
-                    cfg = self._cfg_zeroed()
-                    tail, loss_k, _keep = self._step_tail(b, b.term_w, first and collect_stats)
-                    # one view per step and a producer-side reducer (N > 1): the per-Gaussian backward goes out in row
-                    # chunks, the all-reduce of each chunk starts while the next one is produced (dist.py)
-                    produce = (len(timesteps) == 1 and getattr(reduce_compact, "producer", False))
-                    if produce:
-                        for ci, (lo, hi) in enumerate(reduce_compact.bounds(pc.num_points)):
-                            _lib.check(lib.fsgs_render_backward_compact_rows(
-                                C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
-                                _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil), _lib.ptr(tgt_gc),
-                                None if m2 is None else _lib.ptr(m2), C.byref(tail), _lib.ptr(b.bwd_scratch),
-                                b.bwd_scratch.numel(), lo, hi, int(ci == 0), stream), "fsgs_render_backward_compact_rows")
-                            reduce_compact.produced(tgt_gc, lo, hi)
-                    else:
-                        _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args),
-                                                                    _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
-                                                                    _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil),
-                                                                    _lib.ptr(tgt_gc), None if m2 is None else _lib.ptr(m2),
-                                                                    C.byref(tail), _lib.ptr(b.bwd_scratch),
-                                                                    b.bwd_scratch.numel(), stream),
-                                   "fsgs_render_backward_compact")
-                    if first:
-                        stats_done = collect_stats
-                    else:
-                        b.gc.add_(b.gc_view)
-                        if collect_stats:
-                            pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
-                    total = loss_k if total is None else total + loss_k
-                    if first:
-                        radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
-                    if k == len(timesteps) - 1:
-                        adam = self._fused_adam_struct()
-
-                        def adam_rows(lo, hi, args=args, adam=adam):
-                            """Adam for Gaussians [lo, hi) from the (reduced) compact gradient"""
-                            a2, ad2 = self._offset_structs(args, adam, lo)
-                            with torch.cuda.device(dev):
-                                _lib.check(lib.fsgs_adam_step_compact(hi - lo, C.byref(a2), b.gc.data_ptr() + lo * 56,
-                                                                      C.byref(ad2), _lib.current_stream()),
-                                           "fsgs_adam_step_compact")
-
-                        if reduce_compact is None:
-                            adam_rows(0, pc.num_points)
-                        elif produce:
-                            reduce_compact.finish(adam_rows)  # Adam per chunk, each behind its own all-reduce
-                        elif getattr(reduce_compact, "pipelined", False):
-                            reduce_compact(b.gc, adam_rows)  # chunked: all-reduce of chunk i+1 beside Adam of chunk i
+                    tgt = []
+                    for name in PARAM_NAMES:
+                        p = pc.params[name]
+                        if first:
+                            if p.grad is None:
+                                p.grad = torch.empty_like(p)
+                            tgt.append(p.grad)
                         else:
-                            reduce_compact(b.gc)  # ONE all-reduce of 56 B / Gaussian
-                            adam_rows(0, pc.num_points)
-                        optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
-                        step_optimizer = False  # done
-                    continue
-                # render backward straight into the parameters' .grad (view 0) or a scratch set that is added
-                first = k == 0
-                tgt = []
-                for name in PARAM_NAMES:
-                    p = pc.params[name]
-                    if first:
-                        if p.grad is None:
-                            p.grad = torch.empty_like(p)
-                        tgt.append(p.grad)
-                    else:
-                        tgt.append(torch.empty_like(p))
-                m2 = b.means2D_grad if first else torch.empty_like(b.means2D_grad)
-                grads = self._grad_struct(tgt, m2, None)
-                self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, b.d_depth_sil, grads, True, False, True)
-                if not first:
-                    for name, t in zip(PARAM_NAMES, tgt):
-                        pc.params[name].grad.add_(t)
-                    # render() itself raises max_radii2D for EVERY rendered view (gaussian_renderer/__init__.py:79)
-                    pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
-                loss_k = torch.dot(b.terms, b.term_w)
-                total = loss_k if total is None else total + loss_k
-                if first:  # densification statistics come from view 0 only (train.py:260-263)
-                    radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
+                            tgt.append(torch.empty_like(p))
+                    m2 = b.means2D_grad if first else torch.empty_like(b.means2D_grad)
+                    grads = self._grad_struct(tgt, m2, None)
+                    self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, b.d_depth_sil, grads, True, False, True)
+                    if not first:
+                        for name, t in zip(PARAM_NAMES, tgt):
+                            pc.params[name].grad.add_(t)
+                        # render() itself raises max_radii2D for EVERY rendered view (gaussian_renderer/__init__.py:79)
+                        pc.variables["max_radii2D"] = torch.maximum(pc.variables["max_radii2D"], b.radii.float())
+                    loss_k = torch.dot(b.terms, b.term_w)
+                    total = loss_k if total is None else total + loss_k
+                    if first:  # densification statistics come from view 0 only (train.py:260-263)
+                        radii0 = b.radii if len(timesteps) == 1 else b.radii.clone()
+                last_b = b
             if grad_sync is not None:
                 grad_sync(pc)
             if collect_stats and not stats_done:
                 optim.densify_stats(radii0, b.means2D_grad, pc.variables["max_radii2D"],
                                     pc.variables["xyz_gradient_accum"], pc.variables["denom"])
-            self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": b.image, "depth_sil": b.depth_sil,
-                         "state": state, "max_pairs": cap, "radii_last": b.radii, "P": pc.num_points}  # LAST view (debugging / statistics)
+            self.last = {"radii": radii0, "viewspace_grad": b.means2D_grad, "image": last_b.image,
+                         "depth_sil": last_b.depth_sil, "state": state, "max_pairs": cap, "radii_last": last_b.radii,
+                         "P": pc.num_points}  # LAST view (debugging / statistics)
             if step_optimizer:
                 pc.optimizer.step()
                 # gradients are overwritten by the next step's backward; nothing to zero
         return total
+
+    def _mapping_compact(self, timesteps, corners, reduce_compact, collect_stats, dev, H, W, n_patches):
+        """The compact-gradient route of mapping_step: every view's backward leaves its [P,14] gradient in the view's own
+        buffer set; views >= 1 run on their own streams when `overlap_views`; Adam consumes the (reduced) sum."""
+        pc, lib = self.pc, self.lib
+        P = pc.num_points
+        main = torch.cuda.current_stream()
+        overlap = getattr(self, "overlap_views", True) and len(timesteps) > 1
+        views, joins, totals = [], [], []
+        fwd0 = None
+        for k, ts in enumerate(timesteps):
+            b = self._buffers(P, H, W, n_patches, dev, view=k)
+            first = k == 0
+            vstream = main if (first or not overlap) else self._view_stream(dev, k)
+            if vstream is not main:
+                # the parameters are final behind the previous Adam, and this view copies its per-Gaussian colours from
+                # view 0's forward state: both lie in front of `fwd0` on the main stream
+                vstream.wait_event(fwd0)
+            with torch.cuda.stream(vstream):
+                stream = _lib.current_stream()
+                args, state, sbytes, cap, nr, fwd_done = self._view_forward_and_losses(b, ts, corners, dev, H, W,
+                                                                                      n_patches, k)
+                if first:
+                    fwd0 = fwd_done
+                if b.gc is None:
+                    b.gc = torch.empty((P, 14), dtype=torch.float32, device=dev)
+                # the densification statistic comes from view 0 only (train.py:260-263); the other views of the step raise
+                # max_radii2D, as every render() does (gaussian_renderer/__init__.py:79) -- both inside the backward launch
+                m2 = b.means2D_grad if (first and collect_stats) else None
+                cfg = self._cfg_zeroed()
+                tail, loss_k, _keep = self._step_tail(b, b.term_w, (True if first else "radii") if collect_stats else False)
+                # one view per step and a producer-side reducer (N > 1): the per-Gaussian backward goes out in row
+                # chunks, the all-reduce of each chunk starts while the next one is produced (dist.py)
+                produce = (len(timesteps) == 1 and getattr(reduce_compact, "producer", False))
+                if produce:
+                    for ci, (lo, hi) in enumerate(reduce_compact.bounds(P)):
+                        _lib.check(lib.fsgs_render_backward_compact_rows(
+                            C.byref(cfg), P, C.byref(args), _lib.ptr(b.radii), _lib.ptr(state), sbytes, cap, nr,
+                            _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil), _lib.ptr(b.gc),
+                            None if m2 is None else _lib.ptr(m2), C.byref(tail), _lib.ptr(b.bwd_scratch),
+                            b.bwd_scratch.numel(), lo, hi, int(ci == 0), stream), "fsgs_render_backward_compact_rows")
+                        reduce_compact.produced(b.gc, lo, hi)
+                else:
+                    _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), P, C.byref(args), _lib.ptr(b.radii),
+                                                                _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
+                                                                _lib.ptr(b.d_depth_sil), _lib.ptr(b.gc),
+                                                                None if m2 is None else _lib.ptr(m2), C.byref(tail),
+                                                                _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(), stream),
+                               "fsgs_render_backward_compact")
+                if vstream is not main:
+                    done = torch.cuda.Event()
+                    done.record()
+                    joins.append(done)
+            views.append(b)
+            totals.append(loss_k)
+        for e in joins:
+            main.wait_event(e)
+        total = totals[0]
+        for t_ in totals[1:]:
+            total = total + t_
+        self._compact_total = total
+        b0 = views[0]
+        # Adam reads at most two gradient buffers: further views (the reference never has more than two) are added up
+        for extra in views[2:]:
+            views[1].gc.add_(extra.gc)
+        second = views[1].gc if len(views) > 1 else None
+        if reduce_compact is not None and second is not None:  # an exchange moves ONE buffer
+            b0.gc.add_(second)
+            second = None
+        adam = self._fused_adam_struct()
+
+        def adam_rows(lo, hi, args=args, adam=adam):
+            """Adam for Gaussians [lo, hi) from the (reduced) compact gradient"""
+            a2, ad2 = self._offset_structs(args, adam, lo)
+            with torch.cuda.device(dev):
+                _lib.check(lib.fsgs_adam_step_compact_sum(hi - lo, C.byref(a2), b0.gc.data_ptr() + lo * 56,
+                                                          None if second is None else second.data_ptr() + lo * 56,
+                                                          C.byref(ad2), _lib.current_stream()),
+                           "fsgs_adam_step_compact_sum")
+
+        if reduce_compact is None:
+            adam_rows(0, P)
+        elif produce:
+            reduce_compact.finish(adam_rows)  # Adam per chunk, each behind its own all-reduce
+        elif getattr(reduce_compact, "pipelined", False):
+            reduce_compact(b0.gc, adam_rows)  # chunked: all-reduce of chunk i+1 beside Adam of chunk i
+        else:
+            reduce_compact(b0.gc)  # ONE all-reduce of 56 B / Gaussian
+            adam_rows(0, P)
+        optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
+        return b0.radii, views[-1], state, cap
 
     # ---- tracking (train.py:166-200) -----------------------------------------------------------------------
     def tracking_step(self, t, targets, rigid_mask, want_losses=True):

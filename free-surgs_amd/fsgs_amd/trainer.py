@@ -461,8 +461,16 @@ class Runner:
     def eval_pose(self):
         from . import metrics
 
+        n = len(self.frames.colors)
         with torch.no_grad():
-            pred = np.stack([self.poses.get_pose(i).detach().cpu().numpy() for i in range(len(self.frames.colors))])
+            if self.test_frame_quirks:
+                # train.py:499-500 reads record_data['pred_w2c'] -- what the LAST get_pose of each frame recorded (for a
+                # test frame the pose its last tracking iteration rendered with, before that iteration's optimizer step;
+                # zeros for a frame no get_pose ever reached, scene/pose_optimizer.py:454) -- and records nothing itself
+                pred = np.stack([np.zeros((4, 4), np.float32) if w is None else w.detach().cpu().numpy()
+                                 for w in self.poses.pred_w2c[:n]])
+            else:  # the poses as they stand now; an evaluation leaves the record alone either way
+                pred = np.stack([self.poses.peek_pose(i).cpu().numpy() for i in range(n)])
         # train.py:492-506: every <data> run of the sequence is Sim(3)-aligned on its own and the three metrics are summed
         # with the runs' frame-count weights (dataset.read_sequence keeps data_ind / weights / gt_poses per run)
         runs = getattr(self.frames, "gt_poses", None)

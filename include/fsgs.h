@@ -244,7 +244,9 @@ typedef struct FsgsFusedAdam {
  *    Gaussians with radii > 0:  max_radii2D = max(., radius), xyz_gradient_accum += ||dL/dmeans2D (RGB pass)||,
  *    denom += 1   (what fsgs_densify_stats does from the means2D_grad tensor in a launch of its own);
  *  - the scalar loss of the iteration, loss_total[0] = sum_k loss_terms[k] * loss_weights[k] (n_terms <= 16 device
- *    floats each, written by the loss kernels earlier on the stream): reporting only, nothing reads it back. */
+ *    floats each, written by the loss kernels earlier on the stream): reporting only, nothing reads it back.
+ *  With max_radii2D alone (xyz_gradient_accum = denom = NULL) only the radius maximum is raised: a further view of a
+ *  multi-view step (render() updates max_radii2D for every view it renders, gaussian_renderer/__init__.py:79). */
 typedef struct FsgsStepTail {
   float *max_radii2D;         /* [P] */
   float *xyz_gradient_accum;  /* [P] */
@@ -284,6 +286,11 @@ int fsgs_render_backward_compact_rows(const FsgsRasterCfg *cfg, int P, const Fsg
  * on the fly.  Updates args->xyz ... args->rotation and the moments in place; args->w2c is not read. */
 int fsgs_adam_step_compact(int P, const FsgsRenderArgs *args, const float *gcompact, const FsgsFusedAdam *adam,
                            fsgs_stream_t stream);
+/* The same from the SUM of two compact gradients (gcompact2 may be NULL): the two views of the reference's progressive
+ * mapping iteration (train.py:236-259, summed loss) run their backwards on two streams into two buffers, and the
+ * sum is formed here instead of by a launch of its own. */
+int fsgs_adam_step_compact_sum(int P, const FsgsRenderArgs *args, const float *gcompact, const float *gcompact2,
+                               const FsgsFusedAdam *adam, fsgs_stream_t stream);
 
 /* ---- simple-knn -------------------------------------------------------------- */
 

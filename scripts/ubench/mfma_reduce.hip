@@ -6,6 +6,7 @@
 // F = 160 (the VALU work of two pairs' quadrant bodies), to see whether the MFMAs overlap the other waves' VALU work.
 //   hipcc --offload-arch=gfx950 -O3 -I free-surgs_amd/csrc -o scripts/ubench/mfma_reduce.bin scripts/ubench/mfma_reduce.hip
 #include "fsgs_device.h"
+#include "selftest_reductions.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

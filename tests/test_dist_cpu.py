@@ -118,6 +118,25 @@ def _compact_worker(rank, world, port, out_dir):
     seen.clear()
     fdist.ProducerPipelinedReducer(2)(gc, adam_rows)
     assert [s[0] for s in seen] == [0, 512] and seen[-1][1] == P
+    # a step that died between produced() and finish() (an FsgsError in a later chunk) must not leak its chunks into the
+    # next step -- after a densification they may lie past the cloud -- and an empty cloud still yields one (0, 0) chunk
+    # (the backward call that writes the step's loss), which neither exchanges nor steps anything
+    red = fdist.ProducerPipelinedReducer(2)
+    red.bounds(P)
+    red.produced(gc, 0, 512)
+    assert len(red._pending) == 1
+    small = base[:300] * (rank + 1)
+    seen.clear()
+    P_small = 300
+    for lo, hi in red.bounds(P_small):
+        red.produced(small, lo, hi)
+    red.finish(lambda lo, hi: seen.append((lo, hi)))
+    assert seen == [(0, 256), (256, 300)] and torch.equal(small, base[:300] * 3)
+    assert red.bounds(0) == [(0, 0)]
+    red.produced(small[:0], 0, 0)
+    seen.clear()
+    red.finish(lambda lo, hi: seen.append((lo, hi)))
+    assert seen == [] and red._pending == []
     dist.barrier()
     dist.destroy_process_group()
 
@@ -126,3 +145,39 @@ def test_compact_gradient_reducers():
     """all_reduce_compact / PipelinedCompactReducer / ProducerPipelinedReducer (fsgs_amd/dist.py): the [P,14] gradient
     of the HIP step driver, as one collective, consumer-side chunks and producer-side chunks."""
     mp.spawn(_compact_worker, args=(2, _free_port(), ""), nprocs=2, join=True)
+
+
+def _producer_world4_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fsgs_amd import dist as fdist
+
+    fdist.init_from_env(backend="gloo")
+    red = fdist.ProducerPipelinedReducer(4)
+    scale = sum(q + 1 for q in range(world))
+    # three "steps" with a densification between them: P is never a multiple of 256 x chunks, grows, then shrinks below
+    # one chunk; the compact gradient buffer is re-made whenever P changes (fast_step._Buffers does the same)
+    for step, P in enumerate((1037, 1037, 2911, 130)):
+        base = torch.arange(P * 14, dtype=torch.float32).reshape(P, 14) + step
+        gc = base * (rank + 1)
+        bounds = red.bounds(P)
+        assert bounds[0][0] == 0 and bounds[-1][1] == P and len(bounds) <= 4
+        assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:])) and all(lo % 256 == 0 for lo, _ in bounds)
+        done = []
+        for lo, hi in bounds:
+            red.produced(gc, lo, hi)
+
+        def adam_rows(lo, hi):
+            assert torch.equal(gc[lo:hi], base[lo:hi] * scale)  # this chunk's exchange has landed
+            done.append((lo, hi))
+
+        red.finish(adam_rows)
+        assert done == bounds and torch.equal(gc, base * scale)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_producer_pipelined_reducer_world_four_uneven_rows_and_a_changing_cloud():
+    """dist.ProducerPipelinedReducer over four gloo ranks: row counts that are not multiples of 256 x chunks, a cloud
+    that grows and shrinks between steps (densify / prune), every row exchanged exactly once before its Adam chunk."""
+    mp.spawn(_producer_world4_worker, args=(4, _free_port(), ""), nprocs=4, join=True)

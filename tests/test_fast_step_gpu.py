@@ -140,6 +140,35 @@ def test_mapping_step_without_statistics_is_the_same_update():
     assert float(a[0].variables["denom"].sum()) > 0 and float(b[0].variables["denom"].sum()) == 0
 
 
+def test_two_view_step_overlapped_on_two_streams_equals_the_serial_step():
+    """The progressive phase's two-view iteration (train.py:236-259): view 1's whole pipeline on its own stream and buffer
+    set beside view 0's, the two compact gradients summed inside fsgs_adam_step_compact_sum, max_radii2D raised by BOTH
+    views inside their backward launches (gaussian_renderer/__init__.py:79) -- against the same step with the views one
+    after the other on one stream, and against the full-gradient route (gradients added by torch, torch.maximum for the
+    radii); three views exercise the fold of the surplus views."""
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    worlds = [_world() for _ in range(3)]
+    steppers = [FastStepper(w[0], w[1], w[2]) for w in worlds]
+    steppers[1].overlap_views = False
+    steppers[2].fuse_adam = steppers[2].compact = False
+    assert steppers[0].overlap_views
+    for views in ([2, 1], [1, 2], [0, 1, 2], [1]):
+        ls = [fs.mapping_step(views, corners=corners) for fs in steppers]
+        torch.cuda.synchronize()
+        assert all(abs(l.item() - ls[0].item()) <= 1e-5 * abs(ls[0].item()) for l in ls)
+    ref = worlds[1][0]
+    for w in (worlds[0], worlds[2]):
+        pc = w[0]
+        for k in PARAM_NAMES:
+            pa, pb = ref.params[k].detach(), pc.params[k].detach()
+            assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
+        for k in ("max_radii2D", "denom"):
+            assert torch.equal(ref.variables[k], pc.variables[k]), k
+        assert torch.allclose(ref.variables["xyz_gradient_accum"], pc.variables["xyz_gradient_accum"], rtol=1e-4, atol=1e-9)
+    assert float(ref.variables["max_radii2D"].max()) > 0
+
+
 def test_full_size_c2_gradient_routes_agree():
     """BASELINE.json's C2 (1280x1024, 300 000 Gaussians): the three gradient routes of the step driver -- Adam inside the
     backward, the compact [P,14] gradient, full gradients + multi-tensor Adam -- must produce the same update at full

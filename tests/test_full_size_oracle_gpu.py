@@ -31,7 +31,7 @@ _scenes = {}
 def oracle_all_cores(oracle32):
     from oracle.fsgs_oracle import usable_cores
 
-    n = min(usable_cores(), oracle32.max_threads())
+    n = usable_cores()  # (not min(., max_threads()): the session fixture set 1 thread, which is what max_threads reports)
     old = torch.get_num_threads()
     oracle32.set_threads(n)
     torch.set_num_threads(n)

@@ -422,8 +422,20 @@ def test_eval_pose_aligns_every_run_on_its_own_and_global_run_starts_at_iteratio
                               "_features_rest": torch.randn(5, 15, 3), "_opacity": torch.randn(5, 1),
                               "_scaling": torch.randn(5, 3), "_rotation": torch.randn(5, 4)}, device="cpu")
     run = Runner(pc, poses, frames, fused=False)
+    for i in range(8):  # what a run leaves behind: every frame's last get_pose recorded (scene/pose_optimizer.py:635-638)
+        poses.get_pose(i)
     rpe_t, rpe_r, ate = run.eval_pose()
     assert ate < 1e-4 and rpe_r < 0.3, (rpe_t, rpe_r, ate)
+    # train.py:499-500 evaluates the RECORD, not the parameters: a pose moved after its last get_pose (a test frame's last
+    # tracking step) does not show, and the evaluation itself records nothing; test_frame_quirks=False reads the
+    # parameters as they stand -- without touching the record either
+    recorded = [w.clone() for w in poses.pred_w2c]
+    poses.set_pose(4, (1, 0, 0, 0), (5.0, 5.0, 5.0))
+    assert run.eval_pose()[2] == ate
+    run.test_frame_quirks = False
+    assert run.eval_pose()[2] > 10 * max(ate, 1e-6)
+    assert all(torch.equal(a, b) for a, b in zip(recorded, poses.pred_w2c))
+    run.test_frame_quirks = True
     del frames.gt_poses  # one joint alignment of the two differently-scaled runs cannot fit both
     assert run.eval_pose()[2] > 1e-2
     # the iterations of the global phase

@@ -5,6 +5,8 @@ import torch
 
 from fsgs_amd import synth
 
+from oracle.fsgs_oracle import usable_cores
+
 pytestmark = pytest.mark.gpu
 
 
@@ -16,7 +18,7 @@ def _hip(pts):
 
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 255, 256, 257, 1000, 20000])
 def test_random_clouds_match_oracle(oracle32, P):
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     pts = np.random.default_rng(P).standard_normal((P, 3)).astype(np.float32)
     got, want = _hip(pts), oracle32.knn_meandist2(pts)
     fin = np.isfinite(want) & (want < 1e37)
@@ -26,7 +28,7 @@ def test_random_clouds_match_oracle(oracle32, P):
 
 def test_init_cloud_32k_matches_oracle(oracle32):
     """the actual use: back-projected first-frame cloud (scene/gaussian_model.py:346)."""
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     sc = synth.init_scene(640, 512, 32768, seed=1, knn_fn=lambda p: np.ones(len(p)))
     got, want = _hip(sc["_xyz"]), oracle32.knn_meandist2(sc["_xyz"])
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
@@ -57,7 +59,7 @@ def test_full_size_idempotence_and_permutation_invariance():
 def test_randomised_clouds_with_degenerate_geometry(oracle32, seed):
     """cloud sizes around the Morton-box and workgroup boundaries; anisotropic, planar, collinear and clustered point
     sets; exact duplicates (distance 0) mixed in; wide dynamic range of coordinates."""
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     rng = np.random.default_rng(300 + seed)
     P = int(rng.choice([4, 6, 63, 64, 65, 127, 129, 511, 513, 1023, 1025, 3000, 5000]))
     kind = seed % 5

@@ -9,6 +9,8 @@ import torch
 from fsgs_amd import synth
 from tests.util import ATTRIBUTION_LOG, assert_close_attributed, c1_poses, sh0_colors, sign_balance, to_camera_frame
 
+from oracle.fsgs_oracle import usable_cores
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -87,7 +89,7 @@ def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False, tag=None)
 
 def test_c1_init_scene_eight_poses(oracle32):
     """BASELINE.json configs[0]: 640x512, 20k init Gaussians, 8 poses, pure raster fwd/bwd."""
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     W, H, P = 640, 512, 20000
     cam = synth.make_camera(W, H)
     sc = synth.init_scene(W, H, P, seed=0)
@@ -142,7 +144,7 @@ def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
         sc = synth.trained_like_scene(W, H, P, seed=0)
         xyz = to_camera_frame(sc["_xyz"], c1_poses()[1])
         col = sh0_colors(sc)
-        oracle32.set_threads(min(usable_cores(), oracle32.max_threads()))
+        oracle32.set_threads(usable_cores())
     else:
         W, H, P = 320, 256, 6000
         sc = synth.trained_like_scene(W, H, P, seed=2, base_ratio=0.02)

@@ -12,7 +12,9 @@ from fsgs_amd.model import PARAM_NAMES, GaussianCloud
 from fsgs_amd.render import render, render_two_pass
 from fsgs_amd.trainer import PoseTrack, settings_from_cam
 from tests import ref_cpu
-from tests.util import ATTRIBUTION_LOG, assert_close_attributed
+from tests.util import ATTRIBUTION_LOG, RENDER_OUTLIER_FRACTION, assert_close_attributed
+
+from oracle.fsgs_oracle import usable_cores
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -69,7 +71,7 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
             assert not rogue_r.any(), tag("radii")
             assert (got_o["vis"] != ref_o["vis"]).sum() == 0, tag("vis")
             for k in outputs:
-                stats[tag(k)] = assert_close_attributed(got_o[k], ref_o[k], z(ref_o, amp_o, k), tag(k), floor=1.0, tag=ctx)
+                stats[tag(k)] = assert_close_attributed(got_o[k], ref_o[k], z(ref_o, amp_o, k), tag(k), floor=1.0, tag=ctx, max_fraction=RENDER_OUTLIER_FRACTION)
             rogue_p = got_o["presence"] != ref_o["presence"]
             if amp_o is not None:
                 rogue_p &= ~amp_o["presence"]
@@ -78,14 +80,15 @@ def _check_against_reference(oracle, pc, poses, gs_grad, cam_grad, wi, wd, ws, f
                 # dL/dpose = sum over the cloud of g_i [x_i; 1]^T pulled back through LearnPose: P-term fp32 sums in
                 # three different orders (torch on CPU, torch on GPU, DPP + atomics): a few 1e-6 of cancellation on top
                 for k in ("r", "t"):
-                    stats[tag(k)] = assert_close_attributed(got_g[k], ref_g[k], z(ref_g, amp_g, k), tag(k), tol=2e-4, tag=ctx)
+                    stats[tag(k)] = assert_close_attributed(got_g[k], ref_g[k], z(ref_g, amp_g, k), tag(k), tol=2e-4, tag=ctx, max_fraction=RENDER_OUTLIER_FRACTION)
             else:
                 assert got_g["r"] is None or not np.any(got_g["r"]), tag("r")
             if gs_grad:
                 floor = 1e-3 * max(float(np.abs(ref_g[k]).max()) for k in PARAM_NAMES)
                 for k in PARAM_NAMES + ("viewspace",):
                     stats[tag(k)] = assert_close_attributed(got_g[k].reshape(P, -1), ref_g[k].reshape(P, -1),
-                                                            z(ref_g, amp_g, k).reshape(P, -1), tag(k), floor=floor, tag=ctx)
+                                                            z(ref_g, amp_g, k).reshape(P, -1), tag(k), floor=floor, tag=ctx,
+                                                            max_fraction=RENDER_OUTLIER_FRACTION)
         return stats
 
     # the plain tolerance first, against one pass of the CPU reference; the allowances (3 threshold settings x 4 pixel
@@ -114,7 +117,7 @@ def test_fused_render_equals_two_pass(oracle32, deg, mode):
     wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
     ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
     # (the fused path computes parameter gradients only when gs_grad: pose-only backward otherwise)
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     _check_against_reference(oracle32, pc, poses, gs_grad, cam_grad, wi, wd, ws)
 
 
@@ -154,7 +157,7 @@ def test_fused_render_with_a_posed_raster_camera(oracle32):
     wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV) / (H * W)
     wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
     ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     _check_against_reference(oracle32, pc, poses, True, True, wi, wd, ws, outputs=("render", "render_dep", "sil"))
 
 
@@ -226,7 +229,7 @@ def test_randomised_fused_render_equals_two_pass(oracle32, seed):
     wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV) / (H * W)
     wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
     ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
-    oracle32.set_threads(0)
+    oracle32.set_threads(usable_cores())
     _check_against_reference(oracle32, pc, poses, gs_grad, cam_grad, wi, wd, ws, ctx=(W, H, P, deg, gs_grad, cam_grad))
 
 

@@ -48,8 +48,16 @@ Attribution = collections.namedtuple("Attribution", "outliers fragile size pos n
 # statistics tests read it (fraction of witnessed outliers, sign balance of got - want over them), and
 # dump_attribution_log() writes it out next to the profiles
 ATTRIBUTION_LOG = []
-MAX_OUTLIER_FRACTION = 1e-4   # of a tensor's elements ...
-MIN_OUTLIER_COUNT = 8         # ... but a tensor of a few hundred elements may hold this many
+# Bounds on the WITNESSED outliers of one tensor.  Same inputs on both sides (the operator-boundary rasteriser against the
+# oracle): 1e-4 of the elements -- measured 8e-7 (image) ... 1.2e-5 (gradients) at C2 / C4, 5e-5 at C1.  One flipped
+# (pixel, Gaussian) pair moves every gradient component of that Gaussian and of the ones behind it at that pixel, so
+# small tensors get a floor of 32 elements.  The end-to-end render comparisons (fused HIP glue against torch CPU glue)
+# pass RENDER_OUTLIER_FRACTION instead: the two sides compute the view-space depth with differently rounded arithmetic,
+# so list neighbours within a few ulp of depth swap places (Oracle.find_order_ties) -- ~0.6 such pairs per tile at C2,
+# each visible wherever both Gaussians overlap: 2.1e-4 of the image at C2, 3.8e-4 at C4 (profiles/r03_full_size_parity.jsonl).
+MAX_OUTLIER_FRACTION = 1e-4
+RENDER_OUTLIER_FRACTION = 1e-3
+MIN_OUTLIER_COUNT = 32
 
 
 def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.0, max_outlier=5e-2, max_fraction=None,
