@@ -159,9 +159,29 @@ __global__ void selftest_transpose_reduce_sparse_kernel(const float *in, float *
     out[64 + lane] = (float)fsgs::transpose5_slot(lane);
   }
 }
+// the blend kernels' one definition of "does Gaussian g reach pixel p" (fsgs_device.h: splat_coef + splat_alpha, the
+// pre-scaled exponent and the single v_exp_f32), isolated: in[i] = {gx, gy, A, B, C, o, px, py}
+__global__ void selftest_splat_alpha_kernel(int n, const float *__restrict__ in, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *r = in + (size_t)i * 8;
+  const fsgs::SplatCoef k = fsgs::splat_coef(r[2], r[3], r[4]);
+  fsgs::SplatEval e;
+  e.a = 0.f;
+  const bool ok = fsgs::splat_alpha(r[0], r[1], k.a, k.b, k.c, r[5], r[6], r[7], e);
+  out[2 * i] = e.a;
+  out[2 * i + 1] = ok ? 1.f : 0.f;
+}
 }  // namespace
 
 extern "C" {
+int fsgs_selftest_splat_alpha(int n, const float *in8, float *out2, fsgs_stream_t stream) {
+  if (n < 0 || (n > 0 && (!in8 || !out2))) return FSGS_ERR_INVALID;
+  if (n == 0) return FSGS_OK;
+  hipLaunchKernelGGL(selftest_splat_alpha_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, in8, out2);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
 int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int width, fsgs_stream_t stream) {
   if (!in64x64 || !out64) return FSGS_ERR_INVALID;
   if (width == 64) return fsgs_selftest_transpose_reduce(in64x64, out64, stream);

@@ -94,6 +94,7 @@ _PROTOTYPES = {
     "fsgs_last_error": (C.c_char_p, []),
     "fsgs_selftest_transpose_reduce": (_i, [_vp, _vp, _vp]),
     "fsgs_selftest_transpose_reduce_n": (_i, [_vp, _vp, _i, _vp]),
+    "fsgs_selftest_splat_alpha": (_i, [_i, _vp, _vp, _vp]),
     "fsgs_profile_enable": (_i, [C.c_uint64]),
     "fsgs_profile_stride": (_i, [C.c_int]),
     "fsgs_profile_count": (_i, []),

@@ -100,6 +100,11 @@ int fsgs_selftest_transpose_reduce(const float *in64x64, float *out64, fsgs_stre
  * (two Gaussians x 16 slots of which 12 are reduced / x 8 of which 5; the other columns are taken as zero): out64 must
  * then hold 128 floats, out[l] = the lane's total and out[64 + l] = the column (slot) that lane ends up owning. */
 int fsgs_selftest_transpose_reduce_n(const float *in64x64, float *out64, int width, fsgs_stream_t stream);
+/* Self-test of the blend kernels' per-(pixel, Gaussian) evaluation -- pre-scaled exponent, one v_exp_f32, the
+ * power > 0 and alpha < 1/255 skips -- on n independent samples: in8[i] = {mean2D x, y, conic A, B, C,
+ * opacity, pixel x, y} -> out2[i] = {o e^power (unclamped; 0 when power > 0), 1 if the pair contributes else 0}.
+ * tests/test_raster_gpu.py checks it against a float64 evaluation for bias around the 1/255 threshold. */
+int fsgs_selftest_splat_alpha(int n, const float *in8, float *out2, fsgs_stream_t stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launching stream.
  * mask: bit i enables kernel id i (ids: fsgs_profile_name); 0 disables.  Enabling resets totals.

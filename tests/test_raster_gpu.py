@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from fsgs_amd import synth
-from tests.util import ATTRIBUTION_LOG, assert_close_attributed, c1_poses, sh0_colors, sign_balance, to_camera_frame
+from tests.util import (ATTRIBUTION_LOG, assert_close_attributed, assert_sign_balanced, c1_poses, sh0_colors, sign_balance,
+                        to_camera_frame)
 
 from oracle.fsgs_oracle import usable_cores
 
@@ -186,7 +187,7 @@ def test_final_T_and_last_contributor_match_oracle_by_id(oracle32, scene):
     pos, neg, z = sign_balance([res._asdict()])
     print("final_T %s: %d witnessed outliers of %d pixels (%d above, %d below the oracle, z = %.2f); last contributor "
           "differs at %d pixels" % (scene, res.outliers, res.size, pos, neg, z, int((mine != ref).sum())))
-    assert abs(z) <= 4.0, (scene, pos, neg, z)
+    assert_sign_balanced([res._asdict()], "final_T " + scene)
 
 
 def test_edge_cases_empty_ragged_and_culled(oracle32):
@@ -348,6 +349,72 @@ def test_wave_transposing_reduction_selftest():
             assert np.array_equal(slot[:32], slot[32:]) and np.allclose(tot[:32][live[:32]], tot[32:][live[32:]])
 
 
+def test_alpha_evaluation_is_unbiased_around_the_skip_threshold():
+    """VERDICT r2 weak #3, asked directly: does the blend kernels' alpha -- the exponent pre-scaled by log2(e) and ONE
+    v_exp_f32 instead of expf (fsgs_device.h: splat_coef / splat_alpha) -- resolve near-ties against 1/255 one way?
+    2 M samples whose true alpha (float64) lies within +-2e-3 relative of the threshold, on footprints from round to
+    needle-shaped: the relative error of HIP's alpha stays inside an fp32 evaluation's budget and its MEAN is a small
+    fraction of that budget (no systematic sign),
+    every decision that differs from the float64 one sits within the oracle's flip margin of the threshold
+    (Oracle.FLIP_MARGINS: 4e-4 + 5e-7 x the exponent's cancelling terms), and the differing decisions split evenly
+    between 'blended although below' and 'skipped although above'."""
+    from fsgs_amd import _lib
+    from oracle.fsgs_oracle import Oracle
+
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    # conic of a footprint with sigmas s1 >= s2 (pixels) rotated by th; offset d at a random direction
+    s1 = rng.uniform(0.6, 30.0, n)
+    s2 = s1 * rng.uniform(0.03, 1.0, n)
+    s2 = np.maximum(s2, 0.55)
+    th = rng.uniform(0, np.pi, n)
+    c, s_ = np.cos(th), np.sin(th)
+    ia, ib = 1.0 / (s1 * s1), 1.0 / (s2 * s2)
+    A = c * c * ia + s_ * s_ * ib
+    B = c * s_ * (ia - ib)
+    Cc = s_ * s_ * ia + c * c * ib
+    o = rng.uniform(0.01, 1.0, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    ux, uy = np.cos(phi), np.sin(phi)
+    q1 = 0.5 * (A * ux * ux + Cc * uy * uy) + B * ux * uy          # power = -q1 r^2
+    target = (1.0 / 255.0) * (1.0 + rng.uniform(-2e-3, 2e-3, n))    # the alpha to land on
+    r = np.sqrt(np.maximum(np.log(o / target), 0.0) / q1)
+    px = np.floor(rng.uniform(0, 1900, n))
+    py = np.floor(rng.uniform(0, 1000, n))
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    rec = np.stack([f32(px + r * ux), f32(py + r * uy), f32(A), f32(B), f32(Cc), f32(o), f32(px), f32(py)], 1)
+    # truth on the ROUNDED inputs, in float64
+    R = rec.astype(np.float64)
+    dx, dy = R[:, 0] - R[:, 6], R[:, 1] - R[:, 7]
+    t1, t2, t3 = 0.5 * R[:, 2] * dx * dx, 0.5 * R[:, 4] * dy * dy, R[:, 3] * dx * dy
+    power = -(t1 + t2) - t3
+    alpha = R[:, 5] * np.exp(power)
+    use = (power < -1e-3) & (np.abs(alpha * 255.0 - 1.0) < 5e-3)
+    assert use.mean() > 0.8
+    d_in, d_out = torch.tensor(rec, device=DEV), torch.zeros((n, 2), device=DEV)
+    _lib.check(lib.fsgs_selftest_splat_alpha(n, _lib.ptr(d_in), _lib.ptr(d_out), _lib.current_stream()), "selftest")
+    out = d_out.cpu().numpy().astype(np.float64)
+    rel = (out[use, 0] - alpha[use]) / alpha[use]
+    cond = (np.abs(t1) + np.abs(t2) + np.abs(t3))[use]
+    # error budget of any fp32 evaluation: ~1 ulp from the multiply + the exponent's rounding x its condition
+    budget = 3e-7 + 5e-7 * cond
+    assert np.all(np.abs(rel) <= budget), float(np.max(np.abs(rel) / budget))
+    mean_bias = float(np.mean(rel / budget))
+    assert abs(mean_bias) <= 0.1, mean_bias            # no systematic sign: <= 10 % of the per-sample budget
+    hip = out[use, 1] > 0.5
+    want = alpha[use] >= 1.0 / 255.0
+    differ = hip != want
+    m = Oracle.FLIP_MARGINS
+    margin = m["alpha_min"] + m["alpha_cond"] * cond
+    assert np.all(np.abs(alpha[use] * 255.0 - 1.0)[differ] <= margin[differ]), "a decision flipped outside the flip margin"
+    more, less = int((hip & ~want).sum()), int((~hip & want).sum())
+    print("alpha near 1/255: %d samples, %d decisions differ from float64 (%d blended although below, %d skipped although "
+          "above); mean normalised error %.4f" % (int(use.sum()), int(differ.sum()), more, less, mean_bias))
+    if more + less >= 50:
+        assert 0.3 <= more / (more + less) <= 0.7, (more, less)
+
+
 def test_heavy_tile_takes_the_global_memory_sort_path(oracle32):
     """> 2048 Gaussians in one tile (LDS sort capacity) -> in-place global-memory bitonic fallback; duplicate
     depths included so the (depth, index) tie order is exercised."""
@@ -455,11 +522,10 @@ def test_witnessed_outliers_of_c1_and_the_sweep_are_few_and_unsigned():
                                                     pos=sum(r["pos"] for r in rs), neg=sum(r["neg"] for r in rs))
             if group == "c1":  # full-size tensors: the fraction itself (the sweep's tiny tensors are bounded per call)
                 assert out <= MAX_OUTLIER_FRACTION * size, (group, what, out, size)
-    pos, neg, z = sign_balance(recs)
-    summary["sign_balance"] = dict(pos=pos, neg=neg, z=z)
+    pos, neg, z, share = assert_sign_balanced(recs, "C1 poses + 40-seed sweep")
+    summary["sign_balance"] = dict(pos=pos, neg=neg, z=z, positive_share=share)
     print(summary)
     dump_attribution_log("r03_outlier_statistics", summary)
-    assert abs(z) <= 4.0, (pos, neg, z)
 
 
 def test_unsupported_channel_count_is_an_error_not_a_wrong_image():
