@@ -229,11 +229,15 @@ struct SplatCoef {
   float a, b, c;
 };
 __device__ __forceinline__ SplatCoef splat_coef(float A, float B, float Cc) {
-  const float L2E = 1.44269504088896340736f;
+  // log2(e) in DOUBLE, the product rounded once: the fp32 constant alone is 1.3e-8 (relative) short, which makes every
+  // exponent that much smaller and alpha = o 2^p about |power| x 1.3e-8 ~ 4e-8 too large -- a bias, not noise (measured
+  // with fsgs_selftest_splat_alpha around the 1/255 threshold: of 122 decisions that differed from float64, 85 said
+  // "blend").  Staged once per (tile, Gaussian) record, not per pixel: three f64 multiplies per 64 pairs.
+  const double L2E = 1.44269504088896340736;
   SplatCoef k;
-  k.a = __fmul_rn(-0.5f * L2E, A);
-  k.b = __fmul_rn(-L2E, B);
-  k.c = __fmul_rn(-0.5f * L2E, Cc);
+  k.a = (float)(-0.5 * L2E * (double)A);
+  k.b = (float)(-L2E * (double)B);
+  k.c = (float)(-0.5 * L2E * (double)Cc);
   return k;
 }
 struct SplatEval {

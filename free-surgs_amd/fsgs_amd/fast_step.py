@@ -149,7 +149,7 @@ class FastStepper:
             self._cfgt, self._cfgt_of = z, base
         return self._cfgt
 
-    def _render_forward(self, w2c, b, tracking=False):
+    def _render_forward(self, w2c, b, tracking=False, allow_reuse=True):
         pc, lib = self.pc, self.lib
         p = pc.params
         for name in PARAM_NAMES:  # raw pointers go to the kernels: no silent reinterpretation of other layouts
@@ -172,7 +172,7 @@ class FastStepper:
             (id(p[n]), p[n]._version) for n in PARAM_NAMES)
         # (the tensors themselves are part of the entry: ids alone can be recycled by the allocator)
         owners = tuple(p[n] for n in PARAM_NAMES) + (self.poses.cam_center,)
-        prev = self.__dict__.get("_color_src") if getattr(self, "reuse_colors", True) else None
+        prev = self.__dict__.get("_color_src") if (allow_reuse and getattr(self, "reuse_colors", True)) else None
         if prev is not None and (prev[0] != ckey or len(prev[4]) != len(owners) or any(a is not b for a, b in zip(prev[4], owners))):
             prev = None
         for _attempt in range(3):
@@ -330,12 +330,10 @@ class FastStepper:
         return t, total, keep
 
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
-    def _view_forward_and_losses(self, b, ts, corners, dev, H, W, n_patches, view):
-        """Front half of one view's pipeline on the CURRENT stream (+ the view's side stream): render forward, L1+SSIM
-        forward / backward, patch draws + Pearson forward / backward.  Leaves dL/dimage in b.d_image, dL/ddepth in
-        b.d_depth_sil[0], the loss terms in b.terms.  -> (args, state, sbytes, cap, nr, event behind the forward)"""
-        lib = self.lib
-        stream = _lib.current_stream()
+    def _view_forward(self, b, ts, corners, dev, H, W, view, allow_reuse=True):
+        """First part of one view's pipeline on the CURRENT stream (+ the view's side stream): patch draws and the clear
+        of the backward's accumulators on the side stream, then the render forward (returns when the pair count has
+        arrived, i.e. as the forward blend starts).  -> context for _view_losses / the backward"""
         w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
                else self.poses.get_pose(ts).detach().contiguous())
         # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound) are independent
@@ -351,16 +349,25 @@ class FastStepper:
         with torch.cuda.stream(side):
             cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
             b.bwd_scratch.zero_()
-        args, state, sbytes, cap, nr = self._render_forward(w2c, b)
-        gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
+        args, state, sbytes, cap, nr = self._render_forward(w2c, b, allow_reuse=allow_reuse)
         fwd_done = torch.cuda.Event()
         fwd_done.record()
+        return {"args": args, "state": state, "sbytes": sbytes, "cap": cap, "nr": nr, "fwd_done": fwd_done, "cr": cr,
+                "side": side, "ts": ts}
+
+    def _view_losses(self, b, ctx, H, W, n_patches):
+        """Second part, same streams: L1+SSIM forward / backward on the current stream, Pearson forward / backward on
+        the side stream.  Leaves dL/dimage in b.d_image, dL/ddepth in b.d_depth_sil[0], the loss terms in b.terms."""
+        lib = self.lib
+        stream = _lib.current_stream()
+        ts, cr, side = ctx["ts"], ctx["cr"], ctx["side"]
+        gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
         # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
         _lib.check(lib.fsgs_photometric_loss_forward_backward(
             3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
             _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
             "fsgs_photometric_loss_forward_backward")
-        side.wait_event(fwd_done)
+        side.wait_event(ctx["fwd_done"])
         with torch.cuda.stream(side):
             sstream = _lib.current_stream()
             dep = b.depth_sil[0]
@@ -375,7 +382,14 @@ class FastStepper:
             for t_ in cr:  # drawn on the side stream, last used there
                 t_.record_stream(side)
         torch.cuda.current_stream().wait_event(side_done)
-        return args, state, sbytes, cap, nr, fwd_done
+
+    def _view_forward_and_losses(self, b, ts, corners, dev, H, W, n_patches, view):
+        """Front half of one view's pipeline on the CURRENT stream (+ the view's side stream): render forward, L1+SSIM
+        forward / backward, patch draws + Pearson forward / backward.  -> (args, state, sbytes, cap, nr, event behind
+        the forward)"""
+        ctx = self._view_forward(b, ts, corners, dev, H, W, view)
+        self._view_losses(b, ctx, H, W, n_patches)
+        return ctx["args"], ctx["state"], ctx["sbytes"], ctx["cap"], ctx["nr"], ctx["fwd_done"]
 
     def mapping_step(self, timesteps, step_optimizer=True, grad_sync=None, corners=None, reduce_compact=None,
                      collect_stats=True):
@@ -472,22 +486,34 @@ class FastStepper:
         P = pc.num_points
         main = torch.cuda.current_stream()
         overlap = getattr(self, "overlap_views", True) and len(timesteps) > 1
-        views, joins, totals = [], [], []
-        fwd0 = None
+        views, joins, totals, ctxs, streams = [], [], [], [], []
+        # Overlapped: ALL forwards are enqueued first, every view on its own stream, then every view's losses + backward.
+        # A forward call returns when its pair count has arrived (its binning is done and its blend enqueued), so the
+        # host hands view 1's binning over while view 0's forward blend runs, and view 0's loss kernels while view 1's
+        # does: no stream waits for the ~0.2 ms of host work a view's calls take.  View k >= 1 evaluates its own
+        # per-Gaussian colours (copying view 0's would make its first kernel wait for view 0's whole forward).
+        # Serial (overlap_views = False): one view after the other on the current stream, colours reused.
+        step_begun = None
+        if overlap:
+            step_begun = torch.cuda.Event()
+            step_begun.record(main)  # the parameters are final behind the previous Adam
         for k, ts in enumerate(timesteps):
             b = self._buffers(P, H, W, n_patches, dev, view=k)
-            first = k == 0
-            vstream = main if (first or not overlap) else self._view_stream(dev, k)
+            vstream = main if (k == 0 or not overlap) else self._view_stream(dev, k)
             if vstream is not main:
-                # the parameters are final behind the previous Adam, and this view copies its per-Gaussian colours from
-                # view 0's forward state: both lie in front of `fwd0` on the main stream
-                vstream.wait_event(fwd0)
+                vstream.wait_event(step_begun)
+            views.append(b)
+            streams.append(vstream)
+            if overlap:
+                with torch.cuda.stream(vstream):
+                    ctxs.append(self._view_forward(b, ts, corners, dev, H, W, k, allow_reuse=(k == 0)))
+        for k, ts in enumerate(timesteps):
+            b, vstream, first = views[k], streams[k], k == 0
             with torch.cuda.stream(vstream):
                 stream = _lib.current_stream()
-                args, state, sbytes, cap, nr, fwd_done = self._view_forward_and_losses(b, ts, corners, dev, H, W,
-                                                                                      n_patches, k)
-                if first:
-                    fwd0 = fwd_done
+                ctx = ctxs[k] if overlap else self._view_forward(b, ts, corners, dev, H, W, k)
+                self._view_losses(b, ctx, H, W, n_patches)
+                args, state, sbytes, cap, nr = ctx["args"], ctx["state"], ctx["sbytes"], ctx["cap"], ctx["nr"]
                 if b.gc is None:
                     b.gc = torch.empty((P, 14), dtype=torch.float32, device=dev)
                 # the densification statistic comes from view 0 only (train.py:260-263); the other views of the step raise
@@ -517,7 +543,6 @@ class FastStepper:
                     done = torch.cuda.Event()
                     done.record()
                     joins.append(done)
-            views.append(b)
             totals.append(loss_k)
         for e in joins:
             main.wait_event(e)
