@@ -47,7 +47,7 @@ def valu_frac(wave_insts, kernel_seconds):
     return (wave_insts / VALU_SIMDS) * VALU_CYCLES_PER_WAVE_INST / VALU_CLOCK_HZ / kernel_seconds
 
 
-def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default"):
+def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default", texture=0.0):
     from fsgs_amd import synth
     from fsgs_amd.model import GaussianCloud
     from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
@@ -75,6 +75,15 @@ def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default"):
     # per-frame targets resident in HBM: a colour image and a mono-depth map
     img = torch.tensor(sc["image"], device=device)
     dep = torch.tensor(sc["depth_map"], device=device)
+    if texture > 0.0:
+        # Detail the cloud does not have yet, in a third of the image (a fine oblique grating): what an under-reconstructed
+        # region looks like to the optimiser -- view-space gradients there cross the reference's densification threshold
+        # (2e-4, train.py:307) and the cloud GROWS by clone / split instead of only being pruned (--densify-every)
+        v, u = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                              torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+        region = ((u > 0.15 * W) & (u < 0.65 * W) & (v > 0.2 * H) & (v < 0.85 * H)).float()
+        grating = torch.sin(2 * np.pi * (u + 0.5 * v) / 9.0) * torch.cos(2 * np.pi * (v - 0.3 * u) / 13.0)
+        img = (img + texture * region * grating.unsqueeze(0) * torch.tensor([1.0, -0.7, 0.5], device=device).reshape(3, 1, 1)).clamp(0, 1)
     frames = FrameData([img + 0.01 * i for i in range(n_frames)], [dep * (1 + 0.01 * i) for i in range(n_frames)])
     return pc, poses, frames, cam, sc
 
@@ -269,7 +278,10 @@ def main():
     np.random.seed(0)
     _lib.load()
 
-    pc, poses, frames, cam, sc = build_problem(args.config, device, rank, world, scene=args.scene)
+    # with densification inside the timed loop the targets carry detail the cloud lacks (build_problem: texture), so that
+    # part of the cloud crosses the reference's 2e-4 threshold and clone / split outgrow the opacity prune
+    texture = 0.15 if args.densify_every else 0.0
+    pc, poses, frames, cam, sc = build_problem(args.config, device, rank, world, scene=args.scene, texture=texture)
     W, H, P, _ = CONFIGS[args.config]
     fused = not args.two_pass
     hip_losses = not args.torch_losses
@@ -636,6 +648,7 @@ def main():
                 args.config, W, H, P, CONFIGS[args.config][3]),
                 "num_rendered": R, "upstream_num_rendered": upstream_main,
                 "scene": args.scene, "densify_every": args.densify_every or None, "gaussians_at_end": pc.num_points,
+                "target_texture": texture or None,
                 "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"

@@ -23,6 +23,15 @@ FLAGS = [
 DIAG = os.environ.get("FSGS_DIAG") == "1"
 if DIAG:
     FLAGS.append("-DFSGS_DIAG_HOOKS")
+# A/B experiments on one GPU box: FSGS_CFLAGS="-DFOO=1" FSGS_LIB_TAG=foo builds lib/libfsgs_hip.foo.so from objects of
+# its own (the product library is untouched); FSGS_LIB_PATH=<that file> makes fsgs_amd._lib load it.
+EXTRA = os.environ.get("FSGS_CFLAGS", "").split()
+TAG = os.environ.get("FSGS_LIB_TAG", "")
+if EXTRA and not TAG:
+    raise SystemExit("FSGS_CFLAGS needs FSGS_LIB_TAG (the product library is only ever built with the default flags)")
+FLAGS += EXTRA
+if TAG:
+    LIB = os.path.join(OUT_DIR, "libfsgs_hip.%s.so" % TAG)
 
 
 def sources():
@@ -44,7 +53,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", ".diag.o" if DIAG else ".o"))
+    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", (".%s.o" % TAG) if TAG else (".diag.o" if DIAG else ".o")))
     if _stale(obj, [src] + headers()):
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

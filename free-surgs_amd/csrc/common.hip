@@ -168,7 +168,7 @@ __global__ void selftest_splat_alpha_kernel(int n, const float *__restrict__ in,
   const fsgs::SplatCoef k = fsgs::splat_coef(r[2], r[3], r[4]);
   fsgs::SplatEval e;
   e.a = 0.f;
-  const bool ok = fsgs::splat_alpha(r[0], r[1], k.a, k.b, k.c, r[5], r[6], r[7], e);
+  const bool ok = fsgs::splat_alpha(__fsub_rn(r[0], r[6]), __fsub_rn(r[1], r[7]), k.a, k.b, k.c, r[5], e);
   out[2 * i] = e.a;
   out[2 * i + 1] = ok ? 1.f : 0.f;
 }

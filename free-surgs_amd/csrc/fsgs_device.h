@@ -250,10 +250,19 @@ __device__ __forceinline__ float splat_exponent(float ca, float cb, float cc, fl
   const float q = __fmul_rn(__fmaf_rn(cb, dy, __fmul_rn(ca, dx)), dx);
   return __fmaf_rn(__fmul_rn(cc, dy), dy, q);
 }
-__device__ __forceinline__ bool splat_alpha(float gx, float gy, float ca, float cb, float cc, float o, float px,
-                                            float py, SplatEval &e) {
-  e.dx = __fsub_rn(gx, px);
-  e.dy = __fsub_rn(gy, py);
+// The offset d = mean2D - pixel of the lane's pixel in quadrant k, from the offset to the lane's FIRST pixel (quadrant
+// 0): the four pixels of a lane sit 8 apart, so d_k = d_0 - (8 (k & 1), 8 (k >> 1)).  d_0 is formed once per pair; a
+// lane then keeps ONE pixel position instead of four (six registers, which is what stood between the mapping
+// backward and five waves per SIMD), and the quadrants on the left / top need no subtraction at all.  Forward and
+// backward both come through here, so their skip decisions stay bit-identical.  (mean2D - integer is exact in fp32
+// whenever the result is not larger than the mean itself, i.e. for every pair a 16x16 tile can see except
+// screen-filling footprints, where the second rounding is 1e-7 of the footprint's size.)
+__device__ __forceinline__ float quad_offset(float d0, bool second) {
+  return second ? __fsub_rn(d0, (float)FSGS_QUAD) : d0;
+}
+__device__ __forceinline__ bool splat_alpha(float dx, float dy, float ca, float cb, float cc, float o, SplatEval &e) {
+  e.dx = dx;
+  e.dy = dy;
   const float p = splat_exponent(ca, cb, cc, e.dx, e.dy);
   if (p > 0.0f) return false;
   e.a = __fmul_rn(o, __builtin_amdgcn_exp2f(p));
@@ -265,10 +274,10 @@ __device__ __forceinline__ bool splat_alpha(float gx, float gy, float ca, float 
 // (power > 0, alpha < 1/255 or `live` false).  The skip decision is bit-identical to splat_alpha; with
 // alpha = a = 0 every gradient term of the pair vanishes and T / gB stay untouched, so no divergent branch is
 // needed around the arithmetic (one v_cndmask: alpha = min(0.99, a) follows from the masked a).
-__device__ __forceinline__ bool splat_alpha_masked(float gx, float gy, float ca, float cb, float cc, float o, float px,
-                                                   float py, bool live, SplatEval &e) {
-  e.dx = __fsub_rn(gx, px);
-  e.dy = __fsub_rn(gy, py);
+__device__ __forceinline__ bool splat_alpha_masked(float dx, float dy, float ca, float cb, float cc, float o, bool live,
+                                                   SplatEval &e) {
+  e.dx = dx;
+  e.dy = dy;
   const float p = splat_exponent(ca, cb, cc, e.dx, e.dy);
   // (p > 0 is masked below: whatever 2^p is there -- even +inf -- only reaches the unselected side of the select)
   const float a = __fmul_rn(o, __builtin_amdgcn_exp2f(p));

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   const int tile = (int)tile_u;
   const int W = cam.W, H = cam.H;
   const TilePix tp = tile_pixels(tile, cam.gx, lane);
-  float px[4], py[4];
+  const float px0 = (float)tp.x[0], py0 = (float)tp.y[0];  // the lane's pixel in quadrant 0 (the others: + 8, quad_offset)
   // T[k] > 0: transmittance of a pixel that is still blending; a FINISHED pixel (T (1 - alpha) < 1e-4 seen, or outside
   // the image) keeps its transmittance with the sign flipped -- the "done" flag costs no register and one compare
   // (86 -> 80 VGPRs: six waves per SIMD; one VALU less per quadrant body)
@@ -697,8 +697,6 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    px[k] = (float)tp.x[k];
-    py[k] = (float)tp.y[k];
     T[k] = (tp.x[k] < W && tp.y[k] < H) ? 1.0f : -1.0f;
     D[k] = 0.0f;
     last[k] = 0;
@@ -749,12 +747,13 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
       const float bcol8[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
+      const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (!((bm >> k) & 1u)) continue;  // wave-uniform
         if (!(T[k] > 0.f)) continue;  // finished
         SplatEval e;
-        if (!splat_alpha(bx, by, bA, bB, bC, bo, px[k], py[k], e)) continue;
+        if (!splat_alpha(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, e)) continue;
         float test_T = T[k] * (1.0f - e.alpha);
         if (test_T < 0.0001f) {
           T[k] = -T[k];
@@ -834,7 +833,10 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // ROW: floats per accumulator row when moments and colour sums share one row per Gaussian (kFusedRow, the fused
 // render); 0 = the operator boundary's layout (moments [P,8] in scratch, colour sums straight into dcolors [P,C]).
 template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
-__global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_bwd_kernel(
+#ifndef FSGS_BWD_WAVES
+#define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
+#endif
+__global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? FSGS_BWD_WAVES : 4)) void blend_bwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
@@ -866,12 +868,11 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_b
   //   gc = sum_ch g_ch c_ch;  dL/dalpha = T gc - (gB + T_final bg.g) / (1 - alpha);  gB += alpha T gc.
   // gB[k] starts at T_final * (bg . dL/dpixel), so the sum in the bracket is one register; gBr: the same restricted
   // to the RGB channels (SPLIT).
-  float px[4], py[4], T[4], gB[4], gBr[4], g[4][CG];
+  const float px0 = (float)tp.x[0], py0 = (float)tp.y[0];  // the lane's pixel in quadrant 0 (the others: + 8, quad_offset)
+  float T[4], gB[4], gBr[4], g[4][CG];
   int last[4], qlast[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    px[k] = (float)tp.x[k];
-    py[k] = (float)tp.y[k];
     bool inside = tp.x[k] < W && tp.y[k] < H;
     size_t pix = inside ? (size_t)tp.y[k] * W + tp.x[k] : 0;
     const float Tfin = inside ? final_T[pix] : 0.0f;
@@ -958,11 +959,12 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : 4) void blend_b
         const float bcol[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
         float *s = &v[SL * u];
         bool any = false;
+        const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (!((bm >> k) & 1u)) continue;  // wave-uniform
           SplatEval e;  // alpha = G = 0 for lanes that do not contribute: the arithmetic below is a no-op for them
-          any |= splat_alpha_masked(bx, by, bA, bB, bC, bo, px[k], py[k], pos < last[k], e);
+          any |= splat_alpha_masked(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, pos < last[k], e);
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
           T[k] = T[k] * inv1ma;
           const float wgt = e.alpha * T[k];

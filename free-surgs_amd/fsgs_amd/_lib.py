@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfsgs_hip.so")
+# FSGS_LIB_PATH: an experiment build (free-surgs_amd/build.py, FSGS_LIB_TAG) instead of the product library -- A/B runs only
+LIB_PATH = os.environ.get("FSGS_LIB_PATH") or os.path.join(_HERE, "lib", "libfsgs_hip.so")
 
 FSGS_OK = 0
 FSGS_ERR_INVALID = -1

@@ -11,6 +11,8 @@ cp gpurun_out/pmc_WRITE_SIZE_summary.csv profiles/${tag}_pmc_WRITE_SIZE_summary.
 cp gpurun_out/sq_summary.txt profiles/${tag}_sq_counters.txt
 cp gpurun_out/trace_step.txt profiles/${tag}_step_timeline.txt
 cp gpurun_out/trace_tracking.txt profiles/${tag}_tracking_timeline.txt
+[ -f gpurun_out/trace_two_view.txt ] && cp gpurun_out/trace_two_view.txt profiles/${tag}_two_view_timeline.txt
+for n in full_size_parity outlier_statistics; do [ -f gpurun_out/${tag}_$n.jsonl ] && cp gpurun_out/${tag}_$n.jsonl profiles/${tag}_$n.jsonl; done
 R=$(python -c "import json; print(json.load(open('gpurun_out/bench.json'))['config']['num_rendered'])")
 python scripts/make_pmc_json.py $tag $R 300000 1280 1024 | grep blend
 grep -o '"avg_kernel_ms": [0-9.]*' gpurun_out/rocprof.log | head -1

@@ -19,4 +19,5 @@ bash scripts/gpu_pmc.sh > gpurun_out/pmc.log 2>&1
 bash scripts/gpu_sq.sh > gpurun_out/sq.log2 2>&1
 bash scripts/gpu_trace.sh > /dev/null 2>&1
 bash scripts/gpu_trace_tracking.sh > /dev/null 2>&1
+bash scripts/gpu_trace_two_view.sh > /dev/null 2>&1
 ls -la gpurun_out | tail -30

@@ -169,6 +169,34 @@ def test_two_view_step_overlapped_on_two_streams_equals_the_serial_step():
     assert float(ref.variables["max_radii2D"].max()) > 0
 
 
+def test_colour_reuse_check_switch_catches_a_write_without_a_version_bump(monkeypatch):
+    """The per-Gaussian colours are copied from the previous forward's state while the parameters' version counters and
+    the camera centre stand still (fast_step._render_forward).  FSGS_CHECK_REUSE=1 re-evaluates them: silent through
+    legitimate sequences (tracking iterations, a mapping step in between), loud when a parameter is written behind the
+    counters' back (`.data` writes do not bump them) -- and a bumped write simply ends the reuse."""
+    from fsgs_amd.flow import FlowTargets
+
+    monkeypatch.setenv("FSGS_CHECK_REUSE", "1")
+    pc, poses, frames, cam = _world()
+    H, W = 256, 320
+    fs = FastStepper(pc, poses, frames)
+    poses.initialize_tracking_optimizer(50)
+    tg = FlowTargets(frames.monodeps[0].reshape(1, H, W), np.eye(4, dtype=np.float32), cam["K"], frames.flows_fw[0], None)
+    for _ in range(3):
+        fs.tracking_step(1, tg, None)
+    fs.mapping_step([1, 2])
+    for _ in range(2):
+        fs.tracking_step(2, tg, None)
+    torch.cuda.synchronize()
+    pc.params["_features_dc"].data.add_(0.25)  # no version bump: the next forward would render stale colours
+    with pytest.raises(RuntimeError, match="FSGS_CHECK_REUSE"):
+        fs.tracking_step(2, tg, None)
+    with torch.no_grad():
+        pc.params["_features_dc"].add_(0.0)      # a counted write: the reuse ends, the colours are evaluated afresh
+    fs.tracking_step(2, tg, None)
+    torch.cuda.synchronize()
+
+
 def test_full_size_c2_gradient_routes_agree():
     """BASELINE.json's C2 (1280x1024, 300 000 Gaussians): the three gradient routes of the step driver -- Adam inside the
     backward, the compact [P,14] gradient, full gradients + multi-tensor Adam -- must produce the same update at full
