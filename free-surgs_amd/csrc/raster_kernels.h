@@ -259,7 +259,11 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
           seg[u] = (uint32_t)bin_slot(ty * gx + tx, (int)klo[u]);
+#ifdef FSGS_EXP_SCATTER_NO_ATOMICS  // experiment builds only: the scatter's floor without its slot claims (results are garbage)
+          slot[u] = (item * 2654435761u) % cap_sub;
+#else
           slot[u] = atomicAdd(&cursors[seg[u]], 1u);
+#endif
         }
       }
     }
@@ -1009,6 +1013,10 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         const uint32_t gu = readlane(gid, max(jj - u, 0));
         gsel = my_u == u ? gu : gsel;
       }
+#ifdef FSGS_EXP_NO_ATOMICS  // experiment builds only (free-surgs_amd/build.py FSGS_CFLAGS): what do the accumulator atomics cost?
+      if (j_mine >= 0 && c_used && tot == 1.2345e33f) grad_acc[0] = tot;  // keeps the reduction alive, never stores
+      if (true) continue;
+#endif
       if (j_mine >= 0 && c_used && tot != 0.f) {
         if constexpr (ROW != 0) {
           // one row per Gaussian holds moments AND colour sums (dcolors = grad_acc + 8, stride ROW: launch_blend_bwd checks
