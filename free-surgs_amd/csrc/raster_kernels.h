@@ -269,7 +269,11 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
     }
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++)
+#ifdef FSGS_EXP_SCATTER_NO_STORE  // experiment builds only: what do the scattered 8-byte key stores cost? (results are garbage)
+      if (hit[u] && slot[u] == 0xFFFFFFF0u)
+#else
       if (hit[u] && slot[u] < cap_sub)  // an overflowing segment keeps counting (the sort kernel reports it)
+#endif
         keys[(size_t)seg[u] * cap_sub + slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
   }
 }
