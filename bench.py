@@ -179,8 +179,10 @@ def rccl_diagnostics_env():
     `comm.rccl_info`, so that a poor scaling point can be attributed.  Init-time subsystems only: nothing
     is logged per collective, the timed loop is not touched.  FSGS_RCCL_TUNING_LOG=1 adds the TUNING subsystem (the
     algorithm / protocol chosen per call -- one log line per collective, a diagnostic run, not a measurement).
-    Variables the user already set win."""
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    NCCL_DEBUG is raised to INFO unless it already asks for more than VERSION / WARN; the other variables only get
+    defaults."""
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN"):  # (the image presets VERSION)
+        os.environ["NCCL_DEBUG"] = "INFO"
     subsys = "INIT,GRAPH,ENV" + (",TUNING" if os.environ.get("FSGS_RCCL_TUNING_LOG") == "1" else "")
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", subsys)
     os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fsgs_rccl.%h.%p.log")
