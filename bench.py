@@ -198,13 +198,16 @@ def rccl_info_lines(limit=40):
         return None
     files = glob.glob(pat.replace("%h", "*").replace("%p", str(os.getpid())))
     keep = re.compile(r"(RCCL version|NCCL version|nRanks|Channel \d+/\d+\s*:|Ring \d+|Trees|channels|via P2P|via SHM|via NET|"
-                      r"xGMI|XGMI|Algo|[Pp]rotocol|proto |threshold|NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set|Connected all)")
+                      r"xGMI|XGMI|Algo|[Pp]rotocol|proto |threshold|NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set|Connected all|Dmabuf|Using network|"
+                      r"NCCL WARN)")
     out = []
     for f in files:
         try:
             for line in open(f, errors="replace"):
                 if keep.search(line):
-                    out.append(re.sub(r"^\S+:\d+:\d+ \[\d+\] ", "", line.strip())[:200])
+                    # drop the "[time] host:pid:tid [dev]" prefix and the build path RCCL prints in front of its warnings
+                    l = re.sub(r"^(\[[^\]]*\] )?\S+:\d+:\d+ \[\d+\] ", "", line.strip())
+                    out.append(re.sub(r"/\S*/src/", "src/", l)[:200])
         except OSError:
             pass
     seen, uniq = set(), []
