@@ -74,6 +74,10 @@ typedef struct {
   real *depth;           /* [P]   view-space z                         */
   real *cov3D;           /* [P,6] upper triangle of Sigma              */
   real *tvec;            /* [P,3] view-space mean                      */
+  real *kappa;           /* [P] a c / det of the dilated 2D covariance: how far det = a c - b^2 cancels.  The conic =
+                            (c, -b, a) / det of a needle-shaped footprint carries ~6 kappa eps of relative error in ANY
+                            fp32 evaluation (found by the 3000-seed soak: kappa = 3e3 -> the conic of the oracle's fp32
+                            build and of the HIP path 1.1e-3 / 0.8e-3 off the fp64 value, to opposite sides) */
   int *radii;            /* [P]                                        */
   int *tiles;            /* [P]   tiles_touched                        */
   int *rect;             /* [P,4] minx,miny,maxx,maxy                  */
@@ -150,15 +154,17 @@ typedef struct {
   double alpha_cond;    /* 0: alpha_min is additionally scaled by (1 - alpha_cond * sum |terms of the exponent|): the
                            exponent's three products cancel on elongated footprints and carry rounding in proportion
                            to their magnitudes, not to their sum */
+  double alpha_kappa;   /* 0: the alpha_cond term is additionally multiplied by (1 + alpha_kappa * kappa_g): the conic
+                           itself is only good to ~6 kappa eps (OracleState.kappa), and the exponent inherits that */
 } OracleThresholds;
-static OracleThresholds g_thr = {1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0};
+static OracleThresholds g_thr = {1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0, 0.0};
 void oracle_set_thresholds(double alpha_min, double alpha_max, double T_min, double power_max, double radius_scale,
-                           double near_plane, double rect_shift, double alpha_cond) {
+                           double near_plane, double rect_shift, double alpha_cond, double alpha_kappa) {
   g_thr.alpha_min = alpha_min; g_thr.alpha_max = alpha_max; g_thr.T_min = T_min; g_thr.power_max = power_max;
   g_thr.radius_scale = radius_scale; g_thr.near_plane = near_plane; g_thr.rect_shift = rect_shift;
-  g_thr.alpha_cond = alpha_cond;
+  g_thr.alpha_cond = alpha_cond; g_thr.alpha_kappa = alpha_kappa;
 }
-void oracle_reset_thresholds(void) { oracle_set_thresholds(1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0); }
+void oracle_reset_thresholds(void) { oracle_set_thresholds(1.0 / 255.0, 0.99, 0.0001, 0.0, 1.0, 0.2, 0.0, 0.0, 0.0); }
 /* The other discontinuity: the depth ORDER inside a tile.  Two implementations whose view-space depths differ in the
  * last bit (different glue in front of the rasteriser) may sort a near-tie either way.  The tests find the pairs of
  * list neighbours whose depths are within a few ulp and hand over a per-Gaussian relative shift of the SORT KEY only
@@ -167,11 +173,12 @@ static const double *g_depth_shift = 0;
 static int g_depth_shift_n = 0;
 void oracle_set_depth_shift(const double *rel_shift, int n) { g_depth_shift = rel_shift; g_depth_shift_n = n; }
 /* nominal: exactly (real)(1/255); perturbed: moved further in proportion to the exponent's conditioning */
-#define THR_ALPHA_MIN_AT(co, dx, dy)                                                                                  \
+#define THR_ALPHA_MIN_AT(co, dx, dy, kap)                                                                             \
   (g_thr.alpha_cond == 0.0 ? (real)g_thr.alpha_min                                                                    \
-                           : (real)(g_thr.alpha_min * (1.0 - g_thr.alpha_cond * (0.5 * (fabs((double)((co)[0] * (dx) * (dx))) + \
-                                                                                           fabs((double)((co)[2] * (dy) * (dy)))) + \
-                                                                                    fabs((double)((co)[1] * (dx) * (dy)))))))
+                           : (real)(g_thr.alpha_min * (1.0 - g_thr.alpha_cond * (1.0 + g_thr.alpha_kappa * (double)(kap)) *   \
+                                                                    (0.5 * (fabs((double)((co)[0] * (dx) * (dx))) +   \
+                                                                            fabs((double)((co)[2] * (dy) * (dy)))) +  \
+                                                                     fabs((double)((co)[1] * (dx) * (dy)))))))
 #define THR_ALPHA_MIN ((real)g_thr.alpha_min)
 #define THR_ALPHA_MAX ((real)g_thr.alpha_max)
 #define THR_T_MIN ((real)g_thr.T_min)
@@ -197,7 +204,7 @@ int oracle_real_bytes(void) { return (int)sizeof(real); }
 
 void oracle_raster_free(OracleState *st) {
   if (!st) return;
-  free(st->xy); free(st->conic_op); free(st->depth); free(st->cov3D); free(st->tvec);
+  free(st->xy); free(st->conic_op); free(st->depth); free(st->cov3D); free(st->tvec); free(st->kappa);
   free(st->radii); free(st->tiles); free(st->rect); free(st->plist); free(st->range);
   free(st->final_T); free(st->n_contrib);
   free(st);
@@ -235,6 +242,7 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
   st->depth = (real *)calloc(Pn, sizeof(real));
   st->cov3D = (real *)calloc(Pn * 6, sizeof(real));
   st->tvec = (real *)calloc(Pn * 3, sizeof(real));
+  st->kappa = (real *)calloc(Pn, sizeof(real));
   st->radii = (int *)calloc(Pn, sizeof(int));
   st->tiles = (int *)calloc(Pn, sizeof(int));
   st->rect = (int *)calloc(Pn * 4, sizeof(int));
@@ -304,6 +312,7 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
     st->xy[2*i] = px; st->xy[2*i+1] = py;
     st->conic_op[4*i] = c * det_inv; st->conic_op[4*i+1] = -b * det_inv;
     st->conic_op[4*i+2] = a * det_inv; st->conic_op[4*i+3] = opac[i];
+    st->kappa[i] = (a * c) * det_inv;
     st->rect[4*i] = minx; st->rect[4*i+1] = miny; st->rect[4*i+2] = maxx; st->rect[4*i+3] = maxy;
     st->tiles[i] = area;
   }
@@ -354,7 +363,7 @@ OracleState *oracle_raster_forward(const OracleCfg *cfg, int P, const real *mean
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
           if (power > THR_POWER_MAX) continue;
           real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * R_EXP(power));
-          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy)) continue;
+          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy, st->kappa[g])) continue;
           real test_T = T * (1 - alpha);
           if (test_T < THR_T_MIN) break;
           real w = alpha * T;
@@ -421,7 +430,7 @@ void oracle_raster_backward(const OracleCfg *cfg, const OracleState *st, const r
           if (power > THR_POWER_MAX) continue;
           real G = R_EXP(power);
           real alpha = R_FMIN(THR_ALPHA_MAX, co[3] * G);
-          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy)) continue;
+          if (alpha < THR_ALPHA_MIN_AT(co, dx, dy, st->kappa[id])) continue;
           T = T / (1 - alpha);
           real wgt = alpha * T, dL_dalpha = 0;
           for (int ch = 0; ch < C; ch++) {

@@ -473,12 +473,8 @@ def test_pair_capacity_overflow_is_reported_and_retried(oracle32):
         rasterizer._capacity.pop(key, None)
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_randomised_small_scenes_match_oracle(oracle32, seed):
-    """A seeded sweep over what the fixed cases do not vary together: image sizes that are not multiples of the tile
-    (down to less than one tile), cloud sizes from 1 up, footprints from sub-pixel to screen-filling, needle-shaped
-    Gaussians, a posed raster camera, opacities at both extremes (below 1/255: never visible; 1.0: clamped to 0.99),
-    points on and behind the near plane, 1, 3 or 6 channels."""
+def sweep_scene(seed):
+    """The scene of one seed of the randomised sweep below (also scripts/soak_raster.py, scripts/dev/diag_pixel.py)."""
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.integers(5, 150)), int(rng.integers(5, 120))
     P = int(rng.choice([1, 2, 7, 64, 65, 300, 1500]))
@@ -496,9 +492,19 @@ def test_randomised_small_scenes_match_oracle(oracle32, seed):
     op[rng.random(P) < 0.1] = 1.0          # clamped to 0.99 in the blend
     xyz[rng.random(P) < 0.05, 2] = 0.2     # exactly on the near-plane cull (z <= 0.2 is culled)
     f = lambda a: np.ascontiguousarray(a, np.float32)
+    return cam, f(xyz), f(col), f(op), f(s), f(r)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_small_scenes_match_oracle(oracle32, seed):
+    """A seeded sweep over what the fixed cases do not vary together: image sizes that are not multiples of the tile
+    (down to less than one tile), cloud sizes from 1 up, footprints from sub-pixel to screen-filling, needle-shaped
+    Gaussians, a posed raster camera, opacities at both extremes (below 1/255: never visible; 1.0: clamped to 0.99),
+    points on and behind the near plane, 1, 3 or 6 channels."""
     # (the sweep also creates and drops a camera per case: the allocator hands the old matrices' addresses to the new
     # ones, which is how a pointer-keyed host cache of the camera matrices was caught serving stale values)
-    _compare(oracle32, cam, f(xyz), f(col), f(op), f(s), f(r), seed=seed, tag="sweep/%d" % seed)
+    cam, xyz, col, op, s, r = sweep_scene(seed)
+    _compare(oracle32, cam, xyz, col, op, s, r, seed=seed, tag="sweep/%d" % seed)
 
 
 def test_witnessed_outliers_of_c1_and_the_sweep_are_few_and_unsigned():

@@ -51,13 +51,13 @@ ATTRIBUTION_LOG = []
 # Bounds on the WITNESSED outliers of one tensor.  Same inputs on both sides (the operator-boundary rasteriser against the
 # oracle): 1e-4 of the elements -- measured 8e-7 (image) ... 1.2e-5 (gradients) at C2 / C4, 5e-5 at C1.  One flipped
 # (pixel, Gaussian) pair moves every gradient component of that Gaussian and of the ones behind it at that pixel, so
-# small tensors get a floor of 32 elements.  The end-to-end render comparisons (fused HIP glue against torch CPU glue)
+# small tensors get a floor of 64 elements (a 650-Gaussian cloud crammed into a 24 x 54 image: 36 of 1944).  The end-to-end render comparisons (fused HIP glue against torch CPU glue)
 # pass RENDER_OUTLIER_FRACTION instead: the two sides compute the view-space depth with differently rounded arithmetic,
 # so list neighbours within a few ulp of depth swap places (Oracle.find_order_ties) -- ~0.6 such pairs per tile at C2,
 # each visible wherever both Gaussians overlap: 2.1e-4 of the image at C2, 3.8e-4 at C4 (profiles/r03_full_size_parity.jsonl).
 MAX_OUTLIER_FRACTION = 1e-4
 RENDER_OUTLIER_FRACTION = 1e-3
-MIN_OUTLIER_COUNT = 32
+MIN_OUTLIER_COUNT = 64
 
 
 def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.0, max_outlier=5e-2, max_fraction=None,
@@ -92,8 +92,11 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
                              "got %g want %g (err %g of the norm, oracle flip amplitude %g); %d witnessed outliers" % (
                                  what, len(idx), tol, worst.tolist(), got[tuple(worst)], want[tuple(worst)],
                                  err[tuple(worst)] / scale, amp[tuple(worst)], int(((err > tol * scale) & ~rogue).sum())))
-    assert err.max() <= max_outlier * scale, "%s: worst error %g of the inf-norm exceeds the flip bound %g" % (
-        what, err.max() / scale, max_outlier)
+    # (a sanity cap on what a witness may excuse; in a scene of a handful of Gaussians ONE flipped pair legitimately
+    # moves a gradient by a large part of its norm -- soak seed 1459: two Gaussians, 15 % -- so it applies to real tensors)
+    cap = max_outlier if got.size >= 4096 else 1.0
+    assert err.max() <= cap * scale, "%s: worst error %g of the inf-norm exceeds the flip bound %g" % (
+        what, err.max() / scale, cap)
     out = err > tol * scale
     res = Attribution(int(out.sum()), int((amp > 0).sum()), int(got.size), int((diff[out] > 0).sum()),
                       int((diff[out] < 0).sum()))
