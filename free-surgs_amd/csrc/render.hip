@@ -147,11 +147,38 @@ __device__ __forceinline__ void stage_out(float *dst, const float *lds, size_t f
   }
 }
 
+// clamp_min(eval_sh(deg, sh, dir) + 0.5, 0) of one Gaussian (utils/sh_utils.py:57-112, scene/gaussian_model.py:317-320):
+// dir = normalised (world position - frame-0 camera centre), f_dc [3], `rest` = the Gaussian's (K - 1) x 3 SH-rest row.
+// ONE definition for the forward's preprocess and for the Adam kernels that hand the next forward its colours (below),
+// so that a cached colour is bit-for-bit the one the forward would have evaluated.  -> clamp flags (bit c: channel c)
+__device__ __forceinline__ uint32_t sh_colors(const RenderDev &a, float x, float y, float z, const float *fdc,
+                                              const float *rest, float rgb[3]) {
+  float dx = x - a.cam_center[0], dy = y - a.cam_center[1], dz = z - a.cam_center[2];
+  float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= inv_n; dy *= inv_n; dz *= inv_n;
+  float b[16];
+  sh_basis(a.deg, dx, dy, dz, b);
+  const int nk = (a.deg + 1) * (a.deg + 1);
+  uint32_t fl = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float v = b[0] * fdc[c];
+    for (int k = 1; k < nk; k++) v = fmaf(b[k], rest[(k - 1) * 3 + c], v);
+    v += 0.5f;
+    if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
+    rgb[c] = v;
+  }
+  return fl;
+}
+
 // REUSE: the colours (and clamp flags) of every Gaussian are taken from the packed records of an EARLIER forward of
 // the same cloud (`prev_rec`, `prev_flags`) instead of being evaluated: they depend on the parameters and on the frame-0
 // camera centre only (scene/gaussian_model.py:317-320), not on the pose -- the 50 tracking iterations of a frame and
 // the second view of a two-view mapping step re-read 192 B of SH coefficients per Gaussian for nothing otherwise.
-template <bool REUSE>
+// REUSE == 2: from a colour cache float4 [P] = (r, g, b, clamp flags as bits) that the Adam kernel of the previous step
+// wrote right after it updated the parameters (FsgsFusedAdam.next_colors): a mapping step's forward then reads 16 B
+// per Gaussian instead of its 192 B of SH coefficients, like the tracking iterations do.
+template <int REUSE>
 __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam, RenderDev a, GeomOut g,
                                                              uint32_t *__restrict__ flags,
                                                              const float4 *__restrict__ prev_rec,
@@ -167,9 +194,12 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   uint32_t fl = 0;
   if (i < P) {  // issued before the staging loads and their barrier
     raw = load_raw(a, i);
-    if (REUSE) {
+    if (REUSE == 1) {
       pcol = prev_rec[(size_t)i * kRecF4 + 2];
       fl = prev_flags[i];
+    } else if (REUSE == 2) {
+      pcol = prev_rec[i];
+      fl = __float_as_uint(pcol.w);
     } else {
       fdc[0] = a.f_dc[3 * i]; fdc[1] = a.f_dc[3 * i + 1]; fdc[2] = a.f_dc[3 * i + 2];
     }
@@ -185,22 +215,8 @@ __global__ __launch_bounds__(RB) void render_pre_fwd_kernel(int P, CamParams cam
   if (REUSE) {
     rgb[0] = pcol.x; rgb[1] = pcol.y; rgb[2] = pcol.z;
   } else {
-    const float *my_rest = s_rest + (size_t)threadIdx.x * row;
     // view direction from the (frame-0) camera centre to the WORLD position (scene/gaussian_model.py:317-318)
-    float dx = raw.x - a.cam_center[0], dy = raw.y - a.cam_center[1], dz = raw.z - a.cam_center[2];
-    float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    dx *= inv_n; dy *= inv_n; dz *= inv_n;
-    float b[16];
-    sh_basis(a.deg, dx, dy, dz, b);
-    const int nk = (a.deg + 1) * (a.deg + 1);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      float v = b[0] * fdc[c];
-      for (int k = 1; k < nk; k++) v = fmaf(b[k], my_rest[(k - 1) * 3 + c], v);
-      v += 0.5f;
-      if (v < 0.f) { fl |= 1u << c; v = 0.f; }  // clamp_min(.,0): zero gradient below
-      rgb[c] = v;
-    }
+    fl = sh_colors(a, raw.x, raw.y, raw.z, fdc, s_rest + (size_t)threadIdx.x * row, rgb);
   }
   // depth pseudo-colours: row 2 of cam.viewmatrix[0] AS STORED times [x_cam;1] (scene/gaussian_model.py:266-271)
   const float *V = cam.V;
@@ -235,6 +251,7 @@ struct AdamDev {
   float *m[6], *v[6];
   float step_size[6], inv_bc2_sqrt[6];
   float omb1, b2, omb2, eps;
+  float4 *next_colors;  // optional [P]: the colours of the UPDATED parameters for the next forward (render_pre_fwd_kernel<2>)
 };
 // OUT_COMPACT (several views per step, several ranks): 14 floats per Gaussian instead of 59.  The gradient of the
 // 48 SH coefficients is the outer product  basis_k(dir) x gcol_c  where the basis depends only on the Gaussian
@@ -308,14 +325,16 @@ struct GradSink {
       param_of(group)[idx] = pv;
       ad.m[group][idx] = mv;
       ad.v[group][idx] = vv;
+      sp[sl] = pv;  // the updated value stays at hand (next_colors)
     }
   }
 };
 
 // Adam update of the workgroup's SH-rest block from gradients parked in LDS: 76 % of all parameters live here, so
 // p, m, v move with 16-byte accesses, 12 of them in flight per thread, like the stand-alone Adam kernel
-__device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const AdamDev &ad, const float *s_rest,
-                                                   size_t first, size_t stage_cnt) {
+// keep: the updated coefficients replace their gradients in LDS (for the colour cache of the next forward)
+__device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const AdamDev &ad, float *s_rest,
+                                                   size_t first, size_t stage_cnt, bool keep) {
   float *pp = const_cast<float *>(a.f_rest) + first, *mp = ad.m[2] + first, *vp = ad.v[2] + first;
   const bool vec = ((first & 3) == 0) && (((((uintptr_t)pp) | ((uintptr_t)mp) | ((uintptr_t)vp)) & 15) == 0);
   const size_t n4 = vec ? (stage_cnt >> 2) : 0;
@@ -337,13 +356,26 @@ __device__ __forceinline__ void adam_rows_from_lds(const RenderDev &a, const Ada
       adam_one(p4[u].z, g4.z, m4[u].z, v4[u].z, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
       adam_one(p4[u].w, g4.w, m4[u].w, v4[u].w, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
       ((float4 *)pp)[q] = p4[u]; ((float4 *)mp)[q] = m4[u]; ((float4 *)vp)[q] = v4[u];
+      if (keep) ((float4 *)s_rest)[q] = p4[u];
     }
   }
   for (size_t e = (n4 << 2) + threadIdx.x; e < stage_cnt; e += RB) {
     float pv = pp[e], mv = mp[e], vv = vp[e];
     adam_one(pv, s_rest[e], mv, vv, ad.omb1, ad.b2, ad.omb2, ad.eps, ad.step_size[2], ad.inv_bc2_sqrt[2]);
     pp[e] = pv; mp[e] = mv; vp[e] = vv;
+    if (keep) s_rest[e] = pv;
   }
+}
+
+// The colours the NEXT forward will need, from the parameters this launch has just updated (all in registers / LDS):
+// sink.sp[0..2] = xyz, sp[3..5] = f_dc after their Adam update, s_rest = the workgroup's updated SH-rest rows.
+template <typename Sink>
+__device__ __forceinline__ void emit_next_colors(const RenderDev &a, const AdamDev &ad, const Sink &sink,
+                                                 const float *my_rest, int i) {
+  float rgb[3];
+  const float fdc[3] = {sink.sp[3], sink.sp[4], sink.sp[5]};
+  const uint32_t fl = sh_colors(a, sink.sp[0], sink.sp[1], sink.sp[2], fdc, my_rest, rgb);
+  ad.next_colors[i] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float(fl));
 }
 
 __global__ void loss_total_kernel(const float *terms, const float *weights, int n, float *total) {
@@ -502,7 +534,8 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     if (!ADAM) {
       stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
     } else {
-      adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt);
+      adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt, ad.next_colors != nullptr);
+      if (ad.next_colors) __syncthreads();  // the updated rows are read back per Gaussian below
     }
   }
   if (i < P) {
@@ -523,6 +556,9 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
       sink.put(0, i, 0, dxyz[0]);
       sink.put(0, i, 1, dxyz[1]);
       sink.put(0, i, 2, dxyz[2]);
+    }
+    if constexpr (ADAM) {
+      if (ad.next_colors) emit_next_colors(a, ad, sink, my_rest, i);
     }
   }
   if (mode & MODE_CAM_GRAD) {  // dL/dw2c[r][c] = sum_i g_r [x;1]_c   (scene/pose_optimizer.py:985-987 adjoint)
@@ -647,7 +683,11 @@ __global__ __launch_bounds__(RB) void adam_compact_kernel(int P, RenderDev a, co
   }
   if (row > 0) {
     __syncthreads();
-    adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt);
+    adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt, ad.next_colors != nullptr);
+  }
+  if (ad.next_colors) {
+    __syncthreads();
+    if (i < P) emit_next_colors(a, ad, sink, s_rest + (size_t)threadIdx.x * row, i);
   }
 }
 
@@ -696,7 +736,8 @@ int fsgs_render_state_layout(int P, int width, int height, int64_t max_pairs, si
 static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
                                float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes, void *scratch,
                                size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered, fsgs_stream_t stream_,
-                               const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs) {
+                               const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs,
+                               const float *color_cache = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!cfg || P < 0 || !out_image || !out_depth_sil || !state || !scratch || !num_rendered || max_pairs < 0)
     return FSGS_ERR_INVALID;
@@ -712,14 +753,17 @@ static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRender
   if (P > 0) {
     ProfScope ps(PROF_RENDER_PRE_FWD, stream);
     GeomOut g{B.xy, B.co, B.depth, B.rec, radii, B.tiles, B.rect, B.tile_count, cam.gx, binning_clear_words(ntiles)};
-    if (prev_state) {
+    if (color_cache) {
+      hipLaunchKernelGGL(render_pre_fwd_kernel<2>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args), g,
+                         B.flags, (const float4 *)color_cache, (const uint32_t *)nullptr);
+    } else if (prev_state) {
       StateLayout PL = state_layout(P, W, H, prev_max_pairs, 6);
       if (prev_state_bytes < PL.total || prev_state == state) return FSGS_ERR_STATE;
       const char *pb = (const char *)prev_state;
-      hipLaunchKernelGGL(render_pre_fwd_kernel<true>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args),
+      hipLaunchKernelGGL(render_pre_fwd_kernel<1>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam, to_dev(args),
                          g, B.flags, (const float4 *)(pb + PL.rec), (const uint32_t *)(pb + PL.flags));
     } else {
-      hipLaunchKernelGGL(render_pre_fwd_kernel<false>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
+      hipLaunchKernelGGL(render_pre_fwd_kernel<0>, dim3((P + RB - 1) / RB), dim3(RB), 0, stream, P, cam,
                          to_dev(args), g, B.flags, (const float4 *)nullptr, (const uint32_t *)nullptr);
     }
   }
@@ -759,6 +803,15 @@ int fsgs_render_forward_reuse_colors(const FsgsRasterCfg *cfg, int P, const Fsgs
                              max_pairs, num_rendered, stream, prev_state, prev_state_bytes, prev_max_pairs);
 }
 
+int fsgs_render_forward_cached_colors(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                                      float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes,
+                                      void *scratch, size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered,
+                                      const float *colors4, fsgs_stream_t stream) {
+  if (!colors4 && P > 0) return FSGS_ERR_INVALID;
+  return render_forward_impl(cfg, P, args, out_image, out_depth_sil, radii, state, state_bytes, scratch, scratch_bytes,
+                             max_pairs, num_rendered, stream, nullptr, 0, 0, colors4);
+}
+
 }  // extern "C"
 
 namespace {
@@ -774,6 +827,7 @@ int fill_adam(const FsgsFusedAdam *adam, int max_sh_degree, AdamDev &ad) {
     ad.step_size[g] = (float)((double)adam->lr[g] / bc1);  // exactly fsgs_adam_step's host arithmetic
     ad.inv_bc2_sqrt[g] = (float)(1.0 / sqrt(bc2));
   }
+  ad.next_colors = (float4 *)adam->next_colors;
   ad.omb1 = (float)(1.0 - adam->beta1);
   ad.b2 = (float)adam->beta2;
   ad.omb2 = (float)(1.0 - adam->beta2);

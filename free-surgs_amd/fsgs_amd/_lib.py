@@ -56,7 +56,8 @@ class FsgsRenderGrads(C.Structure):
 
 class FsgsFusedAdam(C.Structure):
     _fields_ = [("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6), ("lr", C.c_float * 6),
-                ("step", C.c_int32 * 6), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+                ("step", C.c_int32 * 6), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("next_colors", C.c_void_p)]
 
 
 class FsgsStepTail(C.Structure):
@@ -124,6 +125,11 @@ _PROTOTYPES = {
         _i,
         [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
          C.POINTER(_i64), _vp, _sz, _i64, _vp],
+    ),
+    "fsgs_render_forward_cached_colors": (
+        _i,
+        [C.POINTER(FsgsRasterCfg), _i, C.POINTER(FsgsRenderArgs), _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i64,
+         C.POINTER(_i64), _vp, _vp],
     ),
     "fsgs_render_backward": (
         _i,

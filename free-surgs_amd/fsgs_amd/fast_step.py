@@ -81,7 +81,10 @@ class FastStepper:
         self.fuse_adam = True  # single-view steps on one rank: Adam inside the render backward
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
         self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
-        self.overlap_views = True  # multi-view mapping steps: views >= 1 on their own streams beside view 0
+        # (FSGS_OVERLAP_VIEWS=0 / FSGS_CACHE_COLORS=0: bisection switches, diagnostics only)
+        self.overlap_views = os.environ.get("FSGS_OVERLAP_VIEWS", "1") != "0"  # multi-view mapping steps: views >= 1 on their own streams beside view 0
+        self.cache_colors = os.environ.get("FSGS_CACHE_COLORS", "1") != "0"    # the Adam kernels leave the next forward's per-Gaussian colours behind (16 B instead of 192 B)
+        self.cache_hits = 0        # forwards served from that cache (tests / diagnostics)
 
     def _check_frames(self):
         """the per-frame targets are handed to the kernels as raw pointers: float32, contiguous, on the cloud's device,
@@ -168,12 +171,21 @@ class FastStepper:
         # The per-Gaussian colours depend on the parameters and the frame-0 camera centre only: while neither changes
         # (the 50 tracking iterations of a frame, the second view of a two-view mapping step) a forward copies them from
         # the previous forward's state instead of evaluating 48 SH coefficients per Gaussian again.
-        ckey = (P, W, H, pc.active_sh_degree, pc.max_sh_degree, self.poses.cam_center._version) + tuple(
-            (id(p[n]), p[n]._version) for n in PARAM_NAMES)
+        ckey = self._color_key()
         # (the tensors themselves are part of the entry: ids alone can be recycled by the allocator)
         owners = tuple(p[n] for n in PARAM_NAMES) + (self.poses.cam_center,)
         prev = self.__dict__.get("_color_src") if (allow_reuse and getattr(self, "reuse_colors", True)) else None
         if prev is not None and (prev[0] != ckey or len(prev[4]) != len(owners) or any(a is not b for a, b in zip(prev[4], owners))):
+            prev = None
+        # ... and a MAPPING step's forward takes them from the colour cache the previous step's Adam kernel filled right
+        # after it updated the parameters (FsgsFusedAdam.next_colors), valid under the same identity / version test
+        # (allow_reuse = False only rules out the copy from ANOTHER forward's state -- a view on its own stream must not
+        # wait for view 0's forward; the cache was complete before the step began)
+        cached = self.__dict__.get("_color_cache") if getattr(self, "reuse_colors", True) else None
+        if cached is not None and (cached[0] != ckey or len(cached[2]) != len(owners) or
+                                   any(a_ is not b_ for a_, b_ in zip(cached[2], owners))):
+            cached = None
+        if cached is not None:
             prev = None
         for _attempt in range(3):
             sz = b.sizes.get(cap)
@@ -183,7 +195,12 @@ class FastStepper:
                 sz = b.sizes[cap] = (sb.value, xb.value)
             state = torch.empty((sz[0],), dtype=torch.uint8, device=dev)
             scratch = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
-            if prev is not None:
+            if cached is not None:
+                cached[1].record_stream(torch.cuda.current_stream())
+                rc = lib.fsgs_render_forward_cached_colors(
+                    C.byref(cfg), P, C.byref(args), _lib.ptr(b.image), _lib.ptr(b.depth_sil), _lib.ptr(b.radii),
+                    _lib.ptr(state), sz[0], _lib.ptr(scratch), sz[1], cap, C.byref(nr), _lib.ptr(cached[1]), stream)
+            elif prev is not None:
                 # (the source state may belong to another stream's pool: view 0's forward, read by view 1's on its own)
                 prev[1].record_stream(torch.cuda.current_stream())
                 rc = lib.fsgs_render_forward_reuse_colors(
@@ -202,13 +219,42 @@ class FastStepper:
             break
         else:
             raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
-        if prev is not None and os.environ.get("FSGS_CHECK_REUSE") == "1":
+        if cached is not None:
+            self.cache_hits += 1
+        if (prev is not None or cached is not None) and os.environ.get("FSGS_CHECK_REUSE") == "1":
             self._check_reused_colors(cfg, P, W, H, args, state, sz, cap, b)
         self._color_src = (ckey, state, sz[0], cap, owners)
         rasterizer.last_num_rendered = int(nr.value)
         self.pairs_total += int(nr.value)  # (bench.py reports the mean pair count of the steps it timed)
         self.forward_calls += 1
         return args, state, sz[0], cap, int(nr.value)
+
+    def _color_key(self):
+        """what the per-Gaussian colours depend on: the cloud's size, the SH degrees, the frame-0 camera centre and the
+        parameter tensors (object ids here; the objects themselves are compared by the callers) with their versions"""
+        pc, p = self.pc, self.pc.params
+        cfg = self._cfg()
+        return (pc.num_points, cfg.image_width, cfg.image_height, pc.active_sh_degree, pc.max_sh_degree,
+                self.poses.cam_center._version) + tuple((id(p[n]), p[n]._version) for n in PARAM_NAMES)
+
+    def _next_colors_buffer(self):
+        """[P,4] the Adam kernel of this step fills for the next forward (FsgsFusedAdam.next_colors); None = not wanted"""
+        if not getattr(self, "cache_colors", True):
+            return None
+        P = self.pc.num_points
+        buf = self.__dict__.get("_next_colors")
+        dev = self.pc.params["_xyz"].device
+        if buf is None or buf.shape[0] != P or buf.device != dev:
+            buf = self._next_colors = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        return buf
+
+    def _colors_cached(self, buf):
+        """call right after optim.mark_updated(): `buf` holds the colours of the parameters as they stand now"""
+        if buf is None:
+            self._color_cache = None
+            return
+        p = self.pc.params
+        self._color_cache = (self._color_key(), buf, tuple(p[n] for n in PARAM_NAMES) + (self.poses.cam_center,))
 
     def _check_reused_colors(self, cfg, P, W, H, args, state, sz, cap, b):
         """FSGS_CHECK_REUSE=1 (debugging): the reuse above rests on every raw-pointer writer bumping the version
@@ -250,6 +296,9 @@ class FastStepper:
             adam.exp_avg[k], adam.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             adam.lr[k], adam.step[k] = float(g["lr"]), int(st["step"])
             adam.beta1, adam.beta2, adam.eps = float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+        nc = self._next_colors_buffer()
+        adam.next_colors = None if nc is None else nc.data_ptr()
+        self._adam_next_colors = nc
         return adam
 
     @staticmethod
@@ -271,6 +320,8 @@ class FastStepper:
             if adam.exp_avg[g]:
                 ad2.exp_avg[g] = adam.exp_avg[g] + 4 * r * lo
                 ad2.exp_avg_sq[g] = adam.exp_avg_sq[g] + 4 * r * lo
+        if adam.next_colors:
+            ad2.next_colors = adam.next_colors + 16 * lo
         return a2, ad2
 
     def _side_stream(self, dev, view=0):
@@ -430,6 +481,7 @@ class FastStepper:
                                                          C.byref(tail), _lib.ptr(b.bwd_scratch),
                                                          b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
                 optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
+                self._colors_cached(self._adam_next_colors)
                 step_optimizer = False  # done
                 stats_done = True
                 radii0, last_b = b.radii, b
@@ -490,8 +542,9 @@ class FastStepper:
         # Overlapped: ALL forwards are enqueued first, every view on its own stream, then every view's losses + backward.
         # A forward call returns when its pair count has arrived (its binning is done and its blend enqueued), so the
         # host hands view 1's binning over while view 0's forward blend runs, and view 0's loss kernels while view 1's
-        # does: no stream waits for the ~0.2 ms of host work a view's calls take.  View k >= 1 evaluates its own
-        # per-Gaussian colours (copying view 0's would make its first kernel wait for view 0's whole forward).
+        # does: no stream waits for the ~0.2 ms of host work a view's calls take.  Every view reads its per-Gaussian colours
+        # from the cache the previous step's Adam kernel left (without one, view k >= 1 evaluates its own: copying view 0's
+        # would make its first kernel wait for view 0's whole forward).
         # Serial (overlap_views = False): one view after the other on the current stream, colours reused.
         step_begun = None
         if overlap:
@@ -579,6 +632,7 @@ class FastStepper:
             reduce_compact(b0.gc)  # ONE all-reduce of 56 B / Gaussian
             adam_rows(0, P)
         optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
+        self._colors_cached(self._adam_next_colors)
         return b0.radii, views[-1], state, cap
 
     # ---- tracking (train.py:166-200) -----------------------------------------------------------------------

@@ -215,6 +215,16 @@ int fsgs_render_forward_reuse_colors(const FsgsRasterCfg *cfg, int P, const Fsgs
                                      int64_t max_pairs, int64_t *num_rendered,
                                      const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs,
                                      fsgs_stream_t stream);
+/* A forward that takes the per-Gaussian colours from a colour cache colors4 [P,4] = (r, g, b, clamp flags as bits) written
+ * by the Adam kernel of the PREVIOUS step right after it updated the parameters (FsgsFusedAdam.next_colors of
+ * fsgs_render_backward_adam / fsgs_adam_step_compact[_sum]) -- the colours depend on the parameters and the frame-0
+ * camera centre only (scene/gaussian_model.py:317-320).  Valid while neither has changed since that launch and
+ * args->active_sh_degree is the one it ran with; the caller keeps track (fsgs_amd/fast_step.py checks identities
+ * and version counters).  Bit-identical to fsgs_render_forward. */
+int fsgs_render_forward_cached_colors(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *args, float *out_image,
+                                      float *out_depth_sil, int32_t *radii, void *state, size_t state_bytes,
+                                      void *scratch, size_t scratch_bytes, int64_t max_pairs, int64_t *num_rendered,
+                                      const float *colors4, fsgs_stream_t stream);
 
 /* dL_dimage / dL_ddepth_sil [3,H,W] or NULL (= zero).  gs_grad / cam_grad as in render(...):
  * gs_grad routes the mean gradient to xyz, cam_grad reduces dL/dw2c.  param_grads = 0 skips the
@@ -242,6 +252,8 @@ typedef struct FsgsFusedAdam {
   float lr[6];
   int32_t step[6];
   double beta1, beta2, eps;
+  float *next_colors; /* optional [P,4]: filled with (r, g, b, clamp flags as bits) = clamp_min(eval_sh + 0.5, 0) of the
+                       * UPDATED parameters, for fsgs_render_forward_cached_colors of the next step; NULL = not wanted */
 } FsgsFusedAdam;
 /* What train.py does between loss.backward() and optimizer.step() on the same iteration, folded into the same
  * launch (all optional; tail == NULL or NULL members = skipped):

@@ -197,6 +197,53 @@ def test_colour_reuse_check_switch_catches_a_write_without_a_version_bump(monkey
     torch.cuda.synchronize()
 
 
+def test_colour_cache_left_by_the_adam_kernels_equals_fresh_evaluation(monkeypatch):
+    """The Adam kernels (inside the backward for a single view, from the compact gradients otherwise) leave
+    clamp_min(eval_sh + 0.5, 0) of the UPDATED parameters behind (FsgsFusedAdam.next_colors) and the next forward reads
+    16 B per Gaussian instead of its SH block (fsgs_render_forward_cached_colors).  With FSGS_CHECK_REUSE=1 every such
+    forward re-evaluates the colours and compares them bit for bit; the cache must actually be hit (single-view, two-view
+    and tracking forwards behind a mapping step), must end with an SH-degree step or a foreign write to a parameter,
+    and a run with the cache switched off must produce the same parameters."""
+    from fsgs_amd.flow import FlowTargets
+
+    monkeypatch.setenv("FSGS_CHECK_REUSE", "1")
+    H, W = 256, 320
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV)
+    a, b = _world(), _world()
+    fa, fb = FastStepper(a[0], a[1], a[2]), FastStepper(b[0], b[1], b[2])
+    fb.cache_colors = False
+    tg = FlowTargets(a[2].monodeps[0].reshape(1, H, W), np.eye(4, dtype=np.float32), a[3]["K"], a[2].flows_fw[0], None)
+    a[1].initialize_tracking_optimizer(50)
+    b[1].initialize_tracking_optimizer(50)
+    hits = []
+    for views in ([1], [2], [1, 2], [0], [2, 1]):
+        fa.mapping_step(views, corners=corners)
+        fb.mapping_step(views, corners=corners)
+        hits.append(fa.cache_hits)
+    assert hits == [0, 1, 3, 4, 6], hits          # every forward behind the first step's Adam reads the cache
+    fa.tracking_step(1, tg, None)                   # ... and so does the first tracking forward behind a mapping step
+    fb.tracking_step(1, tg, None)
+    assert fa.cache_hits == 7 and fb.cache_hits == 0
+    a[0].oneupSHdegree()                            # the colours depend on the active degree: the cache ends
+    b[0].oneupSHdegree()
+    fa.mapping_step([1], corners=corners)
+    fb.mapping_step([1], corners=corners)
+    assert fa.cache_hits == 7
+    fa.mapping_step([2], corners=corners)
+    fb.mapping_step([2], corners=corners)
+    assert fa.cache_hits == 8
+    with torch.no_grad():                           # a counted write by somebody else: evaluated afresh
+        a[0].params["_features_dc"].add_(0.0)
+        b[0].params["_features_dc"].add_(0.0)
+    fa.mapping_step([1], corners=corners)
+    fb.mapping_step([1], corners=corners)
+    assert fa.cache_hits == 8
+    torch.cuda.synchronize()
+    for k in PARAM_NAMES:
+        pa, pb = a[0].params[k].detach(), b[0].params[k].detach()
+        assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
+
+
 def test_full_size_c2_gradient_routes_agree():
     """BASELINE.json's C2 (1280x1024, 300 000 Gaussians): the three gradient routes of the step driver -- Adam inside the
     backward, the compact [P,14] gradient, full gradients + multi-tensor Adam -- must produce the same update at full

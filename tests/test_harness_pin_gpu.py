@@ -47,15 +47,23 @@ def test_runner_reproduces_the_cpu_oracle_trajectory():
     # cloud size after densify_and_prune: EXACT (same clone / split / prune decisions from the accumulated statistics)
     assert [[e[1], e[2]] for e in dens] == fx["densify"].tolist(), (dens, fx["densify"].tolist())
     assert run.pc.num_points == int(fx["final_P"])
-    # per-iteration losses.  Before the densification the two runs differ by fp32 rounding only; Adam (eps 1e-15)
-    # turns a rounding-sized gradient difference on a parameter the image does not depend on (the quaternion of an
-    # isotropic Gaussian) into a full-size step of that parameter, which the loss does not see.
+    # per-iteration losses.  Before the densification the two runs differ by fp32 rounding only (measured 1.3e-5); Adam
+    # (eps 1e-15) turns a rounding-sized gradient difference on a parameter the image does not depend on (the quaternion
+    # of an isotropic Gaussian) into a full-size step of that parameter, which the loss does not see.  AFTER the
+    # densification the children start with zero moments: their first steps are lr * sign(gradient), and the trajectory
+    # becomes sensitive to the last bit -- the CPU-oracle harness ITSELF, run with another summation order of its own
+    # backward (8 OpenMP threads instead of 1), leaves its own fixture by 0.9e-4 .. 5.4e-4 there and by 6e-7 before
+    # (tests/test_harness_pin_cpu.py::test_the_reference_trajectory_is_only_that_reproducible_after_a_densification).
+    # Round 2's 5e-4 sat inside that band and held by luck (HIP then 0.4e-4 .. 1.9e-4 off; with the exponent's log2(e)
+    # rounded once from double, round 3, 2.8e-4 .. 5.6e-4: 9 of 25 runs failed); the bound is POST_DENSIFY_RTOL = 2e-3.
     got_map = np.array([e[3] for e in maps])
     n_pre = int((fx["map_iter"] < fx["densify"][0, 0]).sum())
     np.testing.assert_allclose(got_map[:n_pre], fx["map_loss"][:n_pre], rtol=1e-4)
-    np.testing.assert_allclose(got_map[n_pre:], fx["map_loss"][n_pre:], rtol=5e-4)
+    np.testing.assert_allclose(got_map[n_pre:], fx["map_loss"][n_pre:], rtol=ref_harness.POST_DENSIFY_RTOL)
     got_trk = np.array([[e[3], e[4], e[5]] for e in tracks])
-    np.testing.assert_allclose(got_trk, fx["track_loss"], rtol=5e-4, atol=1e-6)
+    first_post = min(k for k, e in enumerate(tracks) if e[1] >= 2)  # frame 1 is tracked before the densification, frame 2 after
+    np.testing.assert_allclose(got_trk[:first_post], fx["track_loss"][:first_post], rtol=5e-4, atol=1e-6)
+    np.testing.assert_allclose(got_trk[first_post:], fx["track_loss"][first_post:], rtol=ref_harness.POST_DENSIFY_RTOL, atol=1e-6)
     # the poses of all three frames after the run (quaternion r, translation t): each took 5 Adam steps of 5e-3 .. 6e-4
     # (lr 0.01 halved at 0, 1, 2, 3, 4 -- MultiStepLR(range(0, 5, 1))); 3e-5 is half a percent of one step
     np.testing.assert_allclose(run.poses.r.detach().cpu().numpy(), fx["pose_r"], atol=3e-5)
