@@ -458,10 +458,11 @@ def main():
                                         "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU in %s" % src}
                 # the second issue-bound kernel, same definitions: blend_fwd (HIP events of this run; counters offline)
                 fms, fl = prof.get("blend_fwd", (0.0, 0))
-                fhits = [k for k in pmc["kernels"] if k.startswith("blend_fwd_kernel<%d" % C)]
+                Cf = 4 if (use_fast and C == 6 and getattr(stepper, "mapping_planes4", False)) else C  # planes the step's forward blends
+                fhits = [k for k in pmc["kernels"] if k.startswith("blend_fwd_kernel<%d" % Cf)]
                 if fl and len(fhits) == 1:
                     fent = pmc["kernels"][fhits[0]]
-                    f_alg = R * (4 + 24 + 4 * C) + H * W * (4 * C + 4 + 8)
+                    f_alg = R * (4 + 24 + 4 * Cf) + H * W * (4 * Cf + 4 + 8)
                     f_s = fms / fl / 1e3
                     roofline["blend_fwd"] = {
                         "kernel": fhits[0], "avg_kernel_ms": fms / fl, "algorithmic_bytes": f_alg,
@@ -486,11 +487,13 @@ def main():
         _lib.profile_enable(list(RASTER_GROUPS), stride=1)
         stepper.pairs_total = stepper.forward_calls = 0
         n_r = 24
-        stepper.reuse_colors = False  # the parameters do not move in this loop; a training step's always have: every
-        for it in range(n_r):         # forward evaluates the SH colours, as in the timed loop above
+        stepper.reuse_colors = False  # the rasteriser ALONE does all of its work here: every forward evaluates the SH
+        stepper.mapping_planes4 = False  # colours and blends all six planes (both passes of render() in full)
+        for it in range(n_r):
             stepper.mapping_step([it % n_frames], step_optimizer=False)
         torch.cuda.synchronize()
         stepper.reuse_colors = True
+        stepper.mapping_planes4 = True
         pr = _lib.profile_read()
         _lib.profile_enable([])
         Rr = int(round(stepper.pairs_total / max(stepper.forward_calls, 1)))
@@ -654,6 +657,8 @@ def main():
                 "num_rendered": R, "upstream_num_rendered": upstream_main,
                 "scene": args.scene, "densify_every": args.densify_every or None, "gaussians_at_end": pc.num_points,
                 "target_texture": texture or None,
+                "step_forward": "blends the planes the step's losses read (image + depth: blend_fwd<4>); SH colours of the "
+                                "updated parameters are left behind by the Adam kernel (colour cache)" if use_fast else None,
                 "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"
