@@ -488,12 +488,11 @@ def main():
         stepper.pairs_total = stepper.forward_calls = 0
         n_r = 24
         stepper.reuse_colors = False  # the rasteriser ALONE does all of its work here: every forward evaluates the SH
-        stepper.mapping_planes4 = False  # colours and blends all six planes (both passes of render() in full)
+        # colours (and, as in the timed loop, all six planes of both passes of render() are blended)
         for it in range(n_r):
             stepper.mapping_step([it % n_frames], step_optimizer=False)
         torch.cuda.synchronize()
         stepper.reuse_colors = True
-        stepper.mapping_planes4 = True
         pr = _lib.profile_read()
         _lib.profile_enable([])
         Rr = int(round(stepper.pairs_total / max(stepper.forward_calls, 1)))
@@ -657,8 +656,9 @@ def main():
                 "num_rendered": R, "upstream_num_rendered": upstream_main,
                 "scene": args.scene, "densify_every": args.densify_every or None, "gaussians_at_end": pc.num_points,
                 "target_texture": texture or None,
-                "step_forward": "blends the planes the step's losses read (image + depth: blend_fwd<4>); SH colours of the "
-                                "updated parameters are left behind by the Adam kernel (colour cache)" if use_fast else None,
+                "step_forward": "all six planes of both passes; the SH colours of the updated parameters are left behind by "
+                                "the previous step's Adam kernel (colour cache: evaluated once per step, on the updated "
+                                "parameters)" if use_fast else None,
                 "fused_render": fused, "hip_losses": hip_losses,
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"

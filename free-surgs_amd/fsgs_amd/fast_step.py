@@ -85,11 +85,11 @@ class FastStepper:
         self.overlap_views = os.environ.get("FSGS_OVERLAP_VIEWS", "1") != "0"  # multi-view mapping steps: views >= 1 on their own streams beside view 0
         self.cache_colors = os.environ.get("FSGS_CACHE_COLORS", "1") != "0"    # the Adam kernels leave the next forward's per-Gaussian colours behind (16 B instead of 192 B)
         self.cache_hits = 0        # forwards served from that cache (tests / diagnostics)
-        # mapping forwards blend the planes the step reads -- image + depth, like the tracking forward (train.py:250-258:
+        # True: mapping forwards blend the planes the step reads -- image + depth, like the tracking forward (train.py:250-258:
         # rgb_loss on `render`, the Pearson losses on `render_dep`; the silhouette and depth^2 planes feed render()'s
-        # `render_opacity` / `uncertainty`, which no training step reads).  False: all six planes (bench.py's rasteriser-alone
-        # timing, tests that look at the planes).
-        self.mapping_planes4 = True
+        # `render_opacity` / `uncertainty`, which no training step reads).  Measured at C2: blend_fwd 137.8 -> 136.2 us (the
+        # colour FMAs are packed two channels an instruction either way), so the default keeps all six planes.
+        self.mapping_planes4 = False
 
     def _check_frames(self):
         """the per-frame targets are handed to the kernels as raw pointers: float32, contiguous, on the cloud's device,
@@ -406,7 +406,7 @@ class FastStepper:
         with torch.cuda.stream(side):
             cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
             b.bwd_scratch.zero_()
-        args, state, sbytes, cap, nr = self._render_forward(w2c, b, tracking=getattr(self, "mapping_planes4", True),
+        args, state, sbytes, cap, nr = self._render_forward(w2c, b, tracking=getattr(self, "mapping_planes4", False),
                                                             allow_reuse=allow_reuse)
         fwd_done = torch.cuda.Event()
         fwd_done.record()
