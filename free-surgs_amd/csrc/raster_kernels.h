@@ -465,10 +465,14 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
       const unsigned long long key = mine ? lds[t] : 0ull;
       uint32_t rank = 0;
       const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(lds);
+#ifdef FSGS_EXP_SORT_NO_RANK  // experiment builds only: the tile sort's floor without its rank loop (lists stay unsorted)
+      rank = (uint32_t)t;
+#else
       for (int j = 0; j < (n + 1) >> 1; j++) {
         const ulonglong2 ab = pairs[j];
         rank += (ab.x < key) + (ab.y < key);
       }
+#endif
       if (mine) plist[base + rank] = (uint32_t)key;
     } else if (n <= 2 * SORT_RANK_KEYS) {
       // 257..512 keys: two rank-sorted halves A = keys [0,256), B = keys [256,n), merged by rank: a key's final
