@@ -243,6 +243,10 @@ def main():
                          "all-reduce while the next is produced, Adam per chunk behind it (dist.ProducerPipelinedReducer); "
                          "default one collective: whether the extra collective launches pay depends on the fabric -- "
                          "the driver's scaling run decides")
+    ap.add_argument("--ar-algo", default="rccl", choices=["rccl", "direct"],
+                    help="N > 1: the step's exchange -- `rccl`: one torch.distributed all_reduce (RCCL picks algorithm and "
+                         "protocol); `direct`: dist.DirectAllReduce, an explicit all-to-all of shards + local sum + all-gather "
+                         "over the point-to-point xGMI links (SURVEY s5).  The extras of every N > 1 run time both alone")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
     ap.add_argument("--scene", default="default", choices=sorted(SCENES),
                     help="dense: every Gaussian 1.62x larger -> upstream pair count ~ SURVEY s8d's nominal 10 tiles per "
@@ -309,7 +313,8 @@ def main():
         stepper = FastStepper(pc, poses, frames)
 
     # N > 1: ONE all-reduce of the compact gradient (optionally chunked and pipelined with Adam, --ar-chunks)
-    reducer = fdist.ProducerPipelinedReducer(args.ar_chunks) if args.ar_chunks > 1 else fdist.all_reduce_compact
+    reducer = (fdist.ProducerPipelinedReducer(args.ar_chunks) if args.ar_chunks > 1 else
+               fdist.DirectAllReduce() if args.ar_algo == "direct" else fdist.all_reduce_compact)
 
     densify_log = []
 
@@ -608,6 +613,9 @@ def main():
         width = nfloat // rows
         chunks = [buf[lo * width:min(rows, lo + per) * width] for lo in range(0, rows, per)]
         comm["chunks4_ms"] = timed(lambda: [torch.distributed.all_reduce(c) for c in chunks])
+        direct = fdist.DirectAllReduce()
+        comm["direct_ms"] = timed(lambda: direct(buf))  # all-to-all of shards + local sum + all-gather (--ar-algo direct)
+        comm["timed_route"] = "pipelined x%d" % args.ar_chunks if args.ar_chunks > 1 else args.ar_algo
         tiny = torch.zeros((1024,), dtype=torch.float32, device=device)
         comm["latency_4KB_ms"] = timed(lambda: torch.distributed.all_reduce(tiny), reps=50)
         comm["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMP_NUM"))}

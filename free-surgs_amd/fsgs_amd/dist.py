@@ -81,6 +81,48 @@ def all_reduce_compact(gc):
         dist.all_reduce(gc, op=dist.ReduceOp.SUM)
 
 
+class DirectAllReduce:
+    """all-reduce(SUM) as a DIRECT reduce-scatter + all-gather: xGMI is point-to-point -- every GPU has
+    a link to every other -- so rank r sends shard j of its gradient straight to rank j (ONE all-to-all: all N - 1 links of
+    a GPU carry 1/N of the buffer at once, one hop each), sums the N shards it holds, and the reduced shards are
+    all-gathered the same way: 2 exchange steps of (N - 1)/N of the bytes in total per GPU, against the 2 (N - 1)
+    dependent steps of a ring.  Whether RCCL's own all_reduce already does as well on a given node is for the first
+    multi-GPU run to say: `bench.py --gpus N` times both (`comm.ms`, `comm.direct_ms`); this class is the explicit form,
+    usable as `reduce_compact=` of FastStepper.mapping_step (`bench.py --ar-algo direct`).  In place; any element count
+    (a padded staging buffer when it is not a multiple of 4 N floats).  gloo runs the same calls in the CPU tests."""
+
+    def __init__(self):
+        self._recv = self._red = self._stage = None
+
+    def _buffers(self, like, n, world):
+        shard = -(-n // (4 * world)) * 4  # floats per rank, 16-byte granular
+        if self._recv is None or self._recv.numel() != world * shard or self._recv.device != like.device:
+            self._recv = torch.empty((world, shard), dtype=like.dtype, device=like.device)
+            self._red = torch.empty((shard,), dtype=like.dtype, device=like.device)
+            self._stage = torch.zeros((world * shard,), dtype=like.dtype, device=like.device)
+        return shard
+
+    def __call__(self, gc):
+        if not _live():
+            return
+        world = dist.get_world_size()
+        flat = gc.reshape(-1)
+        if flat.data_ptr() != gc.data_ptr():
+            raise ValueError("DirectAllReduce reduces in place: the gradient buffer must be contiguous")
+        n = flat.numel()
+        shard = self._buffers(flat, n, world)
+        padded = n != world * shard
+        send = flat
+        if padded:  # the tail of the last shard is padding (zeros)
+            self._stage[:n].copy_(flat)
+            send = self._stage
+        dist.all_to_all_single(self._recv.view(-1), send)         # shard j of every rank -> rank j
+        torch.sum(self._recv, dim=0, out=self._red)               # this rank's shard of the sum
+        dist.all_gather_into_tensor(send, self._red)              # every reduced shard -> everybody (in place of `send`)
+        if padded:
+            flat.copy_(self._stage[:n])
+
+
 class PipelinedCompactReducer:
     """all-reduce of the compact gradient in `nchunks` row ranges on a second stream, the Adam kernel of chunk i
     running beside the all-reduce of chunk i+1:  t = AR + Adam / nchunks instead of AR + Adam.  Chunk boundaries are

@@ -181,3 +181,29 @@ def test_producer_pipelined_reducer_world_four_uneven_rows_and_a_changing_cloud(
     """dist.ProducerPipelinedReducer over four gloo ranks: row counts that are not multiples of 256 x chunks, a cloud
     that grows and shrinks between steps (densify / prune), every row exchanged exactly once before its Adam chunk."""
     mp.spawn(_producer_world4_worker, args=(4, _free_port(), ""), nprocs=4, join=True)
+
+
+def _direct_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from fsgs_amd import dist as fdist
+
+    fdist.init_from_env(backend="gloo")
+    red = fdist.DirectAllReduce()
+    scale = sum(q + 1 for q in range(world))
+    for P in (1024, 1037, 3, 1037, 64):  # multiples of 4 N floats and not; growing and shrinking (the buffers are re-made)
+        base = torch.arange(P * 14, dtype=torch.float32).reshape(P, 14) - 7.0
+        gc = base * (rank + 1)
+        red(gc)
+        assert torch.equal(gc, base * scale), P
+    with pytest.raises(ValueError):
+        red(torch.zeros(8, 14)[:, :7])  # a strided view cannot be reduced in place
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_reduce_scatter_all_gather_equals_all_reduce(world):
+    """dist.DirectAllReduce (all-to-all of shards, local sum, all-gather -- SURVEY.md s5's direct form for point-to-point
+    xGMI) gives the all-reduce's result in place, for element counts that need the padded staging path too."""
+    mp.spawn(_direct_worker, args=(world, _free_port(), ""), nprocs=world, join=True)

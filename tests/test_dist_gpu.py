@@ -71,6 +71,10 @@ def _worker(rank, world, port, out_dir, mode):
             assert all(pc.params[k].grad.data_ptr() == bucket.views[k].data_ptr() for k in PARAM_NAMES)
         elif mode == "compact":  # compact [P,14] gradient, one all-reduce, Adam from the compact form
             loss = fs.mapping_step([rank], reduce_compact=fdist.all_reduce_compact, corners=cr)
+        elif mode == "direct":  # the explicit direct form: all-to-all of shards, local sum, all-gather
+            red = getattr(_worker, "_direct", None) or fdist.DirectAllReduce()
+            _worker._direct = red
+            loss = fs.mapping_step([rank], reduce_compact=red, corners=cr)
         elif mode == "pipelined":  # the same in three row chunks, all-reduce of chunk i+1 beside the Adam kernel of chunk i
             loss = fs.mapping_step([rank], reduce_compact=fdist.PipelinedCompactReducer(3), corners=cr)
         else:  # producer-side: the per-Gaussian backward itself goes out in row chunks, each all-reduced as it is made
@@ -82,7 +86,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["compact", "pipelined", "producer", "bucket"])
+@pytest.mark.parametrize("mode", ["compact", "direct", "pipelined", "producer", "bucket"])
 def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
     from fsgs_amd.fast_step import FastStepper
     from fsgs_amd.model import PARAM_NAMES
@@ -120,12 +124,12 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     fdist.FORCE_COLLECTIVES = True
     results = {}
-    for mode in ("none", "compact", "pipelined", "producer"):
+    for mode in ("none", "compact", "direct", "pipelined", "producer"):
         pc, poses, frames, (H, W) = _world("cuda:0")
         cr = _corners(H, W, "cuda:0")
         fs = FastStepper(pc, poses, frames)
-        red = {"none": None, "compact": fdist.all_reduce_compact, "pipelined": fdist.PipelinedCompactReducer(3),
-               "producer": fdist.ProducerPipelinedReducer(3)}[mode]
+        red = {"none": None, "compact": fdist.all_reduce_compact, "direct": fdist.DirectAllReduce(),
+               "pipelined": fdist.PipelinedCompactReducer(3), "producer": fdist.ProducerPipelinedReducer(3)}[mode]
         for step in range(3):
             if mode == "none":
                 loss = fs.mapping_step([step % 2], reduce_compact=lambda t: None, corners=cr)  # compact route, no exchange
@@ -149,7 +153,7 @@ def test_every_exchange_route_runs_on_rccl_with_one_rank(tmp_path):
 
     mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(os.path.join(tmp_path, "rccl.pt"))
-    for mode in ("compact", "pipelined", "producer"):
+    for mode in ("compact", "direct", "pipelined", "producer"):
         # identity exchange: the same trajectory as without one, up to the arrival order of the backward's atomics
         assert abs(float(r[mode]["loss"]) - float(r["none"]["loss"])) <= 1e-5 * abs(float(r["none"]["loss"])), mode
         for k in PARAM_NAMES:
