@@ -19,7 +19,12 @@
  *   utils/general_utils.py:204-236        (quaternion -> R, Sigma = R S S^T R^T)
  * It is self-pinned by tests/test_oracle_raster.py: analytic single-Gaussian
  * image, occlusion order, the alpha/T thresholds, and fp64 central-difference
- * checks of every gradient (build with -DORACLE_F64).
+ * checks of every gradient (build with -DORACLE_F64); and the two statements of
+ * its maths that ARE in the reference tree are pinned to vectors captured from
+ * the imported reference (tests/golden/make_golden.py): the settings tuple of
+ * PoseModel.setup_camera (camera.npz -> tests/test_golden_host.py) and
+ * Sigma = R S S^T R^T of build_covariance_from_scaling_rotation
+ * (covariance.npz -> oracle_state_cov3D).  The rasteriser itself stays unpinned.
  *
  * Build:  see oracle/Makefile  (liboracle_f32.so / liboracle_f64.so)
  *
