@@ -34,6 +34,18 @@ def test_init_cloud_32k_matches_oracle(oracle32):
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("W,H,P", [(1280, 1024, 131072), (1920, 1080, 207360)])
+def test_full_size_init_clouds_match_the_oracle(oracle32, W, H, P):
+    """distCUDA2 on the first-frame clouds of BASELINE.json's C2 and C4 (10 % of the pixels back-projected,
+    scene/gaussian_model.py:237-258,346) against the brute-force definition at FULL size: 1.7e10 / 4.3e10 pair
+    evaluations, a few seconds on the cores the box grants."""
+    oracle32.set_threads(usable_cores())
+    sc = synth.init_scene(W, H, P, seed=0, knn_fn=lambda p: np.ones(len(p)))
+    got, want = _hip(sc["_xyz"]), oracle32.knn_meandist2(sc["_xyz"])
+    oracle32.set_threads(1)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+
+
 def test_known_answers():
     h = 0.25
     g = (np.stack(np.meshgrid(np.arange(7), np.arange(7), np.arange(7), indexing="ij"), -1).reshape(-1, 3) * h)
