@@ -39,6 +39,32 @@ def test_fused_adam_tracks_torch_adam(eps):
             assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * scale
 
 
+def test_fused_adam_at_c4_size_tracks_torch_adam():
+    """the same comparison at BASELINE.json's largest cloud (1 M Gaussians x 59 parameters = 236 MB per tensor set):
+    64-bit element offsets, the float4 body and every group's tail at a size where 32-bit indices would wrap."""
+    torch.manual_seed(1)
+    P = 1_000_003
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 3), (P, 4)]
+    lrs = [8e-4, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3]
+    a = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs)], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    for step in range(4):
+        for p, q in zip(a, b):
+            p.grad = torch.randn_like(p) * 10.0 ** (-step)
+            q.grad = p.grad.clone()
+        oa.step()
+        ob.step()
+    for p, q in zip(a, b):
+        assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item() + 1e-7
+        sa, sb = oa.state[p], ob.state[q]
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * sb[key].abs().max().item()
+        # the last elements of every tensor were reached
+        assert not torch.equal(p.detach()[-1], torch.zeros_like(p.detach()[-1]))
+
+
 def test_fused_adam_state_survives_densification_surgery():
     """cat_tensors_to_optimizer / prune replace params and slice the moments (scene/gaussian_model.py:523-580)."""
     p = torch.randn(100, 3, device=DEV).requires_grad_(True)
