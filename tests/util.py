@@ -73,7 +73,8 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
     counted and bounded too (max_fraction of the tensor's elements, default MAX_OUTLIER_FRACTION, with a floor of
     MIN_OUTLIER_COUNT for small tensors): a path that lost every near-tie would still be "witnessed" element by
     element, but not in a handful of places.
-    -> Attribution(elements beyond tol, elements with a non-zero allowance, size, outliers with got > want, < want)."""
+    -> Attribution(elements beyond tol, elements whose allowance reaches the plain tolerance, size, outliers with got > want,
+    < want)."""
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     amp = np.asarray(amp, np.float64)
@@ -98,7 +99,9 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
     assert err.max() <= cap * scale, "%s: worst error %g of the inf-norm exceeds the flip bound %g" % (
         what, err.max() / scale, cap)
     out = err > tol * scale
-    res = Attribution(int(out.sum()), int((amp > 0).sum()), int(got.size), int((diff[out] > 0).sum()),
+    # fragile = elements whose allowance is as large as the plain tolerance itself, i.e. where the witness can decide anything
+    # (the round-off term makes the allowance non-zero almost everywhere; what matters is where it is not negligible)
+    res = Attribution(int(out.sum()), int((factor * amp >= tol * scale).sum()), int(got.size), int((diff[out] > 0).sum()),
                       int((diff[out] < 0).sum()))
     ATTRIBUTION_LOG.append(dict(what=str(what), tag=None if tag is None else str(tag), **res._asdict()))
     frac = MAX_OUTLIER_FRACTION if max_fraction is None else max_fraction
