@@ -58,6 +58,15 @@ def _report(name, rec):
     dump_attribution_log("r03_full_size_parity", json.loads(line))
 
 
+def _assert_mostly_plain(stats, what):
+    """the allowances must stay the exception: at full size at most 6 % of a tensor's elements may have one that reaches
+    the plain tolerance (measured: images 0.5-1 %, gradients 1-4 %) -- everything else is held to 1e-4 with no excuse"""
+    for k, v in stats.items():
+        if v.size >= 100_000:
+            assert v.fragile <= 0.06 * v.size, "%s %s: %d of %d elements carry an allowance >= the tolerance" % (
+                what, k, v.fragile, v.size)
+
+
 def _summary(stats):
     return {k: dict(outliers=v.outliers, fragile=v.fragile, size=v.size, pos=v.pos, neg=v.neg,
                     witnessed_fraction=v.outliers / max(v.size, 1)) for k, v in stats.items()}
@@ -77,6 +86,7 @@ def test_rasteriser_at_the_operator_boundary_matches_the_oracle_at_full_size(ora
     n_log = len(ATTRIBUTION_LOG)
     R, stats = _compare(oracle_all_cores, cam, xyz, sh0_colors(sc), o.reshape(-1), s, r, seed=7, tag="%s/%s" % (cfg, pose))
     assert R > P
+    _assert_mostly_plain(stats, "raster op %s/%s" % (cfg, pose))
     # one near-tie moves an image element up or down with the colour behind it: no systematic sign over a full frame
     pos, neg, z, share = assert_sign_balanced(ATTRIBUTION_LOG[n_log:], "raster op %s/%s" % (cfg, pose))
     _report("raster_op", dict(cfg=cfg, pose=pose, P=P, num_rendered_upstream=R, tensors=_summary(stats),
@@ -104,6 +114,7 @@ def test_fused_render_matches_the_cpu_reference_render_at_full_size(oracle_all_c
     n_log = len(ATTRIBUTION_LOG)
     stats = _check_against_reference(oracle_all_cores, pc, poses, gs_grad, cam_grad, wi, wd, ws,
                                      fns=(render, render_two_pass), ctx="%s gs=%d cam=%d" % (cfg, gs_grad, cam_grad))
+    _assert_mostly_plain(stats, "render %s" % cfg)
     pos, neg, z, share = assert_sign_balanced(ATTRIBUTION_LOG[n_log:], "render %s" % cfg)
     _report("fused_render", dict(cfg=cfg, gs_grad=gs_grad, cam_grad=cam_grad, P=P, tensors=_summary(stats),
                                  sign_balance=dict(pos=pos, neg=neg, z=z, positive_share=share)))
