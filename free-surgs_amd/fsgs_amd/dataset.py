@@ -56,8 +56,10 @@ def normalise_monodepth(disparity):
     return (d - d.min()) / (d.max() - d.min()) * 1.0 + 0.5
 
 
-def read_sequence(source_path, frame_start=0, frame_end=-1, device="cuda", sample_rate=8):
-    """-> FrameData with colours / mono-depths / forward flows on `device`, the rescaled intrinsics, the ground-truth
+def read_sequence(source_path, frame_start=0, frame_end=-1, device="cuda", sample_rate=8, staged_capacity=None):
+    """-> FrameData with colours / mono-depths / forward flows on `device` (with `staged_capacity` = n: a
+    staging.StagedFrames instead -- the inputs in pinned host memory, n frames per lane resident on the device, the next
+    frame copied while the current one is optimised; for sequences beyond HBM), the rescaled intrinsics, the ground-truth
     "camera-pose" matrices (grouped per <data> run: data_ind offsets and weights as eval_pose uses them,
     train.py:492-506), backward flows, image names and the i_train / i_test split."""
     paths = list_frames(source_path, frame_start, frame_end)
@@ -83,8 +85,14 @@ def read_sequence(source_path, frame_start=0, frame_end=-1, device="cuda", sampl
     K[1, :] *= H / REF_H
     dev = torch.device(device)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev).contiguous()
-    fw = [t(f.reshape(-1, 2, H, W)[0]) for f in flows_fw]
-    frames = FrameData([t(c) for c in colors], [t(m) for m in monodeps], flows_fw=fw, K=K.astype(np.float32), gt_w2c=gt)
+    fw = [(t if staged_capacity is None else np.ascontiguousarray)(f.reshape(-1, 2, H, W)[0]) for f in flows_fw]
+    if staged_capacity is None:
+        frames = FrameData([t(c) for c in colors], [t(m) for m in monodeps], flows_fw=fw, K=K.astype(np.float32), gt_w2c=gt)
+    else:
+        from .staging import StagedFrames
+
+        frames = StagedFrames(colors, monodeps, flows_fw=fw, K=K.astype(np.float32), gt_w2c=gt, device=dev,
+                              capacity=staged_capacity)
     if sample_rate != 8:
         idx = np.arange(n)
         frames.i_test = idx[int(sample_rate / 2)::sample_rate]

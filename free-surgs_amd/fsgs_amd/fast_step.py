@@ -97,6 +97,10 @@ class FastStepper:
         dev = self.pc.params["_xyz"].device
         hw = None
         for name, seq, lead in (("colors", self.frames.colors, (3,)), ("monodeps", self.frames.monodeps, ())):
+            if hasattr(seq, "prefetch"):  # a staged lane (staging.py): contiguous float32 device buffers of one shape by construction
+                if seq.device != dev or (seq.shape is not None and len(seq.shape) != len(lead) + 2):
+                    raise ValueError("frames.%s is staged on %s with item shape %s" % (name, seq.device, seq.shape))
+                continue
             for i, t in enumerate(seq or []):
                 if t is None:
                     continue
@@ -426,6 +430,9 @@ class FastStepper:
             _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
             "fsgs_photometric_loss_forward_backward")
         side.wait_event(ctx["fwd_done"])
+        ready = getattr(self.frames.monodeps, "ready", None)  # a staged lane: the side stream reads the mono-depth too
+        if ready is not None and ready(ts) is not None:
+            side.wait_event(ready(ts))
         with torch.cuda.stream(side):
             sstream = _lib.current_stream()
             dep = b.depth_sil[0]

@@ -1,0 +1,165 @@
+"""Frame staging for sequences that do not fit in HBM: the per-frame inputs of
+PoseModel.record_data -- colours, mono-depths, forward flows (scene/pose_optimizer.py:441-460) -- live in PINNED host
+memory, a bounded set of frames is resident on the device, and the next frame is copied on a copy stream while the
+current one is being optimised.  The reference moves every frame's tensors host -> device inside every iteration
+(`.cuda()` at train.py:174,253,255,390-393); the resident `FrameData` (trainer.py) removes those copies altogether and
+stays the default -- 288 GB hold ~9 000 frames at 1280x1024 -- this is the path beyond that.
+
+`StagedLane` is list-like (len / [] / iteration), so it stands in for the lists of a FrameData without the step drivers
+noticing: lane[i] returns a device tensor that is valid on the CURRENT stream (it waits for the copy's event); a miss
+copies in order on the current stream.  Device buffers come from a fixed pool; when a buffer is taken from the least
+recently used frame, the copy stream first waits for an event recorded on the current stream AT THAT MOMENT -- every kernel
+that reads the old frame was enqueued before the eviction was decided (the step drivers join their view streams into
+the calling stream before they return), so the copy cannot overtake a reader.  On CPU tensors (the logic tests) the same
+bookkeeping runs with plain copies.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from .trainer import FrameData
+
+
+class StagedLane:
+    def __init__(self, host_items, device, capacity, copy_stream=None):
+        """host_items: list of equally shaped float32 CPU tensors (pinned when the device is a GPU) or None entries"""
+        self.host = list(host_items)
+        self.device = torch.device(device)
+        self.capacity = max(1, int(capacity))
+        self.copy_stream = copy_stream
+        self.cache = collections.OrderedDict()  # frame -> (device tensor, copy-done event or None), least recently used first
+        self.free = []
+        self.hits = self.misses = self.prefetched = 0
+        first = next((h for h in self.host if h is not None), None)
+        if first is not None:
+            for h in self.host:
+                if h is not None and (h.dtype != torch.float32 or tuple(h.shape) != tuple(first.shape) or not h.is_contiguous()):
+                    raise ValueError("a staged lane holds contiguous float32 tensors of one shape")
+            self.free = [torch.empty(first.shape, dtype=torch.float32, device=self.device)
+                         for _ in range(min(self.capacity, len(self.host)))]
+        self.shape = None if first is None else tuple(first.shape)
+
+    # ---- list protocol ----
+    def __len__(self):
+        return len(self.host)
+
+    def __iter__(self):
+        for i in range(len(self.host)):
+            yield self[i]
+
+    def _cuda(self):
+        return self.device.type == "cuda"
+
+    def _load(self, i, asynchronous):
+        evicted = not self.free
+        buf = self.free.pop() if self.free else self.cache.popitem(last=False)[1][0]
+        done = None
+        if self._cuda():
+            cur = torch.cuda.current_stream(self.device)
+            stream = self.copy_stream if (asynchronous and self.copy_stream is not None) else cur
+            if evicted and stream is not cur:
+                fence = torch.cuda.Event()  # everything enqueued so far may still read the evicted frame
+                fence.record(cur)
+                stream.wait_event(fence)
+            with torch.cuda.stream(stream):
+                buf.copy_(self.host[i], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(stream)
+        else:
+            buf.copy_(self.host[i])
+        self.cache[i] = (buf, done)
+
+    def prefetch(self, i):
+        """start copying frame i (no-op when it is resident, out of range or absent)"""
+        if i is None or i < 0 or i >= len(self.host) or self.host[i] is None:
+            return
+        if i in self.cache:
+            self.cache.move_to_end(i)
+            return
+        self._load(i, asynchronous=True)
+        self.prefetched += 1
+
+    def ready(self, i):
+        """the copy-done event of resident frame i (None on CPU or when it is not resident) for FURTHER streams that read
+        the tensor lane[i] returned -- lane[i] itself only makes the current stream wait"""
+        hit = self.cache.get(int(i))
+        return None if hit is None else hit[1]
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += len(self.host)
+        if self.host[i] is None:
+            return None
+        if i in self.cache:
+            self.hits += 1
+            self.cache.move_to_end(i)
+        else:
+            self.misses += 1
+            self._load(i, asynchronous=False)
+        buf, done = self.cache[i]
+        if done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
+        return buf
+
+
+class RecentWindow:
+    """list-like store of per-frame device tensors that keeps the `keep` most recently WRITTEN frames: the predicted depths
+    of record_data (train.py:216-222), of which tracking frame t reads frame t-1 only."""
+
+    def __init__(self, n, keep=4):
+        self.n, self.keep = int(n), max(1, int(keep))
+        self.items = collections.OrderedDict()
+
+    def __len__(self):
+        return self.n
+
+    def __setitem__(self, i, v):
+        i = int(i)
+        self.items.pop(i, None)
+        self.items[i] = v
+        while len(self.items) > self.keep:
+            self.items.popitem(last=False)
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return self.items.get(i)  # None = not written yet or already dropped, as a fresh record_data entry
+
+
+class StagedFrames(FrameData):
+    """FrameData whose colours / mono-depths / forward flows are StagedLanes over pinned host memory.  `capacity` frames
+    per lane stay on the device (>= 4: a tracking iteration reads frame t and the flows t-2, t-1; a two-view mapping
+    iteration a keyframe as well); `prefetch(t)` starts the copies frame t will need."""
+
+    def __init__(self, colors, monodeps, flows_fw=None, K=None, gt_w2c=None, device="cuda", capacity=8):
+        dev = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        pin = (lambda a: a.pin_memory()) if dev.type == "cuda" else (lambda a: a)
+        host = lambda seq: [None if a is None else pin(torch.as_tensor(np.ascontiguousarray(a) if not torch.is_tensor(a) else a)
+                                                       .detach().to("cpu", torch.float32).contiguous()) for a in seq]
+        cap = max(4, int(capacity))
+        lanes = [StagedLane(host(colors), dev, cap, self.copy_stream), StagedLane(host(monodeps), dev, cap, self.copy_stream)]
+        fw = None if flows_fw is None else StagedLane(host(flows_fw), dev, cap, self.copy_stream)
+        super().__init__(lanes[0], lanes[1], flows_fw=fw, K=K, gt_w2c=gt_w2c)
+        self.pred_depths = RecentWindow(len(lanes[0]), keep=cap)
+        self.device = dev
+
+    def prefetch(self, t):
+        """frame t's colours and mono-depth and the flows its tracking reads (t-1 -> t for the flow loss, t-2 -> t-1 for the
+        rigid mask; trainer.Runner.tracking)"""
+        if t is None:
+            return
+        self.colors.prefetch(t)
+        self.monodeps.prefetch(t)
+        if self.flows_fw is not None:
+            self.flows_fw.prefetch(t - 1)
+            self.flows_fw.prefetch(t - 2)
+
+    def stats(self):
+        lanes = {"colors": self.colors, "monodeps": self.monodeps, "flows_fw": self.flows_fw}
+        return {k: {"hits": v.hits, "misses": v.misses, "prefetched": v.prefetched} for k, v in lanes.items() if v is not None}

@@ -277,7 +277,7 @@ class Runner:
 
             self.fast = FastStepper(pc, poses, frames)
         self.log = []
-        H, W = frames.colors[0].shape[-2:]
+        H, W = (getattr(frames.colors, "shape", None) or frames.colors[0].shape)[-2:]  # a staged lane knows its item shape
         self.h, self.w = int(H), int(W)
 
     # ---- train.py:297-316 -------------------------------------------------------------------------------
@@ -347,7 +347,7 @@ class Runner:
 
         # Sampson-distance rigid mask of frame t-2 under the optimised poses t-2, t-1 (train.py:157-165); all rigid
         # for t <= 1.  Once per frame: two launches (csrc/flow.hip), no sync beyond reading the two 4x4 poses.
-        dev = self.frames.colors[0].device
+        dev = self._frames_device()
         rigid = None
         if t > 1 and self.frames.flows_fw is not None:
             from .epipolar import fundamental_from_w2c, rigid_mask
@@ -385,6 +385,7 @@ class Runner:
         with torch.no_grad():
             self.poses.get_pose(0)
         for t in range(n):
+            self._prefetch(t + 1)  # staged sequences (fsgs_amd/staging.py): the next frame's inputs travel while this one is optimised
             self.pc.update_learning_rate(self.iteration)
             if t > 0:
                 if t > 1:
@@ -406,11 +407,19 @@ class Runner:
             elif self.frames.pred_depths[t] is None:
                 if self.test_frame_quirks:  # never rendered upstream: the next frame's flow loss sees no valid depth
                     self.frames.pred_depths[t] = torch.zeros((self.h, self.w), dtype=torch.float32,
-                                                             device=self.frames.colors[0].device)
+                                                             device=self._frames_device())
                 else:
                     with torch.no_grad():
                         pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
                     self.frames.pred_depths[t] = self._stored_depth(pkg)
+
+    def _prefetch(self, t):
+        pf = getattr(self.frames, "prefetch", None)
+        if pf is not None and t is not None and 0 <= t < len(self.frames.colors):
+            pf(int(t))
+
+    def _frames_device(self):
+        return getattr(self.frames, "device", None) or self.frames.colors[0].device
 
     def _stored_depth(self, pkg):
         d = pkg["render_dep"].detach().float()
@@ -428,8 +437,13 @@ class Runner:
         (train.py:437-443, checkpoint.py)."""
         self.pc.initialize_optimizer()
         self.eval_log = getattr(self, "eval_log", [])
+        # the frame of iteration it + 1 is drawn while iteration it is set up (the same draws in the same order: nothing else
+        # takes from self.rng in this loop), so that a staged sequence can start its copy one iteration ahead
+        nxt = int(self.rng.choice(list(self.frames.i_train))) if iterations + 1 > int(first_iter) else None
         for it in range(int(first_iter), iterations + 1):
-            ts = int(self.rng.choice(list(self.frames.i_train)))
+            ts = nxt
+            nxt = int(self.rng.choice(list(self.frames.i_train))) if it < iterations else None
+            self._prefetch(nxt)
             if it % 1000 == 0:
                 self.pc.oneupSHdegree()
             self.pc.update_learning_rate(it)

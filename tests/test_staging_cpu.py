@@ -1,0 +1,123 @@
+"""Bookkeeping of the frame-staging path (fsgs_amd/staging.py) on CPU tensors: residency, least-recently-used eviction,
+hit / miss / prefetch counters, the list protocol the step drivers rely on, and that Runner.global_run draws its frames in
+the order of the reference's loop (train.py:378-384: one random.choice per iteration) although it now draws one iteration
+ahead for the prefetch."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from fsgs_amd.staging import RecentWindow, StagedFrames, StagedLane
+
+
+def _items(n, shape=(3, 4, 5)):
+    return [torch.full(shape, float(i)) for i in range(n)]
+
+
+def test_lane_is_list_like_and_returns_the_frames_it_was_given():
+    lane = StagedLane(_items(6), "cpu", capacity=3)
+    assert len(lane) == 6 and lane.shape == (3, 4, 5)
+    assert [float(t[0, 0, 0]) for t in lane] == [0, 1, 2, 3, 4, 5]
+    assert float(lane[-1].mean()) == 5.0
+    assert lane.misses == 6 and lane.hits == 1  # the iteration missed everywhere (capacity 3 of 6); [-1] found frame 5 resident
+
+
+def test_least_recently_used_frame_is_the_one_replaced():
+    lane = StagedLane(_items(8), "cpu", capacity=3)
+    a, b, c = lane[0], lane[1], lane[2]
+    lane[0]                      # touch 0: frame 1 is now the oldest
+    lane[3]                      # takes frame 1's buffer
+    assert set(lane.cache) == {0, 2, 3} and float(b.mean()) == 3.0  # the buffer object was reused, as on the device
+    assert float(a.mean()) == 0.0 and float(c.mean()) == 2.0
+    assert (lane.hits, lane.misses) == (1, 4)
+
+
+def test_prefetch_turns_the_following_lookup_into_a_hit():
+    lane = StagedLane(_items(5), "cpu", capacity=3)  # (with 2, frame 0's miss after prefetch(1) would leave 1 the oldest)
+    for t in range(5):
+        lane.prefetch(t + 1)     # one past the end and the frames already resident are no-ops
+        assert float(lane[t].mean()) == float(t)
+    assert lane.misses == 1 and lane.hits == 4 and lane.prefetched == 4
+    lane.prefetch(-1)
+    lane.prefetch(None)
+    assert lane.prefetched == 4
+
+
+def test_absent_entries_and_mismatched_shapes():
+    lane = StagedLane([None, torch.ones(2, 2), None], "cpu", capacity=4)
+    assert lane[0] is None and lane[2] is None and float(lane[1].sum()) == 4.0
+    lane.prefetch(0)
+    assert lane.prefetched == 0
+    with pytest.raises(ValueError, match="one shape"):
+        StagedLane([torch.ones(2, 2), torch.ones(2, 3)], "cpu", capacity=2)
+    with pytest.raises(ValueError, match="float32"):
+        StagedLane([torch.ones(2, 2, dtype=torch.float64)], "cpu", capacity=2)
+    assert len(StagedLane([], "cpu", capacity=2)) == 0
+
+
+def test_recent_window_keeps_the_last_written_frames():
+    w = RecentWindow(10, keep=3)
+    assert len(w) == 10 and w[4] is None
+    for t in range(6):
+        w[t] = torch.tensor(float(t))
+    assert [None if w[t] is None else float(w[t]) for t in range(6)] == [None, None, None, 3.0, 4.0, 5.0]
+    w[4] = torch.tensor(40.0)    # rewriting refreshes the entry
+    w[6] = torch.tensor(6.0)
+    assert w[3] is None and float(w[4]) == 40.0 and float(w[-4]) == 6.0
+    with pytest.raises(IndexError):
+        w[10]
+
+
+def test_staged_frames_prefetch_covers_what_tracking_a_frame_reads():
+    n, H, W = 9, 4, 6
+    rng = np.random.default_rng(0)
+    cols = [rng.random((3, H, W), dtype=np.float32) for _ in range(n)]
+    deps = [rng.random((H, W), dtype=np.float32) for _ in range(n)]
+    fws = [rng.random((2, H, W), dtype=np.float32) for _ in range(n - 1)]
+    fr = StagedFrames(cols, deps, flows_fw=fws, K=np.eye(3, dtype=np.float32), device="cpu", capacity=4)
+    assert list(fr.i_test) == [4] and len(fr.pred_depths) == n and fr.pred_depths[0] is None
+    fr.prefetch(3)
+    assert set(fr.colors.cache) == {3} and set(fr.monodeps.cache) == {3} and set(fr.flows_fw.cache) == {1, 2}
+    np.testing.assert_array_equal(fr.colors[3].numpy(), cols[3])
+    np.testing.assert_array_equal(fr.flows_fw[2].numpy(), fws[2])
+    np.testing.assert_array_equal(fr.flows_fw[1].numpy(), fws[1])
+    np.testing.assert_array_equal(fr.monodeps[3].numpy(), deps[3])
+    st = fr.stats()
+    assert all(v["misses"] == 0 for v in st.values()) and st["flows_fw"] == {"hits": 2, "misses": 0, "prefetched": 2}
+    fr.prefetch(0)               # frame 0 has no earlier flows
+    fr.prefetch(n)               # past the end: colours / depths ignore it, the flows n-1 .. n-2 exist only partly
+    assert set(fr.flows_fw.cache) == {1, 2, n - 2}
+
+
+def test_global_run_draws_the_frames_in_the_reference_order_and_prefetches_one_iteration_ahead():
+    from fsgs_amd.trainer import Runner
+
+    class Frames:
+        i_train = np.array([0, 1, 2, 3, 5, 6, 7])
+        i_test = np.array([], dtype=int)
+        colors = [None] * 8
+
+        def __init__(self):
+            self.events = []
+
+        def prefetch(self, t):
+            self.events.append(("prefetch", t))
+
+    class Cloud:
+        def initialize_optimizer(self): pass
+        def oneupSHdegree(self): pass
+        def update_learning_rate(self, it): pass
+
+    run = Runner.__new__(Runner)
+    run.rng, run.frames, run.pc = random.Random(7), Frames(), Cloud()
+    run.mapping = lambda ts, views, progressive: run.frames.events.append(("map", ts))
+    run.global_run(11, eval_every=0)
+    want_rng = random.Random(7)
+    want = [int(want_rng.choice(list(Frames.i_train))) for _ in range(12)]  # range(0, iterations + 1): 12 steps
+    ev = run.frames.events
+    assert [t for k, t in ev if k == "map"] == want
+    assert [t for k, t in ev if k == "prefetch"] == want[1:]
+    for i in range(11):  # the copy of step i + 1 is started before step i is enqueued
+        assert ev[2 * i] == ("prefetch", want[i + 1]) and ev[2 * i + 1] == ("map", want[i])
+    assert run.rng.random() == want_rng.random()  # not one draw more than the reference's loop

@@ -1,0 +1,107 @@
+"""Frame staging on the device (fsgs_amd/staging.py): the harness on a sequence whose inputs live in
+pinned host memory with four frames resident must do what it does on the resident sequence, the copies must never
+overtake a reader of the buffer they replace, and the next frame must be there when its tracking starts."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _staged_copy(frames, capacity):
+    from fsgs_amd.staging import StagedFrames
+
+    st = StagedFrames([c.cpu() for c in frames.colors], [m.cpu() for m in frames.monodeps],
+                      flows_fw=[f.cpu() for f in frames.flows_fw], K=frames.K, gt_w2c=frames.gt_w2c, device="cuda",
+                      capacity=capacity)
+    assert all(h.is_pinned() for h in st.colors.host) and st.copy_stream is not None
+    return st
+
+
+def test_copies_never_overtake_the_readers_of_the_buffer_they_replace():
+    """one pass over 40 frames through 4 device buffers with the next frame prefetched on the copy stream while a long
+    chain of kernels still reads the current one: every frame's checksum must be its own"""
+    from fsgs_amd.staging import StagedLane
+
+    n, shape = 40, (3, 512, 640)
+    g = torch.Generator().manual_seed(0)
+    host = [torch.rand(shape, generator=g).pin_memory() for _ in range(n)]
+    want = [float(h.double().sum()) for h in host]
+    lane = StagedLane(host, "cuda", capacity=4, copy_stream=torch.cuda.Stream())
+    sums = []
+    for rep in range(2):
+        order = list(range(n)) if rep == 0 else list(np.random.default_rng(1).permutation(n))
+        for k, t in enumerate(order):
+            if k + 1 < n:
+                lane.prefetch(order[k + 1])
+            x = lane[t]
+            acc = x.double()
+            for _ in range(20):          # keep the stream busy on x long after the next prefetch was issued
+                acc = acc * 1.0 + (x.double() - x.double())
+            sums.append((t, acc.sum()))
+    torch.cuda.synchronize()
+    for t, s in sums:
+        assert abs(float(s) - want[t]) <= 1e-9 * want[t], t
+    assert lane.misses == 2 and lane.prefetched >= 2 * (n - 1) - 4  # the first frame of either pass; a few were still resident
+
+
+def test_harness_on_a_staged_sequence_follows_the_resident_run():
+    from fsgs_amd.sequence import learner_from_first_frame, make_sequence
+    from fsgs_amd.trainer import PoseTrack, Runner
+
+    W, H, n = 320, 256, 7
+    runs = []
+    for staged in (False, True):
+        torch.manual_seed(0)
+        frames, cam = make_sequence(W, H, n, P=40000, seed=1)
+        resident = frames
+        if staged:
+            frames = _staged_copy(frames, capacity=4)
+        pc = learner_from_first_frame(resident, cam, ratio=0.25)
+        poses = PoseTrack(n, "cuda")
+        run = Runner(pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=100, row0_depth_quirk=False)
+        run.progressive_run()
+        run.global_run(20, eval_every=10)
+        torch.cuda.synchronize()
+        runs.append((run, frames, resident, pc, poses))
+    (ra, fa, _, pca, posa), (rb, fb, res_b, pcb, posb) = runs
+    # the data the steps saw is the data of the resident run, whatever moved through the four buffers meanwhile
+    for i in range(n):
+        assert torch.equal(fb.colors[i], res_b.colors[i]) and torch.equal(fb.monodeps[i], res_b.monodeps[i])
+    for i in range(n - 1):
+        assert torch.equal(fb.flows_fw[i], res_b.flows_fw[i])
+    # the trajectory: same sizes, poses and quality (the runs differ by the order of floating-point atomics only)
+    assert pca.num_points == pcb.num_points
+    ea, eb = np.array(ra.eval_pose()), np.array(rb.eval_pose())
+    gt = np.stack(fa.gt_w2c)
+    step = np.mean([np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(n - 1)])
+    assert eb[0] < 0.25 * step and eb[2] < 0.25 * step and abs(ea[0] - eb[0]) < 0.05 * step, (ea, eb, step)
+    assert (posa.t - posb.t).abs().max().item() < 0.05 * step
+    pa, pb = [m["psnr"] for _, m in ra.eval_log], [m["psnr"] for _, m in rb.eval_log]
+    assert len(pb) == 3 and all(abs(x - y) < 0.3 for x, y in zip(pa, pb)), (pa, pb)
+    # staging did its job: tracking / mapping of frame t found its inputs prefetched (the misses are frame 0, the random
+    # keyframes of the two-view mapping steps that had left the four buffers, and the test frame at validation)
+    st = fb.stats()
+    print("staged run:", st)
+    assert st["colors"]["prefetched"] >= n - 1 and st["flows_fw"]["misses"] == 0
+    assert st["colors"]["hits"] > 20 * st["colors"]["misses"]
+    assert fb.pred_depths[n - 1] is not None and fb.pred_depths[1] is None  # only the recent depths are kept
+
+
+def test_read_sequence_can_stage(tmp_path):
+    from fsgs_amd import dataset
+    from fsgs_amd.sequence import make_sequence, write_frames
+    from fsgs_amd.staging import StagedFrames
+
+    synth_frames, _ = make_sequence(320, 256, 5, P=20000, seed=3)
+    root = str(tmp_path / "scared_demo")
+    write_frames(root, synth_frames)
+    a = dataset.read_sequence(root, device="cuda")
+    b = dataset.read_sequence(root, device="cuda", staged_capacity=4)
+    assert isinstance(b, StagedFrames) and not isinstance(a, StagedFrames)
+    for i in range(5):
+        assert torch.equal(a.colors[i], b.colors[i]) and torch.equal(a.monodeps[i], b.monodeps[i])
+    for i in range(4):
+        assert torch.equal(a.flows_fw[i], b.flows_fw[i])
+    np.testing.assert_array_equal(a.K, b.K)
+    assert list(a.i_train) == list(b.i_train) and a.scene == b.scene and a.data_ind == b.data_ind
