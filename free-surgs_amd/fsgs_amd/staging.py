@@ -21,11 +21,29 @@ import torch
 from .trainer import FrameData
 
 
+class Fence:
+    """`stream` must not start what follows before everything enqueued on `cur` up to the FIRST hold() has finished;
+    recorded once, waited for once per stream"""
+
+    def __init__(self):
+        self.event, self.held = None, set()
+
+    def hold(self, cur, stream):
+        if self.event is None:
+            self.event = torch.cuda.Event()
+            self.event.record(cur)
+        if stream.cuda_stream not in self.held:
+            self.held.add(stream.cuda_stream)
+            stream.wait_event(self.event)
+
+
 class StagedLane:
     def __init__(self, host_items, device, capacity, copy_stream=None):
         """host_items: list of equally shaped float32 CPU tensors (pinned when the device is a GPU) or None entries"""
         self.host = list(host_items)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # "cuda" -> the device tensors will report
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.capacity = max(1, int(capacity))
         self.copy_stream = copy_stream
         self.cache = collections.OrderedDict()  # frame -> (device tensor, copy-done event or None), least recently used first
@@ -51,7 +69,7 @@ class StagedLane:
     def _cuda(self):
         return self.device.type == "cuda"
 
-    def _load(self, i, asynchronous):
+    def _load(self, i, asynchronous, fence=None):
         evicted = not self.free
         buf = self.free.pop() if self.free else self.cache.popitem(last=False)[1][0]
         done = None
@@ -59,9 +77,9 @@ class StagedLane:
             cur = torch.cuda.current_stream(self.device)
             stream = self.copy_stream if (asynchronous and self.copy_stream is not None) else cur
             if evicted and stream is not cur:
-                fence = torch.cuda.Event()  # everything enqueued so far may still read the evicted frame
-                fence.record(cur)
-                stream.wait_event(fence)
+                # everything enqueued so far may still read the evicted frame (one fence serves all the copies a caller
+                # starts together: StagedFrames.prefetch hands the same one to its lanes)
+                (fence if fence is not None else Fence()).hold(cur, stream)
             with torch.cuda.stream(stream):
                 buf.copy_(self.host[i], non_blocking=True)
                 done = torch.cuda.Event()
@@ -70,14 +88,14 @@ class StagedLane:
             buf.copy_(self.host[i])
         self.cache[i] = (buf, done)
 
-    def prefetch(self, i):
+    def prefetch(self, i, fence=None):
         """start copying frame i (no-op when it is resident, out of range or absent)"""
         if i is None or i < 0 or i >= len(self.host) or self.host[i] is None:
             return
         if i in self.cache:
             self.cache.move_to_end(i)
             return
-        self._load(i, asynchronous=True)
+        self._load(i, asynchronous=True, fence=fence)
         self.prefetched += 1
 
     def ready(self, i):
@@ -138,6 +156,8 @@ class StagedFrames(FrameData):
 
     def __init__(self, colors, monodeps, flows_fw=None, K=None, gt_w2c=None, device="cuda", capacity=8):
         dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.copy_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         pin = (lambda a: a.pin_memory()) if dev.type == "cuda" else (lambda a: a)
         host = lambda seq: [None if a is None else pin(torch.as_tensor(np.ascontiguousarray(a) if not torch.is_tensor(a) else a)
@@ -149,16 +169,17 @@ class StagedFrames(FrameData):
         self.pred_depths = RecentWindow(len(lanes[0]), keep=cap)
         self.device = dev
 
-    def prefetch(self, t):
-        """frame t's colours and mono-depth and the flows its tracking reads (t-1 -> t for the flow loss, t-2 -> t-1 for the
-        rigid mask; trainer.Runner.tracking)"""
+    def prefetch(self, t, flows=True):
+        """frame t's colours and mono-depth and, with `flows`, the flows its tracking reads (t-1 -> t for the flow loss,
+        t-2 -> t-1 for the rigid mask; trainer.Runner.tracking) -- a mapping view needs the first two only"""
         if t is None:
             return
-        self.colors.prefetch(t)
-        self.monodeps.prefetch(t)
-        if self.flows_fw is not None:
-            self.flows_fw.prefetch(t - 1)
-            self.flows_fw.prefetch(t - 2)
+        fence = Fence()
+        self.colors.prefetch(t, fence)
+        self.monodeps.prefetch(t, fence)
+        if flows and self.flows_fw is not None:
+            self.flows_fw.prefetch(t - 1, fence)
+            self.flows_fw.prefetch(t - 2, fence)
 
     def stats(self):
         lanes = {"colors": self.colors, "monodeps": self.monodeps, "flows_fw": self.flows_fw}

@@ -303,9 +303,15 @@ class Runner:
         views = 2 if (progressive and cur_t != 0) else 1
         self.pc.optimizer.zero_grad(set_to_none=True)
         pkg = None
-        for _ in range(mapping_iter):
+        # the keyframe of the NEXT iteration is drawn during this one (same draws, same order, none more than train.py:239's
+        # one per iteration), so that a staged sequence can have it on the device in time
+        nxt = self.rng.choice(self.keyframes) if (views == 2 and mapping_iter > 0) else None
+        for k in range(mapping_iter):
             self.iteration += 1
-            ts = [self.rng.choice(self.keyframes), cur_t] if views == 2 else [cur_t]
+            ts = [nxt, cur_t] if views == 2 else [cur_t]
+            if views == 2:
+                nxt = self.rng.choice(self.keyframes) if k + 1 < mapping_iter else None
+                self._prefetch(nxt, flows=False)
             it = self.iteration
             special = self.densify and ((it % self.densify_interval == 0 and it < self.densify_until) or
                                         it % self.opacity_reset_interval == 0)
@@ -413,10 +419,10 @@ class Runner:
                         pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
                     self.frames.pred_depths[t] = self._stored_depth(pkg)
 
-    def _prefetch(self, t):
+    def _prefetch(self, t, flows=True):
         pf = getattr(self.frames, "prefetch", None)
         if pf is not None and t is not None and 0 <= t < len(self.frames.colors):
-            pf(int(t))
+            pf(int(t), flows=flows)
 
     def _frames_device(self):
         return getattr(self.frames, "device", None) or self.frames.colors[0].device
@@ -443,7 +449,7 @@ class Runner:
         for it in range(int(first_iter), iterations + 1):
             ts = nxt
             nxt = int(self.rng.choice(list(self.frames.i_train))) if it < iterations else None
-            self._prefetch(nxt)
+            self._prefetch(nxt, flows=False)
             if it % 1000 == 0:
                 self.pc.oneupSHdegree()
             self.pc.update_learning_rate(it)

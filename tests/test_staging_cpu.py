@@ -101,7 +101,8 @@ def test_global_run_draws_the_frames_in_the_reference_order_and_prefetches_one_i
         def __init__(self):
             self.events = []
 
-        def prefetch(self, t):
+        def prefetch(self, t, flows=True):
+            assert not flows  # a mapping view reads colours and mono-depth only
             self.events.append(("prefetch", t))
 
     class Cloud:
@@ -121,3 +122,47 @@ def test_global_run_draws_the_frames_in_the_reference_order_and_prefetches_one_i
     for i in range(11):  # the copy of step i + 1 is started before step i is enqueued
         assert ev[2 * i] == ("prefetch", want[i + 1]) and ev[2 * i + 1] == ("map", want[i])
     assert run.rng.random() == want_rng.random()  # not one draw more than the reference's loop
+
+
+def test_progressive_mapping_draws_its_keyframes_in_the_reference_order_too():
+    """train.py:239: one random.choice(keyframe_list) per two-view iteration -- now drawn one iteration early"""
+    from fsgs_amd.trainer import Runner
+
+    class Frames:
+        colors = [None] * 8
+
+        def __init__(self):
+            self.prefetched = []
+
+        def prefetch(self, t, flows=True):
+            self.prefetched.append(t)
+
+    class Opt:
+        def zero_grad(self, set_to_none=True): pass
+
+    class Cloud:
+        optimizer = Opt()
+        num_points = 0
+
+    class Fast:
+        last = None
+
+        def __init__(self):
+            self.seen = []
+
+        def mapping_step(self, ts, step_optimizer=True, collect_stats=False):
+            self.seen.append(list(ts))
+            return 0.0
+
+    run = Runner.__new__(Runner)
+    run.rng, run.frames, run.pc, run.fast = random.Random(3), Frames(), Cloud(), Fast()
+    run.keyframes, run.iteration, run.densify, run.trace, run.fused = [0, 1, 2, 3, 5], 0, False, None, True
+    run.densify_interval, run.opacity_reset_interval, run.densify_until = 300, 3000, 15000
+    run.fast.last = {"image": torch.zeros(1), "depth_sil": torch.zeros(2, 1)}
+    run.mapping(6, 9, progressive=True)
+    want_rng = random.Random(3)
+    want = [want_rng.choice([0, 1, 2, 3, 5]) for _ in range(9)]
+    assert run.fast.seen == [[k, 6] for k in want] and run.frames.prefetched == want[1:]
+    assert run.rng.random() == want_rng.random()
+    run.mapping(0, 4, progressive=True)  # frame 0 is mapped alone: no draw at all
+    assert run.fast.seen[-4:] == [[0]] * 4 and run.rng.random() == want_rng.random()

@@ -63,6 +63,7 @@ def test_harness_on_a_staged_sequence_follows_the_resident_run():
         run.progressive_run()
         run.global_run(20, eval_every=10)
         torch.cuda.synchronize()
+        st = frames.stats() if staged else None  # before the checks below look every frame up again
         runs.append((run, frames, resident, pc, poses))
     (ra, fa, _, pca, posa), (rb, fb, res_b, pcb, posb) = runs
     # the data the steps saw is the data of the resident run, whatever moved through the four buffers meanwhile
@@ -75,13 +76,16 @@ def test_harness_on_a_staged_sequence_follows_the_resident_run():
     ea, eb = np.array(ra.eval_pose()), np.array(rb.eval_pose())
     gt = np.stack(fa.gt_w2c)
     step = np.mean([np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(n - 1)])
-    assert eb[0] < 0.25 * step and eb[2] < 0.25 * step and abs(ea[0] - eb[0]) < 0.05 * step, (ea, eb, step)
-    assert (posa.t - posb.t).abs().max().item() < 0.05 * step
+    # (three RESIDENT runs of this short sequence, scripts/dev/staging_repro.py: max |t| apart by up to 1.05e-3 = 0.2 GT steps,
+    # RPE_t 5.0e-4 .. 6.5e-4, test-frame PSNR after the global phase 47.8 .. 50.9 dB -- the order of the float atomics,
+    # amplified by 50-iteration trackings on a 100-iteration map; three staged runs: 0.7e-3 .. 1.1e-3, 4.8e-4 .. 5.0e-4,
+    # 48.8 .. 50.5 dB.  The exact statement about staging is the data check above and the fence test.)
+    assert eb[0] < 0.25 * step and eb[2] < 0.25 * step and abs(ea[0] - eb[0]) < 0.1 * step, (ea, eb, step)
+    assert (posa.t - posb.t).abs().max().item() < 0.5 * step
     pa, pb = [m["psnr"] for _, m in ra.eval_log], [m["psnr"] for _, m in rb.eval_log]
-    assert len(pb) == 3 and all(abs(x - y) < 0.3 for x, y in zip(pa, pb)), (pa, pb)
+    assert len(pb) == 3 and all(abs(x - y) < 5.0 and y > 40.0 for x, y in zip(pa, pb)), (pa, pb)
     # staging did its job: tracking / mapping of frame t found its inputs prefetched (the misses are frame 0, the random
     # keyframes of the two-view mapping steps that had left the four buffers, and the test frame at validation)
-    st = fb.stats()
     print("staged run:", st)
     assert st["colors"]["prefetched"] >= n - 1 and st["flows_fw"]["misses"] == 0
     assert st["colors"]["hits"] > 20 * st["colors"]["misses"]
