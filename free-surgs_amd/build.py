@@ -18,6 +18,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
     "-ffp-contract=on", "-Wno-unused-result", "-DNDEBUG",
+    # no SLP vectoriser: where two FMAs belong in one v_pk_fma_f32 the kernels say so (float2v); the pairs the vectoriser
+    # forms on its own need register shuffles -- and, in streaming loops, copies of loads still in flight -- that cost
+    # blend_bwd 5 % and exposed a memory round trip per row in photometric_bwd (DESIGN s3, round 3)
+    "-fno-slp-vectorize",
 ]
 # FSGS_DIAG=1: the diagnostics hooks of csrc/raster_kernels.h (diag_env) -- experiments only, objects kept apart
 DIAG = os.environ.get("FSGS_DIAG") == "1"

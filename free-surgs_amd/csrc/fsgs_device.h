@@ -12,6 +12,8 @@
 
 namespace fsgs {
 
+typedef float float2v __attribute__((ext_vector_type(2)));  // a register pair: elementwise fma on it is one v_pk_fma_f32
+
 // ---- scalar broadcast of one lane's value (v_readlane_b32: the index must be wave-uniform) ----
 __device__ __forceinline__ float readlane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));

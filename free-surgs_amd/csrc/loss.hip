@@ -22,6 +22,12 @@ using namespace fsgs;
 
 namespace {
 
+#ifdef FSGS_EXP_LOSS_DYNLDS  // experiment builds only: unused dynamic LDS = fewer workgroups of the forward kernel per CU
+constexpr int kFwdDynLds = FSGS_EXP_LOSS_DYNLDS;
+#else
+constexpr int kFwdDynLds = 0;
+#endif
+
 constexpr int SS_TILE = 32;            // output tile edge
 constexpr int SS_HALO = 5;             // 11-tap window
 constexpr int SS_IN = SS_TILE + 2 * SS_HALO;  // 42
@@ -62,12 +68,28 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
                                                               const float *__restrict__ presence,
                                                               float *__restrict__ maps,
                                                               float *__restrict__ partials) {
-  __shared__ float sx[SS_IN][SS_IN + 1];
-  __shared__ float sy[SS_IN][SS_IN + 1];
-  __shared__ float hz[5][SS_IN][SS_TILE + 1];
+  // image and target of a pixel side by side, the moments as two pairs: one 8-byte LDS access moves a pair and the 11-tap
+  // filters of a pair are one v_pk_fma_f32 per tap, each component still accumulating its taps in the order k = 0..10.
+  // SSIM needs the two second moments e11 = G*x^2 and e22 = G*y^2 only as their SUM (sigma1^2 + sigma2^2 =
+  // e11 + e22 - m1^2 - m2^2, utils/loss_utils.py:76-81), so FOUR filters are run, not five: (m1, m2) and (e11 + e22, e12).
+  // That is a fifth of the filter work and, more to the point, 36.6 KB of LDS instead of 42.2: four workgroups per CU instead
+  // of three, for a kernel whose time follows its occupancy (1 / 2 / 3 workgroups per CU: 82 / 57 / 44 us, see DESIGN)
+  __shared__ float2v sxy[SS_IN][SS_IN + 1];           // (x, y)
+  __shared__ float2v hz_m[SS_IN][SS_TILE + 1];        // horizontal pass of (m1, m2)
+  __shared__ float2v hz_s[SS_IN][SS_TILE + 1];        //                    (e11 + e22, e12)
   __shared__ float red[4];
-  const int ch = blockIdx.z;
-  const int x0 = blockIdx.x * SS_TILE, y0 = blockIdx.y * SS_TILE;
+  // XCD-aware placement: the launch is one-dimensional and block b runs on XCD b % 8 (observed; speed only), so every XCD
+  // is handed one contiguous run of tiles in (channel, row, column) order -- a band of the image -- and the 5-pixel halos
+  // two neighbouring tiles both read meet in ONE L2 instead of being fetched over the fabric by two of them
+  const int tiles_x = (W + SS_TILE - 1) / SS_TILE, tiles_y = (H + SS_TILE - 1) / SS_TILE;
+#ifdef FSGS_EXP_LOSS_NO_XCD
+  const int tile_id = blockIdx.x;
+#else
+  const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+#endif
+  const int ch = tile_id / (tiles_x * tiles_y), in_plane = tile_id - ch * (tiles_x * tiles_y);
+  const int tile_y = in_plane / tiles_x, tile_x = in_plane - tile_y * tiles_x;
+  const int x0 = tile_x * SS_TILE, y0 = tile_y * SS_TILE;
   const size_t plane = (size_t)H * W;
   const float *ip = img + ch * plane, *gp = gt + ch * plane;
   // every global load of the (tile + halo) window is issued before the first is waited for: a rolled loop with the
@@ -94,10 +116,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
     const int ly = i / SS_IN, lx = i - ly * SS_IN;
     float m = mask ? vm[r] : 1.0f;  // pixel_mask()
     if (presence) m = vp[r] > 0.f ? m : 0.f;
-    if (i < SS_IN * SS_IN) {
-      sx[ly][lx] = inb[r] ? va[r] * m : 0.f;
-      sy[ly][lx] = inb[r] ? vb[r] * m : 0.f;
-    }
+    if (i < SS_IN * SS_IN) sxy[ly][lx] = inb[r] ? float2v{va[r] * m, vb[r] * m} : float2v{0.f, 0.f};
   }
   __syncthreads();
   // Both 11-tap passes are register-blocked: a thread produces SS_BLK consecutive outputs from SS_BLK + 10 inputs
@@ -106,29 +125,23 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   // horizontal pass of the five moments: SS_IN rows x (SS_TILE / SS_BLK) segments
   for (int task = threadIdx.x; task < SS_IN * (SS_TILE / SS_BLK); task += 256) {
     const int ly = task / (SS_TILE / SS_BLK), lx = (task - ly * (SS_TILE / SS_BLK)) * SS_BLK;
-    float a[SS_BLK + 10], b[SS_BLK + 10], aa[SS_BLK + 10], bb[SS_BLK + 10], ab[SS_BLK + 10];
+    float2v ab[SS_BLK + 10], sq[SS_BLK + 10];
 #pragma unroll
     for (int j = 0; j < SS_BLK + 10; j++) {
-      a[j] = sx[ly][lx + j];
-      b[j] = sy[ly][lx + j];
-      aa[j] = a[j] * a[j];
-      bb[j] = b[j] * b[j];
-      ab[j] = a[j] * b[j];
+      ab[j] = sxy[ly][lx + j];
+      sq[j] = float2v{ab[j].x * ab[j].x + ab[j].y * ab[j].y, ab[j].x * ab[j].y};
     }
 #pragma unroll
     for (int o = 0; o < SS_BLK; o++) {
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+      float2v m = {0.f, 0.f}, e = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 11; k++) {
-        const float g = kGauss[k];
-        m1 = fmaf(g, a[o + k], m1);
-        m2 = fmaf(g, b[o + k], m2);
-        e11 = fmaf(g, aa[o + k], e11);
-        e22 = fmaf(g, bb[o + k], e22);
-        e12 = fmaf(g, ab[o + k], e12);
+        const float2v g2 = {kGauss[k], kGauss[k]};
+        m = __builtin_elementwise_fma(g2, ab[o + k], m);
+        e = __builtin_elementwise_fma(g2, sq[o + k], e);
       }
-      hz[0][ly][lx + o] = m1; hz[1][ly][lx + o] = m2; hz[2][ly][lx + o] = e11; hz[3][ly][lx + o] = e22;
-      hz[4][ly][lx + o] = e12;
+      hz_m[ly][lx + o] = m;
+      hz_s[ly][lx + o] = e;
     }
   }
   __syncthreads();
@@ -138,37 +151,45 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
     // vertical pass: thread = (column lx, SS_BLK consecutive rows); 32 columns x 8 row groups = 256 threads
     static_assert(SS_TILE * (SS_TILE / SS_BLK) == 256, "one task per thread");
     const int lx = threadIdx.x & (SS_TILE - 1), ly0 = (threadIdx.x / SS_TILE) * SS_BLK;
-    float mom[5][SS_BLK];
+    float2v mom_m[SS_BLK], mom_s[SS_BLK];
+    {
+      float2v v[SS_BLK + 10];
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
-      float v[SS_BLK + 10];
-#pragma unroll
-      for (int j = 0; j < SS_BLK + 10; j++) v[j] = hz[m][ly0 + j][lx];
+      for (int j = 0; j < SS_BLK + 10; j++) v[j] = hz_m[ly0 + j][lx];
 #pragma unroll
       for (int o = 0; o < SS_BLK; o++) {
-        float acc = 0.f;
+        float2v acc = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 11; k++) acc = fmaf(kGauss[k], v[o + k], acc);
-        mom[m][o] = acc;
+        for (int k = 0; k < 11; k++) acc = __builtin_elementwise_fma(float2v{kGauss[k], kGauss[k]}, v[o + k], acc);
+        mom_m[o] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < SS_BLK + 10; j++) v[j] = hz_s[ly0 + j][lx];
+#pragma unroll
+      for (int o = 0; o < SS_BLK; o++) {
+        float2v acc = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = __builtin_elementwise_fma(float2v{kGauss[k], kGauss[k]}, v[o + k], acc);
+        mom_s[o] = acc;
       }
     }
 #pragma unroll
     for (int o = 0; o < SS_BLK; o++) {
       const int ly = ly0 + o, gy = y0 + ly, gx = x0 + lx;
       if (gy >= H || gx >= W) continue;
-      const float m1 = mom[0][o], m2 = mom[1][o], e11 = mom[2][o], e22 = mom[3][o], e12 = mom[4][o];
+      const float m1 = mom_m[o].x, m2 = mom_m[o].y, ess = mom_s[o].x, e12 = mom_s[o].y;  // ess = e11 + e22
       float A1 = 2.f * m1 * m2 + SS_C1;
       float A2 = 2.f * (e12 - m1 * m2) + SS_C2;
       float B1 = m1 * m1 + m2 * m2 + SS_C1;
-      float B2 = (e11 - m1 * m1) + (e22 - m2 * m2) + SS_C2;
+      float B2 = ((ess - m1 * m1) - m2 * m2) + SS_C2;
       // v_rcp_f32 (1 ulp) instead of four IEEE divisions per output: each of those expands to ~10 instructions
       // (div_scale, rcp, Newton steps, div_fixup) -- a fifth of this kernel's VALU work for a 24th bit the loss never sees
       const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
       float inv = rB1 * rB2;
       float S = A1 * A2 * inv;
       ss_acc += S;
-      float a = sx[ly + SS_HALO][lx + SS_HALO], b = sy[ly + SS_HALO][lx + SS_HALO];
-      l1_acc += fabsf(a - b);
+      const float2v c = sxy[ly + SS_HALO][lx + SS_HALO];
+      l1_acc += fabsf(c.x - c.y);
       size_t p = ch * plane + (size_t)gy * W + gx;
       maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (rB1 - rB2);  // d/dm1
       maps[cplane + p] = -S * rB2;                                         // d/de11
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   if (threadIdx.x == 0) {
     // per-workgroup partials, reduced by the finish kernel: thousands of atomics on two addresses would
     // serialise in one L2 channel and dominate this (otherwise streaming) kernel
-    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t b = (size_t)tile_id;  // (channel, row, column) order whatever the placement: the finish sums in this order
     partials[2 * b] = t1;
     partials[2 * b + 1] = t2;
   }
@@ -191,6 +212,10 @@ constexpr int ST_W = 64;                      // columns per wave
 constexpr int ST_RS = 16;                     // output rows per wave
 constexpr int ST_IN = ST_W + 2 * SS_HALO;     // 74
 constexpr int ST_NR = ST_RS + 2 * SS_HALO;    // input rows per wave
+#ifndef FSGS_LOSS_PF
+#define FSGS_LOSS_PF 2
+#endif
+constexpr int ST_PF = FSGS_LOSS_PF;           // input rows in flight per wave
 
 // loss = (1-l) * L1mean + l * (1 - SSIMmean);  out[0] = loss, out[1] = L1 mean, out[2] = SSIM mean
 // The same reduction by ONE wave (fixed order too): the extra workgroup of the fused forward + backward entry, which
@@ -260,66 +285,88 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
                                                              const float *__restrict__ upstream, float lambda_dssim,
                                                              float *__restrict__ dimg, FinishArgs fin) {
   __shared__ float row[3][ST_IN + 6];
-  const int lane = threadIdx.x, ch = blockIdx.z;
-  if (fin.out && blockIdx.x == gridDim.x - 1) {  // the grid is one column wider: its first workgroup finishes the loss
-    if (blockIdx.y == 0 && blockIdx.z == 0) photometric_finish_wave(fin, lambda_dssim, lane);
+  const int lane = threadIdx.x;
+  const int strips_x = (W + ST_W - 1) / ST_W, strips_y = (H + ST_RS - 1) / ST_RS, nstrips = strips_x * strips_y * C;
+  if ((int)blockIdx.x >= nstrips) {  // the grid is one workgroup longer: it finishes the loss
+    if (fin.out) photometric_finish_wave(fin, lambda_dssim, lane);
     return;
   }
-  const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_RS;
+  // XCD-aware placement (see the forward kernel): every XCD streams one band of vertically adjacent strips, whose 10 shared
+  // halo rows per boundary then come out of its own L2
+#ifdef FSGS_EXP_LOSS_NO_XCD
+  const int strip = blockIdx.x;
+#else
+  const int strip = xcd_swizzle(blockIdx.x, nstrips);
+#endif
+  const int ch = strip / (strips_x * strips_y), s2 = strip - ch * (strips_x * strips_y);
+  const int strip_y = s2 / strips_x, strip_x = s2 - strip_y * strips_x;
+  const int x0 = strip_x * ST_W, y0 = strip_y * ST_RS;
   const int gx = x0 + lane;
   const size_t plane = (size_t)H * W, cplane = (size_t)C * plane;
+  // Every load of this kernel is UNCONDITIONAL, from coordinates clamped into the image with min / max (no comparison the
+  // compiler could turn into a branch around the load), and what lies outside is masked where the value is USED, one or
+  // more row iterations later.  With the loads inside conditions (or with an address selected by a condition: the compiler
+  // then loads the uniform default with the scalar unit and puts the vector load back under a branch) the values meet
+  // their defaults in a register copy right behind the load -- which waits for it: one exposed memory round trip per row.
+  const int c0 = x0 - SS_HALO + lane, c1 = x0 - SS_HALO + ST_W + lane;
+  const bool in_c0 = c0 >= 0 && c0 < W, in_c1 = lane < 2 * SS_HALO && c1 < W;
+  const uint32_t c0c = (uint32_t)min(max(c0, 0), W - 1);
+  const uint32_t c1c = lane < 2 * SS_HALO ? (uint32_t)min(c1, W - 1) : c0c;  // the other lanes repeat their first address
+  const float *map0 = maps + (size_t)ch * plane, *map1 = map0 + cplane, *map2 = map1 + cplane;
+  const float *img_c = img + (size_t)ch * plane, *gt_c = gt + (size_t)ch * plane;
+  const float *mask_c = mask ? mask : img_c, *pres_c = presence ? presence : img_c;
+  const uint32_t gxc = (uint32_t)min(gx, W - 1);
   auto fetch_row = [&](int gy, float (&v0)[3], float (&v1)[3]) {
-#pragma unroll
-    for (int m = 0; m < 3; m++) v0[m] = v1[m] = 0.f;
-    if (gy >= 0 && gy < H) {
-      const int c0 = x0 - SS_HALO + lane, c1 = x0 - SS_HALO + ST_W + lane;
-      if (c0 >= 0 && c0 < W) {
-        const size_t p = ch * plane + (size_t)gy * W + c0;
-#pragma unroll
-        for (int m = 0; m < 3; m++) v0[m] = maps[m * cplane + p];
-      }
-      if (lane < 2 * SS_HALO && c1 < W) {
-        const size_t p = ch * plane + (size_t)gy * W + c1;
-#pragma unroll
-        for (int m = 0; m < 3; m++) v1[m] = maps[m * cplane + p];
-      }
-    }
+    const uint32_t rowoff = (uint32_t)min(max(gy, 0), H - 1) * (uint32_t)W;  // 32-bit offsets inside one plane (H * W < 2^30)
+    v0[0] = map0[rowoff + c0c]; v0[1] = map1[rowoff + c0c]; v0[2] = map2[rowoff + c0c];
+    v1[0] = map0[rowoff + c1c]; v1[1] = map1[rowoff + c1c]; v1[2] = map2[rowoff + c1c];
   };
   const float up = upstream ? upstream[0] : 1.0f;
   const float invN = 1.0f / ((float)C * (float)H * (float)W);
   const float k_l1 = up * (1.0f - lambda_dssim) * invN, k_ss = -up * lambda_dssim * invN;
   float ring[11][3];
-  float n0[3], n1[3];
-  float nx = 0.f, ny = 0.f, nm = 1.f, np_ = 1.f;  // next output row's pixel (first output row: iteration 2 * SS_HALO)
-  fetch_row(y0 - SS_HALO, n0, n1);
-  for (int r0 = 0; r0 < ST_NR; r0 += 11) {
+  // ST_PF input rows are in flight: iteration r consumes the map row and the output pixel (image, target, mask, presence)
+  // requested ST_PF iterations earlier and re-issues its stage for iteration r + ST_PF.  With one row in flight every
+  // iteration exposed a memory round trip (26 of them per wave at ~4 waves per SIMD: the kernel's time).  The stage of an
+  // iteration is a compile-time index (the loop is unrolled 11 * ST_PF deep): rotating the registers instead would wait
+  // for the loads it moves.  Branch-free (clamped address, every load issued, unused values dropped): a load inside a
+  // conditional block is waited for at the block's end.
+  float n0[ST_PF][3], n1[ST_PF][3], nx[ST_PF], ny[ST_PF], nm[ST_PF], np_[ST_PF];
+  auto fetch_pixel = [&](int rr, float &x, float &y, float &m, float &pr) {  // the output pixel of iteration rr
+    const uint32_t e = (uint32_t)min(max(y0 + rr - 2 * SS_HALO, 0), H - 1) * (uint32_t)W + gxc;
+    x = img_c[e];
+    y = gt_c[e];
+    m = mask_c[e];
+    pr = pres_c[e];
+  };
 #pragma unroll
-    for (int q = 0; q < 11; q++) {
-      const int r = r0 + q;
+  for (int st = 0; st < ST_PF; st++) {
+    fetch_row(y0 - SS_HALO + st, n0[st], n1[st]);
+    fetch_pixel(st, nx[st], ny[st], nm[st], np_[st]);
+  }
+  for (int r0 = 0; r0 < ST_NR; r0 += 11 * ST_PF) {
+#pragma unroll
+    for (int qq = 0; qq < 11 * ST_PF; qq++) {
+      const int r = r0 + qq;
       if (r >= ST_NR) break;  // wave-uniform
+      constexpr int kRing = 11;
+      const int q = qq % kRing, st = qq % ST_PF;
       __syncthreads();
+      {
+        const int gy = y0 - SS_HALO + r;
+        const bool in_row = gy >= 0 && gy < H;  // outside the image: zero padding (F.conv2d padding = 5)
 #pragma unroll
-      for (int m = 0; m < 3; m++) {
-        row[m][lane] = n0[m];
-        if (lane < 2 * SS_HALO) row[m][ST_W + lane] = n1[m];
+        for (int m = 0; m < 3; m++) {
+          row[m][lane] = (in_row && in_c0) ? n0[st][m] : 0.f;
+          if (lane < 2 * SS_HALO) row[m][ST_W + lane] = (in_row && in_c1) ? n1[st][m] : 0.f;
+        }
       }
       __syncthreads();
-      if (r + 1 < ST_NR) fetch_row(y0 - SS_HALO + r + 1, n0, n1);
-      // The output row's own pixel (image, target, mask, presence) was requested one ROW ITERATION ago, like the map rows:
-      // at the point of use the loads cost one exposed memory round trip per output row.  Branch-free (clamped address,
-      // every load issued, unused values dropped): a load inside a conditional block is waited for at the block's end.
       const int oy = y0 + r - 2 * SS_HALO;
       const bool out_ok = r >= 2 * SS_HALO && oy < H && gx < W;
-      const float ex = nx, ey = ny, em = nm, ep = np_;
-      {
-        const int oy1 = oy + 1;
-        const bool ok1 = r + 1 >= 2 * SS_HALO && r + 1 < ST_NR && oy1 < H && gx < W;
-        const size_t epp = ok1 ? (size_t)oy1 * W + gx : 0;
-        nx = img[ch * plane + epp];
-        ny = gt[ch * plane + epp];
-        nm = (mask ? mask : img)[epp];
-        np_ = (presence ? presence : img)[epp];
-      }
+      const float ex = nx[st], ey = ny[st], em = nm[st], ep = np_[st];
+      fetch_row(y0 - SS_HALO + r + ST_PF, n0[st], n1[st]);  // (the last ST_PF requests are never used: no condition, see above)
+      fetch_pixel(r + ST_PF, nx[st], ny[st], nm[st], np_[st]);
 #pragma unroll
       for (int m = 0; m < 3; m++) {
         float acc = 0.f;
@@ -544,12 +591,12 @@ int fsgs_photometric_loss_forward(int C, int H, int W, const float *img, const f
                                   fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3) return FSGS_ERR_INVALID;
-  dim3 grid((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
-  const int nblocks = (int)(grid.x * grid.y * grid.z);
+  const int nblocks = ((W + SS_TILE - 1) / SS_TILE) * ((H + SS_TILE - 1) / SS_TILE) * C;
+  dim3 grid(nblocks);
   float *partials = (float *)sums2;  // caller-sized by fsgs_photometric_scratch_bytes
   {
     ProfScope ps(PROF_LOSS_RGB_FWD, stream);
-    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), 0, stream, C, H, W, img, gt, mask, presence, maps, partials);
+    hipLaunchKernelGGL(photometric_fwd_kernel, grid, dim3(256), kFwdDynLds, stream, C, H, W, img, gt, mask, presence, maps, partials);
     hipLaunchKernelGGL(photometric_finish_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, (double)C * H * W,
                        lambda_dssim, out3);
   }
@@ -562,7 +609,7 @@ int fsgs_photometric_loss_backward(int C, int H, int W, const float *img, const 
                                    fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !dimg) return FSGS_ERR_INVALID;
-  dim3 grid((W + ST_W - 1) / ST_W, (H + ST_RS - 1) / ST_RS, C);
+  dim3 grid(((W + ST_W - 1) / ST_W) * ((H + ST_RS - 1) / ST_RS) * C);
   {
     ProfScope ps(PROF_LOSS_RGB_BWD, stream);
     hipLaunchKernelGGL(photometric_bwd_kernel, grid, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,
@@ -577,14 +624,14 @@ int fsgs_photometric_loss_forward_backward(int C, int H, int W, const float *img
                                            float *out3, const float *upstream, float *dimg, fsgs_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !sums2 || !out3 || !dimg) return FSGS_ERR_INVALID;
-  dim3 gf((W + SS_TILE - 1) / SS_TILE, (H + SS_TILE - 1) / SS_TILE, C);
-  const int nblocks = (int)(gf.x * gf.y * gf.z);
+  const int nblocks = ((W + SS_TILE - 1) / SS_TILE) * ((H + SS_TILE - 1) / SS_TILE) * C;
+  dim3 gf(nblocks);
   float *partials = (float *)sums2;
   {
     ProfScope ps(PROF_LOSS_RGB_FWD, stream);
-    hipLaunchKernelGGL(photometric_fwd_kernel, gf, dim3(256), 0, stream, C, H, W, img, gt, mask, presence, maps, partials);
+    hipLaunchKernelGGL(photometric_fwd_kernel, gf, dim3(256), kFwdDynLds, stream, C, H, W, img, gt, mask, presence, maps, partials);
   }
-  dim3 gb((W + ST_W - 1) / ST_W + 1, (H + ST_RS - 1) / ST_RS, C);  // + 1 column: the finishing workgroup
+  dim3 gb(((W + ST_W - 1) / ST_W) * ((H + ST_RS - 1) / ST_RS) * C + 1);  // + 1: the finishing workgroup
   {
     ProfScope ps(PROF_LOSS_RGB_BWD, stream);
     hipLaunchKernelGGL(photometric_bwd_kernel, gb, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,

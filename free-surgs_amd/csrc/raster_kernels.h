@@ -705,7 +705,12 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   // T[k] > 0: transmittance of a pixel that is still blending; a FINISHED pixel (T (1 - alpha) < 1e-4 seen, or outside
   // the image) keeps its transmittance with the sign flipped -- the "done" flag costs no register and one compare
   // (86 -> 80 VGPRs: six waves per SIMD; one VALU less per quadrant body)
-  float T[4], D[4], acc[4][C];
+  // the colour sums are kept as channel PAIRS: a pair's update is one v_pk_fma_f32 with the record's (x, y) / (z, w) halves
+  // as they come out of the broadcast read.  Written out here because the build runs without the SLP vectoriser (which
+  // formed these pairs by itself, but cost blend_bwd 5 % with the register shuffles it added there).
+  constexpr int CP = (C + 1) / 2;
+  float T[4], D[4];
+  float2v acc[4][CP];
   uint32_t last[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     D[k] = 0.0f;
     last[k] = 0;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) acc[k][ch] = 0.0f;
+    for (int cp = 0; cp < CP; cp++) acc[k][cp] = float2v{0.0f, 0.0f};
   }
   const int2 rg = ranges[tile];
   for (int base = rg.x; base < rg.y; base += 64) {
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       const uint32_t bm = readlane(gmask, j) & alive;  // scalar
       if (bm == 0) continue;
       const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
-      const float bcol8[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+      const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
       const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
 #pragma unroll
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         }
         float w = e.alpha * T[k];
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) acc[k][ch] = fmaf(bcol8[ch], w, acc[k][ch]);
+        for (int cp = 0; cp < CP; cp++) acc[k][cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[k][cp]);
         if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
         T[k] = test_T;
         last[k] = pos;
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       n_contrib[pix] = last[k];
 #pragma unroll
       for (int ch = 0; ch < C; ch++) {
-        float v = fmaf(Tf, cam.bg[ch], acc[k][ch]);
+        float v = fmaf(Tf, cam.bg[ch], acc[k][ch >> 1][ch & 1]);
         if (ch < 3) out_color[ch * HW + pix] = v;
         else out_color2[(ch - 3) * HW + pix] = v;
       }

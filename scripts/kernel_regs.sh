@@ -2,7 +2,7 @@
 # VGPR / SGPR / LDS / occupancy of the blend kernels as compiled (no GPU needed).
 cd "$(dirname "$0")/.."
 mkdir -p /tmp/isa && cd /tmp/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=on -Wno-unused-result -DNDEBUG \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -ffp-contract=on -Wno-unused-result -DNDEBUG -fno-slp-vectorize \
   -c /root/repo/free-surgs_amd/csrc/${1:-render}.hip --save-temps -o ${1:-render}.o 2>/dev/null
 python3 - "${1:-render}" "${2:-blend}" <<'PY'
 import re, subprocess, sys
