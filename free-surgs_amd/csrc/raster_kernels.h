@@ -338,6 +338,11 @@ __device__ __forceinline__ void bitonic_sort_ascending(Mem keys, int n, int m) {
 // the tiles' bins are parked in LDS as bytes, so this path costs the sort kernel no registers (as one more launch-wide
 // register array it took the whole kernel from 8 to 5 waves per SIMD).
 constexpr int ORDER_BINS_FUSED = 256;
+constexpr int ORDER_FOLD = 1024;  // SIMDs of the chip = the period of the workgroup -> SIMD placement (see below)
+// The order is folded only when the WHOLE launch is resident from the start (blend_bwd holds 5 waves per SIMD: up to 5120
+// tiles, C2's 1280 x 1024): with more tiles a freed slot takes the next workgroup, the balance is dynamic and wants the plain
+// longest-first order (C4, 8160 tiles: folding cost blend_bwd 0.4 - 2.5 %, blend_fwd 1 %)
+constexpr uint32_t ORDER_FOLD_ROUNDS = 5;
 __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 KB + 8 KB of LDS */, int ntiles,
                                                         const uint32_t *__restrict__ cursors, uint32_t cap_sub,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ total_out,
@@ -395,7 +400,22 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
     if (w < wv) before += wave_tot[w];
   hist[threadIdx.x] = before + incl - c;
   __syncthreads();
-  for (int i = (int)threadIdx.x; i < ntiles; i += 256) order[atomicAdd(&hist[bins[i]], 1u)] = (uint32_t)i;
+  // rank (0 = longest list) -> dispatch position.  Workgroup b of a one-wave-per-workgroup launch lands on the SAME SIMD as
+  // b + 1024, b + 2048, ... (1024 SIMDs; measured: scripts/ubench/dispatch_map.hip, profiles/r03_dispatch_map.txt), and at C2
+  // all 5120 tiles are resident from the start -- so a strictly descending order hands one SIMD the longest tile of EVERY
+  // round of 1024 and another the shortest of every round (20 % above the mean for evenly spread lengths).  Folding the
+  // order back and forth (boustrophedon: odd rounds run backwards) pairs a SIMD's long tiles with short ones: 4 %.
+  const bool fold = (uint32_t)ntiles <= ORDER_FOLD * ORDER_FOLD_ROUNDS;
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) {
+    const uint32_t rank = atomicAdd(&hist[bins[i]], 1u);
+#ifdef FSGS_EXP_NO_FOLD
+    order[rank] = (uint32_t)i;
+#else
+    const uint32_t round = rank / ORDER_FOLD, idx = rank - round * ORDER_FOLD;
+    const uint32_t m = min((uint32_t)ORDER_FOLD, (uint32_t)ntiles - round * ORDER_FOLD);  // the last round may be short
+    order[round * ORDER_FOLD + (((round & 1u) && fold) ? m - 1u - idx : idx)] = (uint32_t)i;
+#endif
+  }
 }
 
 // order != nullptr: the launch has ntiles + 1 workgroups, block 0 forms the dispatch order / R / mailbox word (above) and
