@@ -403,9 +403,44 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
   // rank (0 = longest list) -> dispatch position.  Workgroup b of a one-wave-per-workgroup launch lands on the SAME SIMD as
   // b + 1024, b + 2048, ... (1024 SIMDs; measured: scripts/ubench/dispatch_map.hip, profiles/r03_dispatch_map.txt), and at C2
   // all 5120 tiles are resident from the start -- so a strictly descending order hands one SIMD the longest tile of EVERY
-  // round of 1024 and another the shortest of every round (20 % above the mean for evenly spread lengths).  Folding the
-  // order back and forth (boustrophedon: odd rounds run backwards) pairs a SIMD's long tiles with short ones: 4 %.
+  // round of 1024 and another the shortest of every round (20 % above the mean for evenly spread lengths).  Laying some
+  // rounds out BACKWARDS pairs a SIMD's long tiles with short ones.
+  // WHICH rounds run backwards is chosen from the lengths at hand: a round's lists span `range` (first minus last, in bins of
+  // four); the rounds are taken by descending range and each is laid against the slope accumulated so far.  (Plain
+  // alternation left the two widest rounds of C2 -- the longest 1024 lists and the shortest 1024 -- running the same way:
+  // the sums of a SIMD's list lengths then spread 899 .. 1154 around 1040 and the SIMDs finished 9 % apart.)
   const bool fold = (uint32_t)ntiles <= ORDER_FOLD * ORDER_FOLD_ROUNDS;
+  __shared__ uint32_t s_rev;
+  __shared__ int s_edge[2 * ORDER_FOLD_ROUNDS];
+  const uint32_t nrounds = ((uint32_t)ntiles + ORDER_FOLD - 1) / ORDER_FOLD;
+  if (fold) {
+    if (threadIdx.x < 2 * nrounds) {
+      const uint32_t k = threadIdx.x >> 1;
+      const uint32_t r = k * ORDER_FOLD + ((threadIdx.x & 1u) ? min((uint32_t)ORDER_FOLD, (uint32_t)ntiles - k * ORDER_FOLD) - 1u : 0u);
+      int b = 0;  // the bin of rank r: the largest b whose first rank is <= r (hist holds the bins' first ranks, ascending)
+#pragma unroll
+      for (int step = ORDER_BINS_FUSED / 2; step > 0; step >>= 1)
+        if (hist[b + step] <= r) b += step;
+      s_edge[threadIdx.x] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int range[ORDER_FOLD_ROUNDS];
+      for (uint32_t k = 0; k < ORDER_FOLD_ROUNDS; k++) range[k] = k < nrounds ? s_edge[2 * k + 1] - s_edge[2 * k] : -1;
+      uint32_t rev = 0;
+      int acc = 0;  // > 0: the load so far falls along a round's positions
+      for (uint32_t n = 0; n < nrounds; n++) {
+        uint32_t best = 0;
+        for (uint32_t k = 1; k < ORDER_FOLD_ROUNDS; k++)
+          if (range[k] > range[best]) best = k;
+        if (acc > 0) { rev |= 1u << best; acc -= range[best]; } else { acc += range[best]; }
+        range[best] = -1;
+      }
+      s_rev = rev;
+    }
+    __syncthreads();
+  }
+  const uint32_t rev = fold ? s_rev : 0u;
   for (int i = (int)threadIdx.x; i < ntiles; i += 256) {
     const uint32_t rank = atomicAdd(&hist[bins[i]], 1u);
 #ifdef FSGS_EXP_NO_FOLD
@@ -413,7 +448,7 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
 #else
     const uint32_t round = rank / ORDER_FOLD, idx = rank - round * ORDER_FOLD;
     const uint32_t m = min((uint32_t)ORDER_FOLD, (uint32_t)ntiles - round * ORDER_FOLD);  // the last round may be short
-    order[round * ORDER_FOLD + (((round & 1u) && fold) ? m - 1u - idx : idx)] = (uint32_t)i;
+    order[round * ORDER_FOLD + (((rev >> round) & 1u) ? m - 1u - idx : idx)] = (uint32_t)i;
 #endif
   }
 }

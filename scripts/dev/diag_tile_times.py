@@ -23,7 +23,7 @@ def main():
     nwaves = ntiles
     buf = torch.zeros((nwaves * 4,), dtype=torch.int64, device=dev)
     os.environ["FSGS_DBG_TILE_TIMES_FWD" if "--fwd" in sys.argv else "FSGS_DBG_TILE_TIMES"] = str(buf.data_ptr())
-    slots = 6144 if "--fwd" in sys.argv else 4096
+    slots = 6144 if "--fwd" in sys.argv else 5120
     from fsgs_amd import _lib
     from fsgs_amd.fast_step import FastStepper
 
@@ -59,6 +59,17 @@ def main():
             if sel.any():
                 print("  list length %3d..%3d: %4d tiles, duration mean %.1f us, start mean %.1f us" % (
                     lo_, hi_, sel.sum(), dur[sel].mean(), (t0[ok][sel] - start).mean()))
+        # per SIMD: workgroup b of these one-wave launches shares its SIMD with b + 1024, b + 2048, ... (profiles/r03_dispatch_map.txt)
+        if ok.all() and nwaves % 1024 == 0:
+            fin = (t1 - start).reshape(-1, 1024).max(axis=0)           # when each SIMD ran dry
+            work = lst.reshape(-1, 1024).sum(axis=0)                   # its tiles' list lengths
+            wk2 = walked.reshape(-1, 1024).sum(axis=0)
+            print("  per SIMD: finish time mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us (makespan / mean %.3f); sum of its list "
+                  "lengths mean %.0f min %.0f max %.0f (max / mean %.3f); corr(finish, sum of lengths) %.3f, corr(finish, sum walked) %.3f" % (
+                      fin.mean(), np.percentile(fin, 10), np.percentile(fin, 50), np.percentile(fin, 90), fin.max(), fin.max() / fin.mean(),
+                      work.mean(), work.min(), work.max(), work.max() / work.mean(), np.corrcoef(fin, work)[0, 1], np.corrcoef(fin, wk2)[0, 1]))
+            cu = fin.reshape(-1)  # by SIMD id = b % 1024; XCD = b % 8
+            print("  per XCD finish (mean of its SIMDs): %s" % " ".join("%.0f" % cu[x::8].mean() for x in range(8)))
         nb = 16
         edges = np.linspace(start, end, nb + 1)
         occ = []
