@@ -747,6 +747,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   // dbg_times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only; NULL otherwise):
   // 100 MHz wall-clock stamps of this wave's start and end, to measure load balance and the kernel's tail
   const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;
+#ifdef FSGS_DIAG_HOOKS
+  uint32_t dbg_bodies = 0, dbg_pairs = 0;  // quadrant bodies executed / pairs not skipped altogether (scalar counters)
+#endif
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
   constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
   __shared__ float4 rec[64 * REC4];
@@ -816,6 +819,10 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t bm = readlane(gmask, j) & alive;  // scalar
       if (bm == 0) continue;
+#ifdef FSGS_DIAG_HOOKS
+      dbg_bodies += (uint32_t)__popc(bm);
+      dbg_pairs += 1;
+#endif
       const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
       const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
@@ -860,7 +867,11 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   if (dbg_times && lane == 0) {
     dbg_times[4 * blockIdx.x + 0] = dbg_t0;
     dbg_times[4 * blockIdx.x + 1] = wall_clock64();
+#ifdef FSGS_DIAG_HOOKS
+    dbg_times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+#else
     dbg_times[4 * blockIdx.x + 2] = 0;
+#endif
     dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
                                     max(max(last[0], last[1]), max(last[2], last[3]));
   }
@@ -915,6 +926,9 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16,
     unsigned long long *__restrict__ dbg_times) {
   const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;  // see blend_fwd_kernel
+#ifdef FSGS_DIAG_HOOKS
+  uint32_t dbg_bodies = 0, dbg_pairs = 0;
+#endif
   constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;  // compile-time: shifts, no 64-bit mads
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
   // 16 floats the NEXT kernel accumulates into with atomics (dL/dw2c): cleared here instead of by a separate fill
@@ -1025,6 +1039,10 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         for (int k = 0; k < 4; k++)
           if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
         if (bm == 0) continue;
+#ifdef FSGS_DIAG_HOOKS
+        dbg_bodies += (uint32_t)__popc(bm);
+        dbg_pairs += 1;
+#endif
         // broadcast reads of record j (same LDS address in every lane)
         const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
         const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y;
@@ -1103,7 +1121,11 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   if (dbg_times && lane == 0) {
     dbg_times[4 * blockIdx.x + 0] = dbg_t0;
     dbg_times[4 * blockIdx.x + 1] = wall_clock64();
+#ifdef FSGS_DIAG_HOOKS
+    dbg_times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+#else
     dbg_times[4 * blockIdx.x + 2] = 0;
+#endif
     dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
   }
 }
@@ -1406,7 +1428,11 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   static int dbg_lds = diag_env("FSGS_DBG_LDS_FWD") ? atoi(diag_env("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
       diag_env("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
-  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
+  // scheduling experiments only (scripts/dev/order_experiment.py): a dispatch order made on the host, holes (0xFFFFFFFF) allowed
+  static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_FWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_FWD"), nullptr, 0) : nullptr;
+  static int dbg_order_n = diag_env("FSGS_DBG_ORDER_FWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_FWD_N")) : 0;
+  const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
+  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
                      final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
   return 0;
 }
@@ -1419,7 +1445,10 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   static int dbg_lds = diag_env("FSGS_DBG_LDS") ? atoi(diag_env("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
       diag_env("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(64), dbg_lds, s, cam, ntiles, order, ranges, plist, rec,
+  static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_BWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_BWD"), nullptr, 0) : nullptr;
+  static int dbg_order_n = diag_env("FSGS_DBG_ORDER_BWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_BWD_N")) : 0;
+  const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
                      final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times);
   return 0;
 }

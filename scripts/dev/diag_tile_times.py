@@ -52,8 +52,19 @@ def main():
             dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), lst[ok].mean(), lst[ok].max(), walked[ok].mean(), walked[ok].max()))
         print("  corr(duration, list length) %.3f   corr(duration, walked depth) %.3f" % (
             np.corrcoef(dur, lst[ok])[0, 1], np.corrcoef(dur, walked[ok])[0, 1]))
+        bodies = (d[:, 2] & 0xFFFFFFFF).astype(np.float64)  # quadrant bodies executed, pairs not skipped altogether
+        pairs = (d[:, 2] >> 32).astype(np.float64)
         np.save("gpurun_out/tile_times_%s_%d.npy" % ("fwd" if "--fwd" in sys.argv else "bwd", it),
-                np.stack([t0[ok] - start, t1[ok] - start, lst[ok], walked[ok]]))
+                np.stack([t0[ok] - start, t1[ok] - start, lst[ok], walked[ok], bodies[ok], pairs[ok]]))
+        if ok.all() and nwaves % 1024 == 0 and bodies.sum() > 0:
+            fin_ = (t1 - start).reshape(-1, 1024).max(axis=0)
+            for nm, v in (("bodies", bodies), ("pairs", pairs), ("35 bodies + 63 pairs", 35 * bodies + 63 * pairs)):
+                sv = v.reshape(-1, 1024).sum(axis=0)
+                print("  per SIMD: sum of %s mean %.0f min %.0f max %.0f (max / mean %.3f), corr with the finish time %.3f" % (
+                    nm, sv.mean(), sv.min(), sv.max(), sv.max() / sv.mean(), np.corrcoef(fin_, sv)[0, 1]))
+            print("  per tile: bodies / list length mean %.2f p10 %.2f p90 %.2f; corr(bodies, list length) %.3f" % (
+                (bodies / np.maximum(lst, 1)).mean(), np.percentile(bodies / np.maximum(lst, 1), 10),
+                np.percentile(bodies / np.maximum(lst, 1), 90), np.corrcoef(bodies, lst)[0, 1]))
         for lo_, hi_ in ((0, 100), (100, 150), (150, 200), (200, 250), (250, 300), (300, 1000)):
             sel = (lst[ok] >= lo_) & (lst[ok] < hi_)
             if sel.any():
