@@ -89,6 +89,7 @@ class Oracle:
             ("oracle_state_conic_op", rp),
             ("oracle_state_depth", rp),
             ("oracle_state_cov3D", rp),
+            ("oracle_state_kappa", rp),
             ("oracle_state_final_T", rp),
             ("oracle_state_n_contrib", ip),
             ("oracle_state_tiles", ip),
@@ -353,8 +354,24 @@ class Oracle:
             for k in names:
                 if P:
                     level = np.maximum(level, rd[k].max(axis=1) / (norm[k] + floor + 1e-300))
+            # ... and the level has a floor set by the conditioning of the Gaussian itself, relative to its OWN gradient row:
+            #  * the conic of a needle-shaped footprint is only good to ~6 kappa eps in ANY fp32 evaluation (kappa = a c / det,
+            #    OracleState.kappa; FLIP_MARGINS['alpha_kappa'] is the same statement for the alpha threshold), and
+            #    dL/dcov2D = -conic dL/dconic conic inherits that;
+            #  * dL/dscale and dL/drotation come from dL/dSigma through Sigma = R S^2 R^T: terms of size s_max^2 |dL/dSigma| cancel
+            #    down to what the small axes leave, kappa3 = (s_max / s_min)^2 of rounding.
+            # The oracle's fp32-vs-fp64 distance is ONE draw of that error and can come out small by luck: seed 2148 of the
+            # soak (a 0.58 x 0.019 x 0.009 needle, kappa3 = 4.1e3, radius 62 px in a 27 x 52 image) sits 7e-5 of the norm from
+            # its fp64 value in the oracle and 5.5e-4 in the HIP path on one rotation component, 8 % beyond the allowance
+            # that one draw gave.  Both factors are ~1 for anything round (4e-7 / 1e-7 of the row): no effect there.
+            eps32 = float(np.finfo(np.float32).eps)
+            kap = np.asarray(nom[4].kappa(), np.float64)
+            sc = np.abs(np.asarray(scales, np.float64).reshape(P, -1)) if P else np.zeros((0, 3))
+            kap3 = (sc.max(axis=1) / np.maximum(sc.min(axis=1), 1e-30)) ** 2 if P else np.zeros(0)
             for k in names:
-                out[k] += 2 * np.maximum(rd[k], (level * (norm[k] + floor))[:, None])
+                own = np.abs(g64[k].reshape(P, -1)).max(axis=1) if P else np.zeros(0)
+                cond = 6.0 * np.maximum(kap, 0.0) * eps32 + (kap3 * eps32 if k in ("scales", "rotations") else 0.0)
+                out[k] += 2 * np.maximum(np.maximum(rd[k], (level * (norm[k] + floor))[:, None]), (cond * own)[:, None])
         return out, nom[:5]
 
     # -- KNN ---------------------------------------------------------------------
@@ -397,6 +414,10 @@ class OracleState:
     def cov3D(self):
         """[P,6] = (xx, xy, xz, yy, yz, zz) of Sigma; zero rows for Gaussians behind the near plane."""
         return self._arr("oracle_state_cov3D", (self.P, 6), self.oracle.dtype)
+
+    def kappa(self):
+        """[P] a c / det of the dilated 2D covariance (1 for a round footprint, thousands for a needle); 0 where culled"""
+        return self._arr("oracle_state_kappa", (self.P,), self.oracle.dtype)
 
     def tiles_touched(self):
         return self._arr("oracle_state_tiles", (self.P,), np.int32)

@@ -223,6 +223,7 @@ const real *oracle_state_depth(const OracleState *st) { return st->depth; }
  * the order strip_symmetric keeps (utils/general_utils.py:191-202); pinned against the reference's own
  * build_covariance_from_scaling_rotation (scene/gaussian_model.py:32-36) by tests/golden/covariance.npz */
 const real *oracle_state_cov3D(const OracleState *st) { return st->cov3D; }
+const real *oracle_state_kappa(const OracleState *st) { return st->kappa; }
 const real *oracle_state_final_T(const OracleState *st) { return st->final_T; }
 const int *oracle_state_n_contrib(const OracleState *st) { return st->n_contrib; }
 const int *oracle_state_tiles(const OracleState *st) { return st->tiles; }

@@ -38,3 +38,9 @@ for k in ("means3D", "scales", "rotations", "means2D", "opacities", "colors"):
     print(k, "scale", sc, "hip-f64", np.abs(a - c).max() / sc, "f32-f64", np.abs(b - c).max() / sc, "hip-f32", np.abs(a - b).max() / sc)
 i = np.unravel_index(np.argmax(np.abs(g["means3D"] - res["f32"]["means3D"])), g["means3D"].shape)
 print("worst means3D", i, g["means3D"][i], res["f32"]["means3D"][i], res["f64"]["means3D"][i], "radii", radii[i[0]], "xyz", xyz[i[0]], "scale", s[i[0]], "op", op[i[0]])
+if len(sys.argv) > 2:  # python diag_seed.py <seed> <tensor> <row>: one Gaussian's row in the three evaluations
+    k, row = sys.argv[2], int(sys.argv[3])
+    print(k, "row", row, "hip", g[k].reshape(P, -1)[row], "\n   f32", res["f32"][k].reshape(P, -1)[row], "\n   f64", res["f64"][k].reshape(P, -1)[row])
+    print("   radius", radii[row], "xyz", xyz[row], "scale", s[row], "rot", r[row], "op", op[row])
+    for kk in ("means3D", "scales", "opacities", "means2D"):
+        print("   ", kk, "hip", g[kk].reshape(P, -1)[row], "f32", res["f32"][kk].reshape(P, -1)[row], "f64", res["f64"][kk].reshape(P, -1)[row])
