@@ -241,6 +241,7 @@ struct RenderGradsDev {
 constexpr int MODE_GS_GRAD = 1;     // means3D gradient flows to _xyz (gs_grad=True)
 constexpr int MODE_CAM_GRAD = 2;    // reduce dL/dw2c (cam_grad=True)
 constexpr int MODE_PARAM_GRAD = 4;  // gradients of features / opacity / scaling / rotation (+ _xyz through the SH direction)
+constexpr int MODE_CLEAN_ACC = 8;   // FSGS_FLAG_SCRATCH_SELF_CLEAN: store zeros over every accumulator row once it has been read
 
 // ADAM = true (single-view mapping step on one GPU): the gradient of every parameter is consumed on the spot by
 // the Adam update of that element instead of being written out and read back by the optimizer kernel
@@ -393,7 +394,7 @@ template <int OUT>
 __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam, RenderDev a,
                                                              const int32_t *__restrict__ radii,
                                                              const float4 *__restrict__ conic_op,
-                                                             const float *__restrict__ grad_acc,
+                                                             float *__restrict__ grad_acc,
                                                              const float *__restrict__ dcolors6,
                                                              const uint32_t *__restrict__ flags, int mode,
                                                              RenderGradsDev out, AdamDev ad, StepTailDev tail,
@@ -420,9 +421,13 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     sink.prefetch(i);  // OUT_ADAM: parameters and moments of the small groups
     raw = load_raw(a, i);
     rad = radii[i];
-    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kFusedRow);  // one 64-byte row: moments | colour sums
+    float4 *ap = (float4 *)(grad_acc + (size_t)i * kFusedRow);  // one 64-byte row: moments | colour sums
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
     const float2 a3 = *(const float2 *)(ap + 3);
+    if (mode & MODE_CLEAN_ACC) {  // the row is zero again for the next backward blend: nobody has to clear the scratch
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      ap[0] = z; ap[1] = z; ap[2] = z; ap[3] = z;
+    }
     acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
     dc[0] = a2.x; dc[1] = a2.y; dc[2] = a2.z; dc[3] = a2.w; dc[4] = a3.x; dc[5] = a3.y;
     co = conic_op[i];
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
 __global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParams cam, RenderDev a,
                                                                   const int32_t *__restrict__ radii,
                                                                   const float4 *__restrict__ conic_op,
-                                                                  const float *__restrict__ grad_acc,
+                                                                  float *__restrict__ grad_acc, int clean,
                                                                   float *__restrict__ dw2c) {
   __shared__ float red[12][RB / 64];
   float part[12];
@@ -598,9 +603,13 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParam
   for (int i = blockIdx.x * RB + threadIdx.x; i < P; i += gridDim.x * RB) {
     const int rad = radii[i];
     const RawGaussian raw = load_raw(a, i);
-    const float4 *ap = (const float4 *)(grad_acc + (size_t)i * kFusedRow);  // moments | colour sums (dc[3], dc[5]: depth)
+    float4 *ap = (float4 *)(grad_acc + (size_t)i * kFusedRow);  // moments | colour sums (dc[3], dc[5]: depth)
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
     const float2 a3 = *(const float2 *)(ap + 3);
+    if (clean) {  // FSGS_FLAG_SCRATCH_SELF_CLEAN (see render_pre_bwd_kernel)
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      ap[0] = z; ap[1] = z; ap[2] = z; ap[3] = z;
+    }
     const float4 co = conic_op[i];
     if (rad <= 0) continue;
     const float acc[kAccStride] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -922,7 +931,9 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                                 stream);
   }
   FSGS_HIP(hipGetLastError());
-  int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0);
+  const bool clean = (cfg->flags & FSGS_FLAG_SCRATCH_SELF_CLEAN) != 0;
+  int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0) |
+             (clean ? MODE_CLEAN_ACC : 0);
   RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
                      grads->rotation, grads->means2D, grads->w2c, compact};
   StepTailDev td{};
@@ -950,10 +961,11 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_COMPACT>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
-    else if (mode == MODE_CAM_GRAD && !out.means2D && !td.accum && !td.total && row_lo == 0 && row_hi == P && out.w2c)
+    else if ((mode & ~MODE_CLEAN_ACC) == MODE_CAM_GRAD && !out.means2D && !td.accum && !td.total && row_lo == 0 && row_hi == P &&
+             out.w2c)
       // the tracking step: dL/dw2c and nothing else
       hipLaunchKernelGGL(render_pre_bwd_pose_kernel, dim3(std::min((P + RB - 1) / RB, 512)), dim3(RB), 0, stream, P, cam,
-                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, out.w2c);
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, clean ? 1 : 0, out.w2c);
     else
       hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,

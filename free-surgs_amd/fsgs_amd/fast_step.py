@@ -64,7 +64,8 @@ class _Buffers:
         self.gc = None  # this view's compact gradient [P,14] (lazily: only multi-view / multi-rank steps)
         self.zero = torch.zeros((), dtype=torch.float32, device=dev)
         self.means2D_grad = f(P, 3)
-        self.bwd_scratch = torch.empty((P * 64 + 512,), dtype=torch.uint8, device=dev)
+        # the backward's accumulator rows: zero here and zero again behind every backward (FSGS_FLAG_SCRATCH_SELF_CLEAN)
+        self.bwd_scratch = torch.zeros((P * 64 + 512,), dtype=torch.uint8, device=dev)
         self.sizes = {}
 
 
@@ -136,12 +137,15 @@ class FastStepper:
             # this driver only ever hands the backward a gradient of the depth plane (Pearson losses): the silhouette and
             # depth^2 planes of d_depth_sil stay zero, and the flag lets the backward blend drop their terms
             self.cfg.flags |= _lib.FSGS_FLAG_DEPTH_GRAD_ONLY
+            # every backward of this driver leaves its accumulator rows zero (the per-Gaussian kernel stores zeros over what
+            # it has read): no fill launch, and no stream bookkeeping to keep a fill clear of the previous backward
+            self.cfg.flags |= _lib.FSGS_FLAG_SCRATCH_SELF_CLEAN
             self.cfg_key = key
         return self.cfg
 
     def _cfg_zeroed(self):
-        """the same configuration with FSGS_FLAG_SCRATCH_ZEROED: for backward calls whose scratch this driver has
-        cleared itself on the side stream"""
+        """the same configuration with FSGS_FLAG_SCRATCH_ZEROED: the scratch of this driver's buffer sets starts out zero and
+        every backward cleans up behind itself (FSGS_FLAG_SCRATCH_SELF_CLEAN, _cfg)"""
         base = self._cfg()
         if getattr(self, "_cfgz_of", None) is not base:
             z = _lib.FsgsRasterCfg()
@@ -392,24 +396,21 @@ class FastStepper:
 
     # ---- mapping (train.py:236-272) ------------------------------------------------------------------------
     def _view_forward(self, b, ts, corners, dev, H, W, view, allow_reuse=True):
-        """First part of one view's pipeline on the CURRENT stream (+ the view's side stream): patch draws and the clear
-        of the backward's accumulators on the side stream, then the render forward (returns when the pair count has
-        arrived, i.e. as the forward blend starts).  -> context for _view_losses / the backward"""
+        """First part of one view's pipeline on the CURRENT stream (+ the view's side stream): the patch draws on the side
+        stream, then the render forward (returns when the pair count has arrived, i.e. as the forward blend starts).
+        -> context for _view_losses / the backward"""
         w2c = (self.poses.get_pose_detached(ts) if hasattr(self.poses, "get_pose_detached")
                else self.poses.get_pose(ts).detach().contiguous())
         # The photometric chain (LDS / VALU bound) and the Pearson chain (bandwidth / latency bound) are independent
         # until the render backward: they run on two HIP streams.  What the side stream can do without the render
         # -- the two randint launches of the patch corners (same position in the RNG sequence as at loss time:
-        # nothing else draws in between) and the clear of the backward's accumulators (free since the previous
-        # backward, which is in front of `begun` on this stream) -- is queued before the forward, so that the
-        # chain behind the forward is the three Pearson launches only.
+        # nothing else draws in between) -- is queued before the forward, so that the chain behind the forward is the
+        # three Pearson launches only.  (Until round 3 the side stream also cleared the backward's accumulators here,
+        # behind an event that kept the fill clear of the previous backward: the per-Gaussian backward now leaves them
+        # zero itself, FSGS_FLAG_SCRATCH_SELF_CLEAN, and the event packet in front of the forward is gone.)
         side = self._side_stream(dev, view)
-        begun = torch.cuda.Event()
-        begun.record()
-        side.wait_event(begun)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side):  # (nothing here depends on the current stream: no event in front of the forward)
             cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
-            b.bwd_scratch.zero_()
         args, state, sbytes, cap, nr = self._render_forward(w2c, b, tracking=getattr(self, "mapping_planes4", False),
                                                             allow_reuse=allow_reuse)
         fwd_done = torch.cuda.Event()
@@ -685,7 +686,6 @@ class FastStepper:
                                                              _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
                                                              _lib.ptr(b.d_flow), _lib.current_stream()),
                                "fsgs_flow_pose_loss_fused")
-                    b.bwd_scratch.zero_()  # the backward's accumulators (previous iteration's readers are behind pose_ready)
                     flow_done = torch.cuda.Event()
                     flow_done.record()
                     wd.record_stream(side)

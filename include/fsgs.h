@@ -65,6 +65,11 @@ enum {
 /* fsgs_render_backward*: the caller has already zeroed the first P * 64 bytes of `scratch` (e.g. on another stream,
  * beside the loss kernels); the call does not enqueue its own fill in front of the backward blend */
 #define FSGS_FLAG_SCRATCH_ZEROED 4
+/* fsgs_render_backward*: the per-Gaussian backward stores zeros over every accumulator row once it has read it, so the
+ * first P * 64 bytes of `scratch` are zero again when the call's kernels have run.  A caller that starts from a zeroed
+ * scratch and passes SCRATCH_ZEROED | SCRATCH_SELF_CLEAN on every backward never clears it again (19 MB more stores inside a
+ * bandwidth-bound kernel instead of a fill launch and the stream bookkeeping around it). */
+#define FSGS_FLAG_SCRATCH_SELF_CLEAN 16
 /* fsgs_render_forward: blend only the RGB planes and the depth plane -- out_depth_sil planes 1 (silhouette) and 2
  * (depth^2) are NOT written.  For the tracking iteration (train.py:166-200), which reads the image and `depth > 0` and
  * nothing else; the state it leaves serves the pose-only backward unchanged. */
