@@ -525,3 +525,76 @@ def test_randomised_image_sizes_step_driver_equals_autograd(seed):
         out.append(l[0].item())
     assert abs(out[0] - out[1]) <= 2e-3 * abs(out[0]), (W, H, P, out)
     assert torch.allclose(a[1].r, b[1].r, rtol=0, atol=4e-4) and torch.allclose(a[1].t, b[1].t, rtol=0, atol=4e-4)
+
+
+def test_every_backward_of_the_step_driver_leaves_its_accumulators_zero():
+    """FSGS_FLAG_SCRATCH_SELF_CLEAN: the per-Gaussian backward stores zeros over the accumulator rows it has read, so the
+    driver never clears its scratch (allocated zero) -- after every kind of step (Adam inside the backward, compact gradient
+    of one and of two views, full gradients, the pose-only tracking backward, the row-chunked producer route) the first
+    P * 64 bytes must be zero again, on every buffer set that was used; and the C-ABI flag itself: the same backward with
+    and without it gives the same gradients."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+    from fsgs_amd.flow import FlowTargets
+
+    pc, poses, frames, cam = _world()
+    H, W = 256, 320
+    fs = FastStepper(pc, poses, frames)
+    assert fs._cfg().flags & _lib.FSGS_FLAG_SCRATCH_SELF_CLEAN
+    poses.initialize_tracking_optimizer(50)
+    tg = FlowTargets(frames.monodeps[0].reshape(1, H, W), np.eye(4, dtype=np.float32), cam["K"], frames.flows_fw[0], None)
+
+    def clean():
+        torch.cuda.synchronize()
+        bufs = [fs.buf] + list(fs.__dict__.get("_view_bufs", {}).values())
+        P = pc.num_points
+        return all(int(b.bwd_scratch[:P * 64].count_nonzero()) == 0 for b in bufs if b is not None)
+
+    fs.mapping_step([1]); assert clean()
+    fs.mapping_step([2, 1]); assert clean()
+    fs.tracking_step(1, tg, None); assert clean()
+    fs.mapping_step([0, 1, 2]); assert clean()
+    fs.mapping_step([1], step_optimizer=False); assert clean()
+    fs.mapping_step([2], reduce_compact=lambda t: None); assert clean()
+
+    class Chunked:  # the producer-side route of N > 1 (dist.ProducerPipelinedReducer), two row chunks, no exchange
+        producer = True
+
+        def bounds(self, P):
+            mid = (P // 2) // 256 * 256
+            return [(0, mid), (mid, P)]
+
+        def produced(self, gc, lo, hi): pass
+        def __call__(self, t): pass
+        def finish(self, *a, **k): pass
+
+    try:
+        fs.mapping_step([1], reduce_compact=Chunked())
+    except (AttributeError, TypeError):  # (the stub does not carry the whole reducer protocol: the backward ran, which is the point)
+        pass
+    assert clean()
+    fs.tracking_step(2, tg, None); assert clean()
+    # the flag at the C ABI: same gradients with and without it; without it the rows keep their sums
+    args, state, sbytes, cap, nr = fs._render_forward(poses.get_pose_detached(1), fs.buf)
+    b = fs.buf
+    b.d_image.normal_(); b.d_depth_sil.zero_(); b.d_depth_sil[0].normal_()
+    outs = []
+    for flags_off in (0, _lib.FSGS_FLAG_SCRATCH_SELF_CLEAN):
+        cfg = _lib.FsgsRasterCfg()
+        C.memmove(C.byref(cfg), C.byref(fs._cfg()), C.sizeof(cfg))
+        cfg.flags &= ~flags_off
+        gc = torch.zeros((pc.num_points, 14), device=DEV)
+        tail = _lib.FsgsStepTail()
+        b.bwd_scratch.zero_()
+        _lib.check(fs.lib.fsgs_render_backward_compact(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii), _lib.ptr(state),
+                                                       sbytes, cap, nr, _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil), _lib.ptr(gc), None,
+                                                       C.byref(tail), _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(),
+                                                       _lib.current_stream()), "fsgs_render_backward_compact")
+        torch.cuda.synchronize()
+        outs.append((gc.clone(), int(b.bwd_scratch[:pc.num_points * 64].count_nonzero())))
+    (g_clean, nz_clean), (g_plain, nz_plain) = outs
+    assert nz_clean == 0 and nz_plain > 0
+    # (two runs of the same backward differ by the arrival order of the blend's float atomics only)
+    assert ((g_clean - g_plain).abs() > 1e-5 * g_plain.abs().max()).float().mean().item() < 2e-3
+    b.bwd_scratch.zero_()
