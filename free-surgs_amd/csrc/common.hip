@@ -22,6 +22,14 @@ int fsgs_fail_hip(hipError_t e, const char *expr, const char *file, int line) {
   return FSGS_ERR_HIP;
 }
 
+// ---- completion event of the next forward (fsgs_forward_done_event) ----
+static thread_local hipEvent_t g_forward_done = nullptr;
+hipEvent_t take_forward_done_event() {
+  hipEvent_t e = g_forward_done;
+  g_forward_done = nullptr;
+  return e;
+}
+
 // ---- mailbox ----------------------------------------------------------------------------------
 static std::once_flag g_mail_once;
 static uint32_t *g_mail_base = nullptr;
@@ -175,6 +183,27 @@ __global__ void selftest_splat_alpha_kernel(int n, const float *__restrict__ in,
 }  // namespace
 
 extern "C" {
+int fsgs_event_create(fsgs_event_t *event) {
+  if (!event) return FSGS_ERR_INVALID;
+  hipEvent_t e = nullptr;
+  FSGS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (fsgs_event_t)e;
+  return FSGS_OK;
+}
+int fsgs_event_destroy(fsgs_event_t event) {
+  if (!event) return FSGS_OK;
+  FSGS_HIP(hipEventDestroy((hipEvent_t)event));
+  return FSGS_OK;
+}
+int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event) {
+  if (!event) return FSGS_ERR_INVALID;
+  FSGS_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return FSGS_OK;
+}
+int fsgs_forward_done_event(fsgs_event_t event) {
+  fsgs::g_forward_done = (hipEvent_t)event;
+  return FSGS_OK;
+}
 int fsgs_selftest_splat_alpha(int n, const float *in8, float *out2, fsgs_stream_t stream) {
   if (n < 0 || (n > 0 && (!in8 || !out2))) return FSGS_ERR_INVALID;
   if (n == 0) return FSGS_OK;

@@ -2,6 +2,7 @@
 // render.hip (fused render).  See raster.hip for the design notes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1424,7 +1425,7 @@ inline int finish_binning(const CamParams &cam, FwdBuffers &B, int64_t max_pairs
 template <int C, bool WITH_DEPTH = true>
 int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
                      const float4 *rec, float *final_T, uint32_t *n_contrib,
-                     float *out_color, float *out_color2, float *out_depth, hipStream_t s) {
+                     float *out_color, float *out_color2, float *out_depth, hipStream_t s, hipEvent_t done = nullptr) {
   static int dbg_lds = diag_env("FSGS_DBG_LDS_FWD") ? atoi(diag_env("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
   static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
       diag_env("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
@@ -1432,8 +1433,13 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_FWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_FWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_FWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_FWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
-  hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
-                     final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
+  if (done)  // the launch's own completion signals the event: no marker packet behind the kernel (fsgs_forward_done_event)
+    hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam, ntiles,
+                          dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
+                          dbg_times);
+  else
+    hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
+                       final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
   return 0;
 }
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>

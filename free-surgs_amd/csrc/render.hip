@@ -748,6 +748,13 @@ static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRender
                                const void *prev_state, size_t prev_state_bytes, int64_t prev_max_pairs,
                                const float *color_cache = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
+  // fsgs_forward_done_event: the event rides on the forward blend's launch; a call that leaves before that launch records it
+  // the plain way on its way out, so that a waiter never hangs on a forward that did not happen
+  struct DoneEvent {
+    hipEvent_t e;
+    hipStream_t s;
+    ~DoneEvent() { if (e) (void)hipEventRecord(e, s); }
+  } done{take_forward_done_event(), stream};
   if (!cfg || P < 0 || !out_image || !out_depth_sil || !state || !scratch || !num_rendered || max_pairs < 0)
     return FSGS_ERR_INVALID;
   if (!args_ok(args, P) || (P > 0 && !radii)) return FSGS_ERR_INVALID;
@@ -785,10 +792,11 @@ static int render_forward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRender
     ProfScope ps(PROF_BLEND_FWD, stream);
     if (cfg->flags & FSGS_FLAG_RGB_DEPTH_ONLY)  // tracking: image + depth plane, 16 instead of 24 accumulators per lane
       launch_blend_fwd<4, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
-                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream);
+                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream, done.e);
     else
       launch_blend_fwd<6, false>(cam, ntiles, B.order, B.ranges, B.plist, B.rec, B.final_T,
-                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream);
+                                 B.n_contrib, out_image, out_depth_sil, nullptr, stream, done.e);
+    done.e = nullptr;  // signalled by the launch
   }
   FSGS_HIP(hipGetLastError());
   // only now does the host look at R (the blend is already queued behind the binning)

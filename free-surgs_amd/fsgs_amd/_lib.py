@@ -183,6 +183,10 @@ _PROTOTYPES = {
                                 _vp]),
     "fsgs_densify_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pearson_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fsgs_event_create": (_i, [C.POINTER(C.c_void_p)]),
+    "fsgs_event_destroy": (_i, [_vp]),
+    "fsgs_stream_wait_event": (_i, [_vp, _vp]),
+    "fsgs_forward_done_event": (_i, [_vp]),
 }
 
 

@@ -14,6 +14,7 @@ Equivalence with the autograd path is asserted in tests/test_fast_step_gpu.py.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -165,7 +166,7 @@ class FastStepper:
             self._cfgt, self._cfgt_of = z, base
         return self._cfgt
 
-    def _render_forward(self, w2c, b, tracking=False, allow_reuse=True):
+    def _render_forward(self, w2c, b, tracking=False, allow_reuse=True, done_event=None):
         # tracking = True: FSGS_FLAG_RGB_DEPTH_ONLY, the forward blends image + depth plane only (tracking AND mapping steps)
         pc, lib = self.pc, self.lib
         p = pc.params
@@ -209,6 +210,8 @@ class FastStepper:
                 sz = b.sizes[cap] = (sb.value, xb.value)
             state = torch.empty((sz[0],), dtype=torch.uint8, device=dev)
             scratch = torch.empty((sz[1],), dtype=torch.uint8, device=dev)
+            if done_event is not None:  # signalled by the forward blend's own completion (one-shot: set before every attempt)
+                _lib.check(lib.fsgs_forward_done_event(done_event), "fsgs_forward_done_event")
             if cached is not None:
                 cached[1].record_stream(torch.cuda.current_stream())
                 rc = lib.fsgs_render_forward_cached_colors(
@@ -411,11 +414,17 @@ class FastStepper:
         side = self._side_stream(dev, view)
         with torch.cuda.stream(side):  # (nothing here depends on the current stream: no event in front of the forward)
             cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+        # the side stream's Pearson chain waits for the forward's outputs: an event that rides on the forward blend's launch
+        # (fsgs_forward_done_event) instead of a marker recorded behind it, which would sit between the blend and the first
+        # loss kernel on this stream (~6 us)
+        if getattr(b, "fwd_event", None) is None:
+            ev = C.c_void_p()
+            _lib.check(self.lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
+            b.fwd_event = ev
+            weakref.finalize(b, self.lib.fsgs_event_destroy, ev)
         args, state, sbytes, cap, nr = self._render_forward(w2c, b, tracking=getattr(self, "mapping_planes4", False),
-                                                            allow_reuse=allow_reuse)
-        fwd_done = torch.cuda.Event()
-        fwd_done.record()
-        return {"args": args, "state": state, "sbytes": sbytes, "cap": cap, "nr": nr, "fwd_done": fwd_done, "cr": cr,
+                                                            allow_reuse=allow_reuse, done_event=b.fwd_event)
+        return {"args": args, "state": state, "sbytes": sbytes, "cap": cap, "nr": nr, "fwd_done": b.fwd_event, "cr": cr,
                 "side": side, "ts": ts}
 
     def _view_losses(self, b, ctx, H, W, n_patches):
@@ -430,7 +439,7 @@ class FastStepper:
             3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
             _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
             "fsgs_photometric_loss_forward_backward")
-        side.wait_event(ctx["fwd_done"])
+        _lib.check(lib.fsgs_stream_wait_event(C.c_void_p(side.cuda_stream), ctx["fwd_done"]), "fsgs_stream_wait_event")
         ready = getattr(self.frames.monodeps, "ready", None)  # a staged lane: the side stream reads the mono-depth too
         if ready is not None and ready(ts) is not None:
             side.wait_event(ready(ts))

@@ -94,6 +94,18 @@ typedef struct FsgsRasterCfg {
 } FsgsRasterCfg;
 
 /* Library / build identification. */
+/* Completion events without a marker packet.  An event recorded BETWEEN two kernels of a stream costs a packet of its own in
+ * front of the second one (~6 us on MI355X); fsgs_forward_done_event(ev) instead makes the NEXT fsgs_render_forward* call of
+ * this thread signal `ev` with the completion of its last kernel (the forward blend: hipExtLaunchKernelGGL's stop event), so
+ * that another stream can wait for the forward's outputs while the calling stream goes on to its next kernel at once.
+ * One-shot (call it before every forward that should signal; a call that fails before its blend launch records the event
+ * the plain way); fsgs_stream_wait_event = hipStreamWaitEvent. */
+typedef void *fsgs_event_t; /* hipEvent_t */
+int fsgs_event_create(fsgs_event_t *event);
+int fsgs_event_destroy(fsgs_event_t event);
+int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event);
+int fsgs_forward_done_event(fsgs_event_t event);
+
 const char *fsgs_version(void);
 const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP */
 

@@ -598,3 +598,50 @@ def test_every_backward_of_the_step_driver_leaves_its_accumulators_zero():
     # (two runs of the same backward differ by the arrival order of the blend's float atomics only)
     assert ((g_clean - g_plain).abs() > 1e-5 * g_plain.abs().max()).float().mean().item() < 2e-3
     b.bwd_scratch.zero_()
+
+
+def test_forward_done_event_orders_another_stream_behind_the_forward_blend():
+    """fsgs_forward_done_event: the next fused forward signals the event with its blend launch (no marker packet behind
+    it); a second stream that waits for it must see the finished image -- also when the forward is repeated on the same
+    buffers with other poses -- and a forward that fails before its blend records the event the plain way (the wait
+    returns).  The event API rejects null handles."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+
+    pc, poses, frames, cam = _world()
+    fs = FastStepper(pc, poses, frames)
+    lib = fs.lib
+    ev = C.c_void_p()
+    _lib.check(lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
+    assert ev.value
+    assert lib.fsgs_stream_wait_event(_lib.current_stream(), None) == _lib.FSGS_ERR_INVALID
+    assert lib.fsgs_event_create(None) == _lib.FSGS_ERR_INVALID
+    other = torch.cuda.Stream()
+    H, W = 256, 320
+    b = fs._buffers(pc.num_points, H, W, 2, torch.device(DEV, torch.cuda.current_device()))
+    for t in (1, 2, 0, 1):
+        w2c = poses.get_pose_detached(t)
+        b.image.fill_(-5.0)  # (on the current stream, in front of the forward)
+        fs._render_forward(w2c, b, allow_reuse=False, done_event=ev)
+        _lib.check(lib.fsgs_stream_wait_event(C.c_void_p(other.cuda_stream), ev), "fsgs_stream_wait_event")
+        with torch.cuda.stream(other):
+            seen = b.image.clone()  # reads behind the event only
+        torch.cuda.synchronize()
+        ref = b.image.clone()
+        assert torch.equal(seen, ref) and float(ref.min()) >= 0.0 and float(ref.max()) > 0.0, t
+    # a forward that leaves before its blend: the event is recorded anyway and a later waiter does not hang
+    _lib.check(lib.fsgs_forward_done_event(ev), "fsgs_forward_done_event")
+    cfg = fs._cfg()
+    nr = C.c_int64(0)
+    rc = lib.fsgs_render_forward(C.byref(cfg), -1, None, None, None, None, None, 0, None, 0, 0, C.byref(nr), _lib.current_stream())
+    assert rc == _lib.FSGS_ERR_INVALID
+    _lib.check(lib.fsgs_stream_wait_event(C.c_void_p(other.cuda_stream), ev), "fsgs_stream_wait_event")
+    with torch.cuda.stream(other):
+        torch.zeros(1, device=DEV).add_(1)
+    other.synchronize()
+    # the one-shot is spent: an ordinary forward afterwards does not touch the event
+    fs._render_forward(poses.get_pose_detached(1), b, allow_reuse=False)
+    torch.cuda.synchronize()
+    _lib.check(lib.fsgs_event_destroy(ev), "fsgs_event_destroy")
+    assert lib.fsgs_event_destroy(None) == _lib.FSGS_OK
