@@ -30,6 +30,13 @@ hipEvent_t take_forward_done_event() {
   return e;
 }
 
+static thread_local hipEvent_t g_pose_step_done = nullptr;
+hipEvent_t take_pose_step_done_event() {
+  hipEvent_t e = g_pose_step_done;
+  g_pose_step_done = nullptr;
+  return e;
+}
+
 // ---- mailbox ----------------------------------------------------------------------------------
 static std::once_flag g_mail_once;
 static uint32_t *g_mail_base = nullptr;
@@ -202,6 +209,10 @@ int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event) {
 }
 int fsgs_forward_done_event(fsgs_event_t event) {
   fsgs::g_forward_done = (hipEvent_t)event;
+  return FSGS_OK;
+}
+int fsgs_pose_step_done_event(fsgs_event_t event) {
+  fsgs::g_pose_step_done = (hipEvent_t)event;
   return FSGS_OK;
 }
 int fsgs_selftest_splat_alpha(int n, const float *in8, float *out2, fsgs_stream_t stream) {

@@ -35,6 +35,7 @@ constexpr uint32_t kMailboxEmpty = 0xFFFFFFFFu;
 volatile uint32_t *mailbox_acquire();
 // the event the next fused forward of this thread signals with its blend launch (fsgs_forward_done_event); cleared by the take
 hipEvent_t take_forward_done_event();
+hipEvent_t take_pose_step_done_event();  // the same for the next fsgs_pose_adam_step (fsgs_pose_step_done_event)
 // spins until *slot != kMailboxEmpty; gives up (returns false) when the stream reports an error or is idle
 // without the slot having been written
 bool mailbox_wait(volatile uint32_t *slot, hipStream_t stream, uint32_t *value);

@@ -4,6 +4,7 @@
 // normalises again).  In PyTorch this is ~15 tiny kernels forward and ~30 backward per tracking iteration;
 // 7 floats in, 16 out.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <math.h>
@@ -132,16 +133,25 @@ int fsgs_pose_adam_step(float *r, float *t, int num_cams, int cam_id, const floa
                         float *exp_avg_sq_t, float lr_r, float lr_t, int step_r, int step_t, double beta1, double beta2,
                         double eps, float *w2c_next, fsgs_stream_t stream) {
   if (!r || !t || !dw2c_a || !exp_avg_r || !exp_avg_sq_r || !exp_avg_t || !exp_avg_sq_t || num_cams <= 0 ||
-      cam_id < 0 || cam_id >= num_cams || step_r < 1 || step_t < 1)
+      cam_id < 0 || cam_id >= num_cams || step_r < 1 || step_t < 1) {
+    if (hipEvent_t done = fsgs::take_pose_step_done_event()) (void)hipEventRecord(done, (hipStream_t)stream);
     return FSGS_ERR_INVALID;
+  }
   // the host arithmetic of fsgs_adam_step
   const float ss_r = (float)((double)lr_r / (1.0 - pow(beta1, (double)step_r)));
   const float ib_r = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step_r)));
   const float ss_t = (float)((double)lr_t / (1.0 - pow(beta1, (double)step_t)));
   const float ib_t = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)step_t)));
-  hipLaunchKernelGGL(pose_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, r, t, num_cams, cam_id, dw2c_a,
-                     weight_a, dw2c_b, exp_avg_r, exp_avg_sq_r, exp_avg_t, exp_avg_sq_t, ss_r, ib_r, ss_t, ib_t,
-                     (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, w2c_next);
+  // fsgs_pose_step_done_event: the update's own completion signals the event (no marker packet behind the launch), so that
+  // the next iteration's second stream can wait for the new pose while this stream goes straight on
+  if (hipEvent_t done = fsgs::take_pose_step_done_event())
+    hipExtLaunchKernelGGL(pose_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nullptr, done, 0, r, t, num_cams,
+                          cam_id, dw2c_a, weight_a, dw2c_b, exp_avg_r, exp_avg_sq_r, exp_avg_t, exp_avg_sq_t, ss_r, ib_r, ss_t,
+                          ib_t, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, w2c_next);
+  else
+    hipLaunchKernelGGL(pose_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, r, t, num_cams, cam_id, dw2c_a,
+                       weight_a, dw2c_b, exp_avg_r, exp_avg_sq_r, exp_avg_t, exp_avg_sq_t, ss_r, ib_r, ss_t, ib_t,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, w2c_next);
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;
 }

@@ -187,6 +187,7 @@ _PROTOTYPES = {
     "fsgs_event_destroy": (_i, [_vp]),
     "fsgs_stream_wait_event": (_i, [_vp, _vp]),
     "fsgs_forward_done_event": (_i, [_vp]),
+    "fsgs_pose_step_done_event": (_i, [_vp]),
 }
 
 

@@ -680,9 +680,18 @@ class FastStepper:
                 # i.e. as the forward blend starts, and the bandwidth-bound flow kernels then share the GPU with the
                 # issue-bound blend instead of with the latency-bound binning kernels (which they slowed by ~10 us)
                 side = self._side_stream(dev)
-                pose_ready = torch.cuda.Event()
-                pose_ready.record()
-                side.wait_event(pose_ready)
+                # the second stream needs the pose.  From the second iteration of a frame on that is the w2c the previous
+                # iteration's pose update produced, and the update's launch carried an event (fsgs_pose_step_done_event):
+                # wait for that -- everything the previous iteration enqueued on this stream lies in front of it -- instead
+                # of recording a marker here, in front of this iteration's first kernel (~6 us)
+                riding = self.__dict__.get("_pose_event_for")
+                if fused_pose and riding is not None and riding[0] is w2c and riding[1] is targets:
+                    _lib.check(lib.fsgs_stream_wait_event(C.c_void_p(side.cuda_stream), self._pose_event), "fsgs_stream_wait_event")
+                else:
+                    pose_ready = torch.cuda.Event()
+                    pose_ready.record()
+                    side.wait_event(pose_ready)
+                self._pose_event_for = None
                 M = int(targets.pts.shape[0])
                 need = int(lib.fsgs_flow_scratch_bytes(M))
                 if b.flow_scratch is None or b.flow_scratch.numel() < need:
@@ -729,7 +738,16 @@ class FastStepper:
                     # scheduler first, as train.py:189,194; then ONE launch: w_rgb dW_rgb + dW_flow -> pose adjoint ->
                     # Adam -> the next iteration's w2c
                     poses.scheduler.step()
+                    if self.__dict__.get("_pose_event") is None:
+                        ev = C.c_void_p()
+                        _lib.check(lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
+                        self._pose_event = ev
+                        weakref.finalize(self, lib.fsgs_event_destroy, ev)
+                    _lib.check(lib.fsgs_pose_step_done_event(self._pose_event), "fsgs_pose_step_done_event")
                     poses.fused_step(t, d_total, float(LOSS_W_TRACKING["rgb"]), b.d_flow)
+                    # (valid for the next call only if it tracks the same frame with the pose this update produced and
+                    # the same flow targets, which were formed on this stream before)
+                    self._pose_event_for = (poses.pred_w2c[int(t)], targets)
                     return total, rgb, flow
                 # d_total = w_rgb * dL_rgb/dw2c + w_flow * dL_flow/dw2c
                 if float(LOSS_W_TRACKING["rgb"]) != 1.0:

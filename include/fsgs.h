@@ -105,6 +105,8 @@ int fsgs_event_create(fsgs_event_t *event);
 int fsgs_event_destroy(fsgs_event_t event);
 int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event);
 int fsgs_forward_done_event(fsgs_event_t event);
+/* the same for the next fsgs_pose_adam_step of this thread: the event is signalled when the updated pose (w2c_next) exists */
+int fsgs_pose_step_done_event(fsgs_event_t event);
 
 const char *fsgs_version(void);
 const char *fsgs_last_error(void); /* thread-local text of the last FSGS_ERR_HIP */
