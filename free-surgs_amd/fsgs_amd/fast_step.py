@@ -421,7 +421,7 @@ class FastStepper:
             ev = C.c_void_p()
             _lib.check(self.lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
             b.fwd_event = ev
-            weakref.finalize(b, self.lib.fsgs_event_destroy, ev)
+            weakref.finalize(b, self.lib.fsgs_event_destroy, ev).atexit = False  # (at interpreter exit the runtime cleans up itself)
         args, state, sbytes, cap, nr = self._render_forward(w2c, b, tracking=getattr(self, "mapping_planes4", False),
                                                             allow_reuse=allow_reuse, done_event=b.fwd_event)
         return {"args": args, "state": state, "sbytes": sbytes, "cap": cap, "nr": nr, "fwd_done": b.fwd_event, "cr": cr,
@@ -742,7 +742,7 @@ class FastStepper:
                         ev = C.c_void_p()
                         _lib.check(lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
                         self._pose_event = ev
-                        weakref.finalize(self, lib.fsgs_event_destroy, ev)
+                        weakref.finalize(self, lib.fsgs_event_destroy, ev).atexit = False
                     _lib.check(lib.fsgs_pose_step_done_event(self._pose_event), "fsgs_pose_step_done_event")
                     poses.fused_step(t, d_total, float(LOSS_W_TRACKING["rgb"]), b.d_flow)
                     # (valid for the next call only if it tracks the same frame with the pose this update produced and
