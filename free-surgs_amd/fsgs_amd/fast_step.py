@@ -623,10 +623,6 @@ class FastStepper:
             totals.append(loss_k)
         for e in joins:
             main.wait_event(e)
-        total = totals[0]
-        for t_ in totals[1:]:
-            total = total + t_
-        self._compact_total = total
         b0 = views[0]
         # Adam reads at most two gradient buffers: further views (the reference never has more than two) are added up
         for extra in views[2:]:
@@ -657,6 +653,12 @@ class FastStepper:
             adam_rows(0, P)
         optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
         self._colors_cached(self._adam_next_colors)
+        # the step's scalar loss (reporting only): summed BEHIND the Adam launch -- in front of it the little add kernel and its
+        # dispatch gap sat on the step's critical path (two-view step: ~8 us)
+        total = totals[0]
+        for t_ in totals[1:]:
+            total = total + t_
+        self._compact_total = total
         return b0.radii, views[-1], state, cap
 
     # ---- tracking (train.py:166-200) -----------------------------------------------------------------------
