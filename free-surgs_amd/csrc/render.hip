@@ -899,6 +899,24 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   const size_t need = (size_t)P * kFusedRow * sizeof(float);
   if (scratch_bytes < need) return FSGS_ERR_CAPACITY;
   if (((uintptr_t)scratch) & 15) return FSGS_ERR_INVALID;  // the accumulator rows are read as float4
+  // EVERY argument is validated before the first launch: the blend backward accumulates into `scratch`, and a caller that
+  // runs with FSGS_FLAG_SCRATCH_ZEROED relies on the per-Gaussian kernel behind it to leave the rows zero again -- a
+  // rejected call must not have touched them
+  StepTailDev td{};
+  if (tail) {
+    if (tail->xyz_gradient_accum || tail->denom || tail->max_radii2D) {
+      // all three (view 0 of a step) or max_radii2D alone (a further view: the radius side effect only)
+      const bool all3 = tail->xyz_gradient_accum && tail->denom && tail->max_radii2D;
+      const bool radii_only = tail->max_radii2D && !tail->xyz_gradient_accum && !tail->denom;
+      if (!all3 && !radii_only) return FSGS_ERR_INVALID;
+      td.max_radii2D = tail->max_radii2D; td.accum = tail->xyz_gradient_accum; td.denom = tail->denom;
+    }
+    if (tail->loss_total) {
+      if (!tail->loss_terms || !tail->loss_weights || tail->n_terms < 0 || tail->n_terms > 16) return FSGS_ERR_INVALID;
+      td.terms = tail->loss_terms; td.weights = tail->loss_weights; td.n_terms = tail->n_terms;
+      td.total = tail->loss_total;
+    }
+  }
   CamParams cam = make_cam(cfg);
   for (int ch = 3; ch < 6; ch++) cam.bg[ch] = cfg->bg[ch - 3];
   const int ntiles = cam.gx * cam.gy;
@@ -944,21 +962,6 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
              (clean ? MODE_CLEAN_ACC : 0);
   RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
                      grads->rotation, grads->means2D, grads->w2c, compact};
-  StepTailDev td{};
-  if (tail) {
-    if (tail->xyz_gradient_accum || tail->denom || tail->max_radii2D) {
-      // all three (view 0 of a step) or max_radii2D alone (a further view: the radius side effect only)
-      const bool all3 = tail->xyz_gradient_accum && tail->denom && tail->max_radii2D;
-      const bool radii_only = tail->max_radii2D && !tail->xyz_gradient_accum && !tail->denom;
-      if (!all3 && !radii_only) return FSGS_ERR_INVALID;
-      td.max_radii2D = tail->max_radii2D; td.accum = tail->xyz_gradient_accum; td.denom = tail->denom;
-    }
-    if (tail->loss_total) {
-      if (!tail->loss_terms || !tail->loss_weights || tail->n_terms < 0 || tail->n_terms > 16) return FSGS_ERR_INVALID;
-      td.terms = tail->loss_terms; td.weights = tail->loss_weights; td.n_terms = tail->n_terms;
-      td.total = tail->loss_total;
-    }
-  }
   if (row_hi > row_lo) {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     if (adam)

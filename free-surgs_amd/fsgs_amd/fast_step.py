@@ -67,6 +67,11 @@ class _Buffers:
         self.means2D_grad = f(P, 3)
         # the backward's accumulator rows: zero here and zero again behind every backward (FSGS_FLAG_SCRATCH_SELF_CLEAN)
         self.bwd_scratch = torch.zeros((P * 64 + 512,), dtype=torch.uint8, device=dev)
+        # True while a backward is under way: raised before its first launch, lowered when its LAST row chunk has been
+        # enqueued.  A backward that raises in between (a rejected argument, an exchange that failed between two row chunks)
+        # leaves it up, and the next backward of this buffer set runs without FSGS_FLAG_SCRATCH_ZEROED, i.e. clears the rows
+        # itself instead of trusting them
+        self.scratch_dirty = False
         self.sizes = {}
 
 
@@ -154,6 +159,18 @@ class FastStepper:
             z.flags |= _lib.FSGS_FLAG_SCRATCH_ZEROED
             self._cfgz, self._cfgz_of = z, base
         return self._cfgz
+
+    def _cfg_backward(self, b, trust=True):
+        """configuration of a backward on buffer set `b`: the accumulator rows are known to be zero (SCRATCH_ZEROED) unless
+        the previous backward on them did not run to its end (or trust=False: the call clears them itself); marks the set
+        dirty until _backward_done(b)"""
+        cfg = self._cfg() if (b.scratch_dirty or not trust) else self._cfg_zeroed()
+        b.scratch_dirty = True
+        return cfg
+
+    @staticmethod
+    def _backward_done(b):
+        b.scratch_dirty = False
 
     def _cfg_tracking(self):
         """the same configuration with FSGS_FLAG_RGB_DEPTH_ONLY: the tracking iteration reads the image and the depth
@@ -359,12 +376,13 @@ class FastStepper:
 
     def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
                          param_grads, zeroed=False):
-        cfg = self._cfg_zeroed() if zeroed else self._cfg()
+        cfg = self._cfg_backward(b, trust=zeroed)
         rc = self.lib.fsgs_render_backward(C.byref(cfg), self.pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                            _lib.ptr(state), sbytes, cap, nr, _lib.ptr(d_image), _lib.ptr(d_depth_sil),
                                            int(gs_grad), int(cam_grad), int(param_grads), C.byref(grads),
                                            _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(), _lib.current_stream())
         _lib.check(rc, "fsgs_render_backward")
+        self._backward_done(b)
 
     @staticmethod
     def _grad_struct(tensors, means2D, w2c):
@@ -495,7 +513,7 @@ class FastStepper:
                 ts = timesteps[0]
                 args, state, sbytes, cap, nr, _ = self._view_forward_and_losses(b, ts, corners, dev, H, W, n_patches, 0)
                 adam = self._fused_adam_struct()
-                cfg = self._cfg_zeroed()
+                cfg = self._cfg_backward(b)
                 # statistics and the scalar loss ride in the same launch (no densify_stats / dot kernels)
                 tail, total, _keep = self._step_tail(b, b.term_w, collect_stats)
                 _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
@@ -504,6 +522,7 @@ class FastStepper:
                                                          _lib.ptr(b.means2D_grad) if collect_stats else None,
                                                          C.byref(tail), _lib.ptr(b.bwd_scratch),
                                                          b.bwd_scratch.numel(), stream), "fsgs_render_backward_adam")
+                self._backward_done(b)
                 optim.mark_updated([pc.params[n_] for n_ in PARAM_NAMES])
                 self._colors_cached(self._adam_next_colors)
                 step_optimizer = False  # done
@@ -596,7 +615,7 @@ class FastStepper:
                 # the densification statistic comes from view 0 only (train.py:260-263); the other views of the step raise
                 # max_radii2D, as every render() does (gaussian_renderer/__init__.py:79) -- both inside the backward launch
                 m2 = b.means2D_grad if (first and collect_stats) else None
-                cfg = self._cfg_zeroed()
+                cfg = self._cfg_backward(b)
                 tail, loss_k, _keep = self._step_tail(b, b.term_w, (True if first else "radii") if collect_stats else False)
                 # one view per step and a producer-side reducer (N > 1): the per-Gaussian backward goes out in row
                 # chunks, the all-reduce of each chunk starts while the next one is produced (dist.py)
@@ -609,6 +628,7 @@ class FastStepper:
                             None if m2 is None else _lib.ptr(m2), C.byref(tail), _lib.ptr(b.bwd_scratch),
                             b.bwd_scratch.numel(), lo, hi, int(ci == 0), stream), "fsgs_render_backward_compact_rows")
                         reduce_compact.produced(b.gc, lo, hi)
+                    self._backward_done(b)  # (every row chunk went out: each one cleaned its own rows)
                 else:
                     _lib.check(lib.fsgs_render_backward_compact(C.byref(cfg), P, C.byref(args), _lib.ptr(b.radii),
                                                                 _lib.ptr(state), sbytes, cap, nr, _lib.ptr(b.d_image),
@@ -616,6 +636,7 @@ class FastStepper:
                                                                 None if m2 is None else _lib.ptr(m2), C.byref(tail),
                                                                 _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(), stream),
                                "fsgs_render_backward_compact")
+                    self._backward_done(b)
                 if vstream is not main:
                     done = torch.cuda.Event()
                     done.record()

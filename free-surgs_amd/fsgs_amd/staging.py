@@ -47,6 +47,10 @@ class StagedLane:
         self.capacity = max(1, int(capacity))
         self.copy_stream = copy_stream
         self.cache = collections.OrderedDict()  # frame -> (device tensor, copy-done event or None), least recently used first
+        # frames whose copy was started by prefetch(protect=True) and that nobody has looked up yet: not evicted (ADVICE r3:
+        # progressive_run asks for frame t+1 a whole frame cycle ahead, and the ~30 random keyframes of the mapping
+        # iterations in between would otherwise push it out of a 4-buffer lane before it is read)
+        self.protected = set()
         self.free = []
         self.hits = self.misses = self.prefetched = 0
         first = next((h for h in self.host if h is not None), None)
@@ -69,9 +73,23 @@ class StagedLane:
     def _cuda(self):
         return self.device.type == "cuda"
 
+    def _victim(self):
+        """least recently used resident frame that is not protected (the oldest protected one when all are: capacity
+        smaller than the number of outstanding prefetches)"""
+        for k in self.cache:
+            if k not in self.protected:
+                return k
+        k = next(iter(self.cache))
+        self.protected.discard(k)
+        return k
+
     def _load(self, i, asynchronous, fence=None):
         evicted = not self.free
-        buf = self.free.pop() if self.free else self.cache.popitem(last=False)[1][0]
+        old_done = None
+        if self.free:
+            buf = self.free.pop()
+        else:
+            buf, old_done = self.cache.pop(self._victim())
         done = None
         if self._cuda():
             cur = torch.cuda.current_stream(self.device)
@@ -80,6 +98,10 @@ class StagedLane:
                 # everything enqueued so far may still read the evicted frame (one fence serves all the copies a caller
                 # starts together: StagedFrames.prefetch hands the same one to its lanes)
                 (fence if fence is not None else Fence()).hold(cur, stream)
+            if old_done is not None:
+                # the evicted frame's own copy may still be in flight on the copy stream (prefetched, never read): the new
+                # copy into the same buffer is ordered behind it whichever stream it runs on
+                stream.wait_event(old_done)
             with torch.cuda.stream(stream):
                 buf.copy_(self.host[i], non_blocking=True)
                 done = torch.cuda.Event()
@@ -88,10 +110,13 @@ class StagedLane:
             buf.copy_(self.host[i])
         self.cache[i] = (buf, done)
 
-    def prefetch(self, i, fence=None):
-        """start copying frame i (no-op when it is resident, out of range or absent)"""
+    def prefetch(self, i, fence=None, protect=False):
+        """start copying frame i (no-op when it is resident, out of range or absent); protect=True keeps it resident until
+        its first lookup"""
         if i is None or i < 0 or i >= len(self.host) or self.host[i] is None:
             return
+        if protect and len(self.protected) < self.capacity - 1:  # (at least one buffer stays evictable)
+            self.protected.add(int(i))
         if i in self.cache:
             self.cache.move_to_end(i)
             return
@@ -110,6 +135,7 @@ class StagedLane:
             i += len(self.host)
         if self.host[i] is None:
             return None
+        self.protected.discard(i)
         if i in self.cache:
             self.hits += 1
             self.cache.move_to_end(i)
@@ -169,17 +195,18 @@ class StagedFrames(FrameData):
         self.pred_depths = RecentWindow(len(lanes[0]), keep=cap)
         self.device = dev
 
-    def prefetch(self, t, flows=True):
+    def prefetch(self, t, flows=True, protect=False):
         """frame t's colours and mono-depth and, with `flows`, the flows its tracking reads (t-1 -> t for the flow loss,
-        t-2 -> t-1 for the rigid mask; trainer.Runner.tracking) -- a mapping view needs the first two only"""
+        t-2 -> t-1 for the rigid mask; trainer.Runner.tracking) -- a mapping view needs the first two only.
+        protect=True: what is fetched stays resident until it is first read (the next FRAME, asked for a frame cycle ahead)"""
         if t is None:
             return
         fence = Fence()
-        self.colors.prefetch(t, fence)
-        self.monodeps.prefetch(t, fence)
+        self.colors.prefetch(t, fence, protect)
+        self.monodeps.prefetch(t, fence, protect)
         if flows and self.flows_fw is not None:
-            self.flows_fw.prefetch(t - 1, fence)
-            self.flows_fw.prefetch(t - 2, fence)
+            self.flows_fw.prefetch(t - 1, fence, protect)
+            self.flows_fw.prefetch(t - 2, fence, protect)
 
     def stats(self):
         lanes = {"colors": self.colors, "monodeps": self.monodeps, "flows_fw": self.flows_fw}

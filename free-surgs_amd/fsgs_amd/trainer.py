@@ -241,8 +241,13 @@ class Runner:
 
     def __init__(self, pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, fused=True,
                  seed=0, densify=True, row0_depth_quirk=True, densify_interval=300, opacity_reset_interval=3000,
-                 densify_until=15000, trace=False, test_frame_quirks=True):
+                 densify_until=15000, trace=False, test_frame_quirks=True, profile=False):
         import random
+
+        # profile=True: wall time of every phase of a frame cycle / the global loop, each bracketed by a device
+        # synchronisation, appended to self.phase_ms as (tag, frame or iteration, ms) -- bench.py's `harness` extra and
+        # scripts/harness_trace.py read it; off by default (the synchronisations are the cost)
+        self.phase_ms = [] if profile else None
 
         # train.py:305-311: densify_and_prune at iteration % 300 == 0 while iteration < 15000, opacity reset at % 3000.
         # (Parameters so that a pinned short trajectory can cross a densification, tests/test_harness_pin_gpu.py.)
@@ -280,6 +285,26 @@ class Runner:
         H, W = (getattr(frames.colors, "shape", None) or frames.colors[0].shape)[-2:]  # a staged lane knows its item shape
         self.h, self.w = int(H), int(W)
 
+    def _phase(self, tag, idx):
+        """context manager: with profile=True the wall time of the block, device work included, lands in self.phase_ms"""
+        import contextlib
+        import time
+
+        if getattr(self, "phase_ms", None) is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def timed():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            try:
+                yield
+            finally:
+                torch.cuda.synchronize()
+                self.phase_ms.append((tag, idx, (time.perf_counter() - t0) * 1e3))
+
+        return timed()
+
     # ---- train.py:297-316 -------------------------------------------------------------------------------
     def densification(self):
         from . import dist as fdist
@@ -288,24 +313,29 @@ class Runner:
         if not self.densify:
             return
         if it % self.densify_interval == 0 and it < self.densify_until:
-            fdist.sync_densification_stats(self.pc)
-            size_threshold = 20 if it > 4000 else None
-            if self.fast is not None:  # one plan + one gather on the device (csrc/densify.hip)
-                self.pc.densify_and_prune_device(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
-            else:
-                self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
+            with self._phase("densify_and_prune", it):
+                fdist.sync_densification_stats(self.pc)
+                size_threshold = 20 if it > 4000 else None
+                if self.fast is not None:  # one plan + one gather on the device (csrc/densify.hip)
+                    self.pc.densify_and_prune_device(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
+                else:
+                    self.pc.densify_and_prune(self.pc.opt.densify_grad_threshold, 0.05, size_threshold)
             if self.trace is not None:
                 self.trace.append(("densify", it, self.pc.num_points))
         if it % self.opacity_reset_interval == 0:
             self.pc.reset_opacity()
 
-    def mapping(self, cur_t, mapping_iter, progressive):
+    def mapping(self, cur_t, mapping_iter, progressive, want_pkg=True):
+        """want_pkg=False (global_run, train.py:386-393: the reference copies the render to the host there and nothing reads
+        it): no render is handed back.  Otherwise the returned `render` / `render_dep` are VIEWS of the step driver's
+        buffers, valid until the next step is enqueued (progressive_run copies what it keeps, _stored_depth)."""
         views = 2 if (progressive and cur_t != 0) else 1
         self.pc.optimizer.zero_grad(set_to_none=True)
         pkg = None
         # the keyframe of the NEXT iteration is drawn during this one (same draws, same order, none more than train.py:239's
         # one per iteration), so that a staged sequence can have it on the device in time
         nxt = self.rng.choice(self.keyframes) if (views == 2 and mapping_iter > 0) else None
+        self._prefetch(nxt, flows=False)  # (the first keyframe of the call as well: ADVICE r3)
         for k in range(mapping_iter):
             self.iteration += 1
             ts = [nxt, cur_t] if views == 2 else [cur_t]
@@ -339,10 +369,13 @@ class Runner:
                 self.pc.optimizer.step()
                 self.pc.optimizer.zero_grad(set_to_none=True)
             pkg = _first if views == 1 else None
+        if not want_pkg:
+            return None
         if pkg is None and self.fast is not None and self.fast.last:
             # the reference returns the render of the LAST view of the LAST iteration (cur_t), taken before that
-            # iteration's optimizer step (train.py:236-265, 291): exactly what the step driver still holds
-            pkg = {"render": self.fast.last["image"].clone(), "render_dep": self.fast.last["depth_sil"][0].clone()}
+            # iteration's optimizer step (train.py:236-265, 291): exactly what the step driver still holds -- handed out
+            # as views (round 3 cloned 21 MB here after every call, global_run's single iterations included)
+            pkg = {"render": self.fast.last["image"], "render_dep": self.fast.last["depth_sil"][0], "views_of_step_buffers": True}
         if pkg is None:
             with torch.no_grad():
                 pkg = (render if self.fused else render_two_pass)(self.poses, cur_t, self.pc, gs_grad=False, cam_grad=False)
@@ -353,62 +386,85 @@ class Runner:
 
         # Sampson-distance rigid mask of frame t-2 under the optimised poses t-2, t-1 (train.py:157-165); all rigid
         # for t <= 1.  Once per frame: two launches (csrc/flow.hip), no sync beyond reading the two 4x4 poses.
-        dev = self._frames_device()
         rigid = None
-        if t > 1 and self.frames.flows_fw is not None:
-            from .epipolar import fundamental_from_w2c, rigid_mask
+        with self._phase("tracking.rigid_mask", t):
+            if t > 1 and self.frames.flows_fw is not None:
+                from .epipolar import fundamental_from_w2c, rigid_mask
 
-            with torch.no_grad():  # get_fundamental_matrix asks the network, not get_pose: pred_w2c is not refreshed
-                Fm = fundamental_from_w2c(self.poses.peek_pose(t - 2), self.poses.peek_pose(t - 1), self.frames.K)
-            rigid, self.last_sampson, _ = rigid_mask(self.frames.flows_fw[t - 2], Fm)
-        all_rigid = rigid is None
-        if all_rigid:
-            rigid = torch.ones((self.h, self.w), dtype=torch.bool, device=dev)
-        depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
-        targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
+                with torch.no_grad():  # get_fundamental_matrix asks the network, not get_pose: pred_w2c is not refreshed
+                    # (both poses in ONE device-to-host copy: each .cpu() is a synchronisation of its own)
+                    pair = torch.stack((self.poses.peek_pose(t - 2), self.poses.peek_pose(t - 1))).cpu().numpy()
+                    Fm = fundamental_from_w2c(pair[0], pair[1], self.frames.K)
+                rigid, self.last_sampson, _ = rigid_mask(self.frames.flows_fw[t - 2], Fm)
+            all_rigid = rigid is None
+        with self._phase("tracking.flow_targets", t):
+            depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
+            # rigid=None = every pixel rigid (t <= 1): no H x W mask of ones is built, the kernels take a null pointer
+            targets = FlowTargets(depth_prev, self.poses.pred_w2c[t - 1], self.frames.K, self.frames.flows_fw[t - 1], rigid)
         out = None
         rendered_last = None
-        for it_ in range(self.tracking_iter):
-            if it_ == self.tracking_iter - 1 and self.test_frame_quirks and t not in self.frames.i_train:
-                with torch.no_grad():
-                    rendered_last = self.poses.peek_pose(t).detach().clone()
-            if self.fast is not None:
-                # the loss values are only logged once per frame (the reference prints them every iteration through
-                # .item(), i.e. a host sync per iteration)
-                out = self.fast.tracking_step(t, targets, None if all_rigid else rigid,
-                                              want_losses=self.trace is not None or it_ == self.tracking_iter - 1) + (None,)
-            else:
-                out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
-            if self.trace is not None:
-                self.trace.append(("track", t, it_, float(out[0]), float(out[1]), float(out[2])))
+        with self._phase("tracking.iterations", t):
+            for it_ in range(self.tracking_iter):
+                if it_ == self.tracking_iter - 1 and self.test_frame_quirks and t not in self._train_set():
+                    with torch.no_grad():
+                        rendered_last = self.poses.peek_pose(t).detach().clone()
+                if self.fast is not None:
+                    # the loss values are only logged once per frame (the reference prints them every iteration through
+                    # .item(), i.e. a host sync per iteration)
+                    out = self.fast.tracking_step(t, targets, None if all_rigid else rigid,
+                                                  want_losses=self.trace is not None or it_ == self.tracking_iter - 1) + (None,)
+                else:
+                    out = tracking_step(self.pc, self.poses, self.frames, t, targets, rigid, fused=False)
+                if self.trace is not None:
+                    self.trace.append(("track", t, it_, float(out[0]), float(out[1]), float(out[2])))
         if rendered_last is not None:
             self.poses.pred_w2c[t] = rendered_last
         return out
+
+    def _train_set(self):
+        """frames.i_train as a set (built once: `t in ndarray` is a scan, and list(i_train) per global iteration a copy)"""
+        arr = self.frames.i_train
+        hit = self.__dict__.get("_train_cache")
+        if hit is None or hit[0] is not arr:  # (the array object itself is kept: an id() alone can be recycled)
+            lst = [int(i) for i in arr]
+            hit = self._train_cache = (arr, frozenset(lst), lst)
+        return hit[1]
+
+    def _train_list(self):
+        self._train_set()
+        return self._train_cache[2]
 
     def progressive_run(self):
         n = len(self.frames.colors)
         self.poses.initialize_tracking_optimizer(self.tracking_iter)
         with torch.no_grad():
             self.poses.get_pose(0)
+        train = self._train_set()
         for t in range(n):
-            self._prefetch(t + 1)  # staged sequences (fsgs_amd/staging.py): the next frame's inputs travel while this one is optimised
+            # staged sequences (fsgs_amd/staging.py): the next frame's inputs travel while this one is optimised, and stay
+            # resident until frame t + 1 reads them whatever keyframes the mapping iterations in between pull through the lanes
+            self._prefetch(t + 1, protect=True)
             self.pc.update_learning_rate(self.iteration)
             if t > 0:
-                if t > 1:
-                    self.poses.initialize_pose(t)
-                else:
-                    with torch.no_grad():
-                        self.poses.r[..., t] = self.poses.r[..., t - 1]
-                        self.poses.t[..., t] = self.poses.t[..., t - 1]
-                self.poses.initialize_tracking_optimizer(self.tracking_iter)
-                loss, rgb, flow, _ = self.tracking(t)
-                self.log.append(("track", t, float(loss), float(rgb), float(flow)))
-            if t in self.frames.i_train:
+                with self._phase("frame.setup", t):
+                    if t > 1:
+                        self.poses.initialize_pose(t)
+                    else:
+                        with torch.no_grad():
+                            self.poses.r[..., t] = self.poses.r[..., t - 1]
+                            self.poses.t[..., t] = self.poses.t[..., t - 1]
+                    self.poses.initialize_tracking_optimizer(self.tracking_iter)
+                with self._phase("frame.tracking", t):
+                    loss, rgb, flow, _ = self.tracking(t)
+                # the three logged values in ONE device-to-host copy (three float() calls are three synchronisations)
+                self.log.append(("track", t) + tuple(float(v) for v in torch.stack((loss, rgb, flow)).tolist()))
+            if t in train:
                 if self.iteration % 1000 == 0:
                     self.pc.oneupSHdegree()
                 it = self.first_mapping_iter if t == 0 else self.mapping_iter
-                pkg = self.mapping(t, it, progressive=True)
-                self.frames.pred_depths[t] = self._stored_depth(pkg)
+                with self._phase("frame.mapping", t):
+                    pkg = self.mapping(t, it, progressive=True)
+                    self.frames.pred_depths[t] = self._stored_depth(pkg)
                 self.keyframes.append(t)
             elif self.frames.pred_depths[t] is None:
                 if self.test_frame_quirks:  # never rendered upstream: the next frame's flow loss sees no valid depth
@@ -419,10 +475,13 @@ class Runner:
                         pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
                     self.frames.pred_depths[t] = self._stored_depth(pkg)
 
-    def _prefetch(self, t, flows=True):
+    def _prefetch(self, t, flows=True, protect=False):
         pf = getattr(self.frames, "prefetch", None)
         if pf is not None and t is not None and 0 <= t < len(self.frames.colors):
-            pf(int(t), flows=flows)
+            if protect:
+                pf(int(t), flows=flows, protect=True)
+            else:
+                pf(int(t), flows=flows)
 
     def _frames_device(self):
         return getattr(self.frames, "device", None) or self.frames.colors[0].device
@@ -430,7 +489,9 @@ class Runner:
     def _stored_depth(self, pkg):
         d = pkg["render_dep"].detach().float()
         if self.row0_depth_quirk:
-            return d[0].expand(self.h, self.w).contiguous()
+            return d[0].expand(self.h, self.w).contiguous()  # (a copy: never aliases the step driver's buffer)
+        if pkg.get("views_of_step_buffers"):
+            return d.clone()  # what mapping() handed out is overwritten by the next step
         return d.contiguous()
 
     def global_run(self, iterations, first_iter=0, eval_every=5000, model_path=None, save_every=5000):
@@ -445,15 +506,16 @@ class Runner:
         self.eval_log = getattr(self, "eval_log", [])
         # the frame of iteration it + 1 is drawn while iteration it is set up (the same draws in the same order: nothing else
         # takes from self.rng in this loop), so that a staged sequence can start its copy one iteration ahead
-        nxt = int(self.rng.choice(list(self.frames.i_train))) if iterations + 1 > int(first_iter) else None
+        train = self._train_list()  # (random.choice over the same sequence draws the same elements as over list(i_train))
+        nxt = int(self.rng.choice(train)) if iterations + 1 > int(first_iter) else None
         for it in range(int(first_iter), iterations + 1):
             ts = nxt
-            nxt = int(self.rng.choice(list(self.frames.i_train))) if it < iterations else None
+            nxt = int(self.rng.choice(train)) if it < iterations else None
             self._prefetch(nxt, flows=False)
             if it % 1000 == 0:
                 self.pc.oneupSHdegree()
             self.pc.update_learning_rate(it)
-            self.mapping(ts, 1, progressive=False)
+            self.mapping(ts, 1, progressive=False, want_pkg=False)
             if eval_every and it % eval_every == 0 and len(self.frames.i_test):
                 self.validation()
                 self.eval_log.append((it, dict(self.last_validation)))

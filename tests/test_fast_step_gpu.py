@@ -600,6 +600,68 @@ def test_every_backward_of_the_step_driver_leaves_its_accumulators_zero():
     b.bwd_scratch.zero_()
 
 
+def test_an_aborted_backward_does_not_poison_the_following_steps():
+    """the driver runs its backwards with FSGS_FLAG_SCRATCH_ZEROED and trusts each one to leave the accumulator rows
+    zero.  (a) A call the library REJECTS (here: an inconsistent FsgsStepTail) must not have launched the blend -- the rows
+    stay zero; (b) a row-chunked backward that stops between two chunks (the exchange of dist.ProducerPipelinedReducer
+    raising) leaves rows dirty: the driver notices and the next step clears them itself, so its update is the update of an
+    undisturbed driver."""
+    import ctypes as C
+
+    from fsgs_amd import _lib
+
+    pc, poses, frames, cam = _world()
+    fs = FastStepper(pc, poses, frames)
+    fs.mapping_step([1])
+    b = fs.buf
+    P = pc.num_points
+    # (a) rejected before anything is launched
+    args, state, sbytes, cap, nr = fs._render_forward(poses.get_pose_detached(1), b)
+    b.d_image.normal_(); b.d_depth_sil.zero_(); b.d_depth_sil[0].normal_()
+    tail = _lib.FsgsStepTail()
+    tail.xyz_gradient_accum = pc.variables["xyz_gradient_accum"].data_ptr()  # ... without denom / max_radii2D: invalid
+    gc = torch.zeros((P, 14), device=DEV)
+    rc = fs.lib.fsgs_render_backward_compact(C.byref(fs._cfg_zeroed()), P, C.byref(args), _lib.ptr(b.radii), _lib.ptr(state),
+                                             sbytes, cap, nr, _lib.ptr(b.d_image), _lib.ptr(b.d_depth_sil), _lib.ptr(gc), None,
+                                             C.byref(tail), _lib.ptr(b.bwd_scratch), b.bwd_scratch.numel(), _lib.current_stream())
+    torch.cuda.synchronize()
+    assert rc == _lib.FSGS_ERR_INVALID
+    assert int(b.bwd_scratch[:P * 64].count_nonzero()) == 0 and int(gc.count_nonzero()) == 0
+
+    # (b) a producer route whose exchange dies after the first row chunk
+    class Dies:
+        producer = True
+
+        def bounds(self, P_):
+            mid = (P_ // 2) // 256 * 256
+            return [(0, mid), (mid, P_)]
+
+        def produced(self, gc_, lo, hi):
+            raise RuntimeError("exchange failed")
+
+    snap = {n: pc.params[n].detach().clone() for n in PARAM_NAMES}
+    with pytest.raises(RuntimeError, match="exchange failed"):
+        fs.mapping_step([1], reduce_compact=Dies())
+    torch.cuda.synchronize()
+    assert b.scratch_dirty and int(b.bwd_scratch[:P * 64].count_nonzero()) > 0  # the second half's rows hold the blend's sums
+    assert all(torch.equal(snap[n], pc.params[n].detach()) for n in PARAM_NAMES)  # no Adam ran
+    # an undisturbed twin in the same state (same parameters, fresh moments on both sides)
+    pc2, poses2, frames2, _ = _world()
+    for n in PARAM_NAMES:
+        pc2.params[n].data.copy_(snap[n])
+    pc.training_setup(); pc2.training_setup()
+    fs2 = FastStepper(pc2, poses2, frames2)
+    cr = losses.draw_patch_corners(256, 320, 128, 0.5, DEV)
+    fs.mapping_step([2], reduce_compact=lambda t: None, corners=cr)
+    fs2.mapping_step([2], reduce_compact=lambda t: None, corners=cr)
+    torch.cuda.synchronize()
+    assert not b.scratch_dirty and int(b.bwd_scratch[:P * 64].count_nonzero()) == 0
+    for n in PARAM_NAMES:  # first Adam step = lr * sign-like: compare the updates, atomics-order tolerance
+        da, db = pc.params[n].detach() - snap[n], pc2.params[n].detach() - snap[n]
+        bad = ((da - db).abs() > 0.05 * db.abs().max()).float().mean().item()
+        assert bad < 1e-2, (n, bad)
+
+
 def test_forward_done_event_orders_another_stream_behind_the_forward_blend():
     """fsgs_forward_done_event: the next fused forward signals the event with its blend launch (no marker packet behind
     it); a second stream that waits for it must see the finished image -- also when the forward is repeated on the same

@@ -44,6 +44,32 @@ def test_prefetch_turns_the_following_lookup_into_a_hit():
     assert lane.prefetched == 4
 
 
+def test_a_protected_prefetch_survives_the_keyframes_pulled_through_the_lane_until_it_is_read():
+    """progressive_run asks for frame t+1 before frame t's 50 tracking + 30 two-view mapping iterations; the
+    random keyframes of those iterations must not push it out of a 4-buffer lane"""
+    lane = StagedLane(_items(12), "cpu", capacity=4)
+    lane[5]                                 # the current frame
+    lane.prefetch(6, protect=True)          # the next frame, a whole cycle ahead
+    for k in (0, 1, 2, 3, 0, 2, 1, 3, 0, 1):  # keyframes of the mapping iterations, each prefetched one iteration ahead
+        lane.prefetch(k)
+        lane[5]
+        lane[k]
+    assert 6 in lane.cache and 6 in lane.protected
+    misses = lane.misses
+    assert float(lane[6].mean()) == 6.0 and lane.misses == misses  # a hit, and the protection ends with the first read
+    assert 6 not in lane.protected
+    for k in (7, 8, 9, 10):
+        lane[k]
+    assert 6 not in lane.cache              # ... after which it ages out like any other frame
+    # never more than capacity - 1 protected frames: one buffer always stays evictable
+    small = StagedLane(_items(6), "cpu", capacity=2)
+    small.prefetch(0, protect=True)
+    small.prefetch(1, protect=True)
+    assert small.protected == {0}
+    small.prefetch(2)
+    assert set(small.cache) == {0, 2} and float(small[0].mean()) == 0.0
+
+
 def test_absent_entries_and_mismatched_shapes():
     lane = StagedLane([None, torch.ones(2, 2), None], "cpu", capacity=4)
     assert lane[0] is None and lane[2] is None and float(lane[1].sum()) == 4.0
@@ -112,7 +138,7 @@ def test_global_run_draws_the_frames_in_the_reference_order_and_prefetches_one_i
 
     run = Runner.__new__(Runner)
     run.rng, run.frames, run.pc = random.Random(7), Frames(), Cloud()
-    run.mapping = lambda ts, views, progressive: run.frames.events.append(("map", ts))
+    run.mapping = lambda ts, views, progressive, want_pkg=True: run.frames.events.append(("map", ts))
     run.global_run(11, eval_every=0)
     want_rng = random.Random(7)
     want = [int(want_rng.choice(list(Frames.i_train))) for _ in range(12)]  # range(0, iterations + 1): 12 steps
@@ -162,7 +188,8 @@ def test_progressive_mapping_draws_its_keyframes_in_the_reference_order_too():
     run.mapping(6, 9, progressive=True)
     want_rng = random.Random(3)
     want = [want_rng.choice([0, 1, 2, 3, 5]) for _ in range(9)]
-    assert run.fast.seen == [[k, 6] for k in want] and run.frames.prefetched == want[1:]
+    # every keyframe is asked for before its iteration, the first one of the call included
+    assert run.fast.seen == [[k, 6] for k in want] and run.frames.prefetched == want
     assert run.rng.random() == want_rng.random()
     run.mapping(0, 4, progressive=True)  # frame 0 is mapped alone: no draw at all
     assert run.fast.seen[-4:] == [[0]] * 4 and run.rng.random() == want_rng.random()

@@ -92,6 +92,39 @@ def test_harness_on_a_staged_sequence_follows_the_resident_run():
     assert fb.pred_depths[n - 1] is not None and fb.pred_depths[1] is None  # only the recent depths are kept
 
 
+def test_a_frame_finds_its_inputs_resident_when_its_tracking_starts():
+    """frame t+1 is prefetched before frame t's iterations; with four buffers per lane and a random keyframe per
+    mapping iteration it used to be evicted again before it was read (a wasted copy and a synchronous miss per frame).
+    Every first lookup of a frame's colours / flows in tracking(t) must be a hit, and so must every keyframe lookup."""
+    from fsgs_amd.sequence import learner_from_first_frame, make_sequence
+    from fsgs_amd.trainer import PoseTrack, Runner
+
+    W, H, n = 320, 256, 8
+    torch.manual_seed(0)
+    resident, cam = make_sequence(W, H, n, P=20000, seed=2)
+    frames = _staged_copy(resident, capacity=4)
+    pc = learner_from_first_frame(resident, cam, ratio=0.25)
+    run = Runner(pc, PoseTrack(n, "cuda"), frames, tracking_iter=6, mapping_iter=12, first_mapping_iter=10,
+                 row0_depth_quirk=False)
+    at_start = []
+    orig = run.tracking
+
+    def tracking(t):
+        before = {k: v.misses for k, v in (("colors", frames.colors), ("flows_fw", frames.flows_fw))}
+        assert t in frames.colors.cache and (t - 1) in frames.flows_fw.cache, "frame %d was evicted before its tracking" % t
+        out = orig(t)
+        at_start.append((t, {k: getattr(frames, k).misses - v for k, v in before.items()}))
+        return out
+
+    run.tracking = tracking
+    run.progressive_run()
+    torch.cuda.synchronize()
+    assert len(at_start) == n - 1 and all(m == {"colors": 0, "flows_fw": 0} for _, m in at_start), at_start
+    st = frames.stats()
+    # the only colour misses of the whole run: frame 0 (nothing could have been asked for earlier)
+    assert st["colors"]["misses"] <= 1 and st["monodeps"]["misses"] <= 1 and st["flows_fw"]["misses"] == 0, st
+
+
 def test_read_sequence_can_stage(tmp_path):
     from fsgs_amd import dataset
     from fsgs_amd.sequence import make_sequence, write_frames
