@@ -150,6 +150,138 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
                       "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
 
 
+def harness_extra(cfg_name, device, scene="default"):
+    """The loop BASELINE.json's metric names ("train iters/sec ... joint pose+GS optimisation as in train.py"): the harness
+    counterpart of FreeSurGS.progressive_run / global_run (train.py:318-443; fsgs_amd/trainer.py:Runner) on this
+    configuration's cloud, timed inside this process behind the headline loop.
+
+      progressive: Runner.progressive_run over the 8 synthetic frames -- frame 0: 200 one-view mapping iterations; every
+        further frame: pose initialisation + fresh pose Adam, the Sampson rigid mask (t >= 2), the flow targets, 50 tracking
+        iterations, and for a training frame 30 two-view mapping iterations (+ densify_and_prune when the iteration counter
+        reaches 300).  Phase times from Runner(profile=True): each phase bracketed by a device synchronisation.
+      global: Runner.global_run, 300 iterations (fresh Adam, random training frame per iteration, xyz learning-rate
+        schedule, densification statistics, densify_and_prune at iteration 300), one synchronisation at either end.
+    """
+    from fsgs_amd.trainer import Runner
+
+    W, H, P, _ = CONFIGS[cfg_name]
+
+    def problem():
+        pc, poses, frames, cam, sc = build_problem(cfg_name, device, 0, 1, scene=scene)
+        n = len(frames.colors)
+        zero_flow = torch.zeros((2, H, W), dtype=torch.float32, device=device)  # a static camera's flow: timing only
+        frames.flows_fw = [zero_flow] * (n - 1)
+        frames.K = cam["K"]
+        from fsgs_amd.trainer import PoseTrack
+
+        return pc, PoseTrack(n, device), frames  # (every pose starts at the identity, as progressive_run expects)
+
+    out = {}
+    # ---- progressive_run, profiled ----
+    pc, poses, frames = problem()
+    run = Runner(pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200, profile=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.progressive_run()
+    torch.cuda.synchronize()
+    wall_profiled = (time.perf_counter() - t0) * 1e3
+    ph = run.phase_ms
+    by = lambda tag: {t: ms for k, t, ms in ph if k == tag}
+    setup, track, mapp = by("frame.setup"), by("frame.tracking"), by("frame.mapping")
+    rigid, targets, iters = by("tracking.rigid_mask"), by("tracking.flow_targets"), by("tracking.iterations")
+    dens = [(t, ms) for k, t, ms in ph if k == "densify_and_prune"]
+    # steady frames: t >= 2 (frame 1 pays the one-time costs: first launches of the flow kernels, torch.sort's workspace, the
+    # tracking buffers; it is reported on its own), training frames with no densification inside their mapping
+    n = len(frames.colors)
+    dens_frames = set()
+    it_at = 200
+    for t in range(1, n):
+        if t in set(int(i) for i in frames.i_train):
+            if any(it_at < d <= it_at + 30 for d, _ in dens):
+                dens_frames.add(t)
+            it_at += 30
+    steady = [t for t in range(2, n)]
+    steady_map = [t for t in steady if t in mapp and t not in dens_frames]
+    mean = lambda xs: float(sum(xs) / len(xs)) if xs else None
+    trk = mean([track[t] for t in steady])
+    out["progressive"] = {
+        "frames": n, "gaussians_start": P, "gaussians_end": pc.num_points,
+        "tracking_ms_per_frame": trk,
+        "tracking_iterations_ms_per_frame": mean([iters[t] for t in steady]),
+        "tracking_ms_per_iter": mean([iters[t] for t in steady]) / 50.0,
+        "per_frame_setup_ms": {"pose_init_and_optimizer": mean([setup[t] for t in steady]),
+                               "rigid_mask": mean([rigid[t] for t in steady]),
+                               "flow_targets": mean([targets[t] for t in steady]),
+                               "sum": mean([setup[t] + rigid[t] + targets[t] for t in steady])},
+        "first_tracked_frame_ms": {"setup": setup.get(1), "tracking": track.get(1), "iterations": iters.get(1)},
+        "mapping_ms_per_frame": mean([mapp[t] for t in steady_map]),
+        "mapping_ms_per_iter_two_views": mean([mapp[t] for t in steady_map]) / 30.0 if steady_map else None,
+        "first_frame_mapping_ms": mapp.get(0), "first_frame_mapping_ms_per_iter": mapp.get(0, 0.0) / 200.0,
+        "ms_per_frame": (mean([setup[t] + track[t] for t in steady]) or 0.0) + (mean([mapp[t] for t in steady_map]) or 0.0),
+        "densify_and_prune": [{"iteration": d, "ms": ms} for d, ms in dens],
+        "wall_ms_profiled": wall_profiled,
+        "what": "Runner.progressive_run (train.py:318-345): per steady frame = pose init + pose Adam/MultiStepLR + Sampson "
+                "rigid mask + flow targets + 50 tracking iterations + 30 two-view mapping iterations; profile=True brackets "
+                "every phase with a device synchronisation",
+    }
+    out["progressive"]["iters_per_sec"] = 80.0 / (out["progressive"]["ms_per_frame"] * 1e-3) if out["progressive"]["ms_per_frame"] else None
+    # the same run without the phase synchronisations: what the profile costs
+    pc, poses, frames = problem()
+    run = Runner(pc, poses, frames, tracking_iter=50, mapping_iter=30, first_mapping_iter=200)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.progressive_run()
+    torch.cuda.synchronize()
+    out["progressive"]["wall_ms_unprofiled"] = (time.perf_counter() - t0) * 1e3
+    del run, pc, poses, frames
+
+    # ---- global_run ----
+    pc, poses, frames = problem()
+    run = Runner(pc, poses, frames, profile=True)  # (the only phase inside global_run is densify_and_prune)
+    run.global_run(9, eval_every=0)  # warm-up: Adam state, buffers (iterations 1 .. 10 of the counter)
+    run.iteration = 0
+    torch.cuda.synchronize()
+    n_it = 300
+    t0 = time.perf_counter()
+    run.global_run(n_it - 1, eval_every=0)  # range(0, iterations + 1): n_it mapping iterations, densify at the 300th
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) * 1e3
+    dens = [ms for k, t, ms in run.phase_ms if k == "densify_and_prune"]
+    out["global"] = {
+        "iterations": n_it, "ms_total": total, "densify_and_prune_ms": dens, "gaussians_start": P,
+        "gaussians_end": pc.num_points,
+        "ms_per_iter": (total - sum(dens)) / n_it, "ms_per_iter_incl_densify": total / n_it,
+        "iters_per_sec": n_it / ((total - sum(dens)) * 1e-3),
+        "what": "Runner.global_run (train.py:378-443): fresh Adam (eps 1e-8), per iteration a random training frame, the xyz "
+                "learning-rate schedule, one one-view mapping iteration with densification statistics; densify_and_prune at "
+                "iteration 300 (timed apart); no test-frame evaluation inside the timed span",
+    }
+    return out
+
+
+
+def comm_model(nbytes, world, step_ms_one_gpu=0.651):
+    """What DESIGN.md s6 predicts for the step's one exchange on a fully connected xGMI node, stated in the line so that a
+    scaling record can be judged against it (VERDICT r3 #2c).  t = launches * a_launch + steps * a_step + wire_bytes / b:
+    every GPU has a link to every other (7 links at N = 8), both routes can keep all N - 1 links of a GPU busy, so the
+    bandwidth term is the same -- 2 (N-1)/N * S bytes per GPU over (N-1) links -- and the routes differ in their dependent
+    steps: a ring all-reduce has 2 (N-1), the direct reduce-scatter + all-gather has 2 (and two launches)."""
+    link_GBps = 64.0      # per direction and link, effective (76.8 GB/s peak = half of the 153.6 GB/s a link carries both ways)
+    a_launch, a_step = 0.020, 0.005  # ms: one collective launch end to end; one dependent hop inside a collective
+    wire_ms = 2.0 * (world - 1) / world * nbytes / ((world - 1) * link_GBps * 1e9) * 1e3
+    rccl = a_launch + 2 * (world - 1) * a_step + wire_ms
+    direct = 2 * a_launch + 2 * a_step + wire_ms + 0.010  # + the local sum of N shards
+    best = min(rccl, direct)
+    return {"rccl_ms": rccl, "direct_ms": direct, "wire_ms": wire_ms,
+            "params": {"link_GBps_per_direction": link_GBps, "links_used": world - 1, "launch_ms": a_launch,
+                       "hop_ms": a_step, "bytes": nbytes},
+            "step_ms": {"one_collective": step_ms_one_gpu + best, "per_rank_path_without_exchange": step_ms_one_gpu},
+            "weak_scaling_efficiency": 0.638 / (step_ms_one_gpu + best),
+            "note": "a model (DESIGN.md s6), not a measurement: no multi-GPU node has run this code; 0.638 / 0.651 ms are the "
+                    "round-3 single-GPU step and its compact-gradient variant at C2"}
+
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one rank
     per GPU (RCCL), pass rank 0's JSON line through, return the launcher's exit code.  Non-zero when fewer than N GPUs
@@ -256,6 +388,7 @@ def main():
                          "train.py:305-311 does every 300 iterations -- configuration 4 as BASELINE.json states it "
                          "(--config C4 --densify-every 300)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (raster-only timing, dense scene)")
+    ap.add_argument("--no-harness", action="store_true", help="skip the harness extra (Runner.progressive_run / global_run)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event timing of every kernel (adds overhead)")
     ap.add_argument("--profile-stride", type=int, default=3,
                     help="HIP-event time every n-th launch of the dominant kernels inside the timed region (each timed "
@@ -550,6 +683,17 @@ def main():
                     "what": "2 views x (fused render fwd + losses + render bwd into the compact [P,14] gradient; the second view "
                             "reuses the first view's per-Gaussian colours) + Adam from the summed gradient"}
 
+    # ---- extra: the reference's own loops through the harness (train.py:318-443), N = 1 ----
+    harness = None
+    if use_fast and world == 1 and not args.no_extras and not args.no_harness and not args.densify_every:
+        try:
+            harness = harness_extra(args.config, device, scene=args.scene)
+            harness["bare_step_ms"] = dt / args.steps * 1e3
+            harness["global"]["over_bare_step"] = harness["global"]["ms_per_iter"] / harness["bare_step_ms"]
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the measurement)
+            harness = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("bench.py: harness extra failed -- %s\n" % harness["error"])
+
     # ---- extra: the same mapping step on the DENSE scene (upstream pair count ~ SURVEY s8d's nominal) ----
     dense = None
     if use_fast and world == 1 and not args.no_extras and args.scene == "default" and args.config in ("C2", "C4") \
@@ -606,18 +750,38 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t_) / reps * 1e3
 
+        def probe(name, fn, reps=10):
+            """a diagnostic exchange on its own: an exception here (a transport that cannot run it) is recorded, it must
+            never cost the line.  Every rank takes the same branch: the error is agreed on by an all-reduce."""
+            err = None
+            try:
+                val = timed(fn, reps)
+            except Exception as e:  # noqa: BLE001
+                err, val = "%s: %s" % (type(e).__name__, str(e)[:200]), None
+            flag = torch.tensor([0.0 if err is None else 1.0], device=device)
+            try:
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            except Exception:  # noqa: BLE001
+                pass
+            if err is not None or float(flag.item()) > 0:
+                comm[name] = None
+                comm[name + "_error"] = err or "failed on another rank"
+            else:
+                comm[name] = val
+
         # the same bytes as 4 row chunks back to back (what --ar-chunks 4 issues; chunk bounds = multiples of 256 rows) and
         # one tiny message: latency vs bandwidth of this fabric, so that t(one collective) = a + bytes / b can be read off
         rows = nfloat // (14 if use_fast else 59)
         per = max(256, -(-(-(-rows // 4)) // 256) * 256)
         width = nfloat // rows
         chunks = [buf[lo * width:min(rows, lo + per) * width] for lo in range(0, rows, per)]
-        comm["chunks4_ms"] = timed(lambda: [torch.distributed.all_reduce(c) for c in chunks])
+        probe("chunks4_ms", lambda: [torch.distributed.all_reduce(c) for c in chunks])
         direct = fdist.DirectAllReduce()
-        comm["direct_ms"] = timed(lambda: direct(buf))  # all-to-all of shards + local sum + all-gather (--ar-algo direct)
+        probe("direct_ms", lambda: direct(buf))  # all-to-all of shards + local sum + all-gather (--ar-algo direct)
         comm["timed_route"] = "pipelined x%d" % args.ar_chunks if args.ar_chunks > 1 else args.ar_algo
         tiny = torch.zeros((1024,), dtype=torch.float32, device=device)
-        comm["latency_4KB_ms"] = timed(lambda: torch.distributed.all_reduce(tiny), reps=50)
+        probe("latency_4KB_ms", lambda: torch.distributed.all_reduce(tiny), reps=50)
+        comm["expected"] = comm_model(nfloat * 4, world)
         comm["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMP_NUM"))}
         try:
             comm["rccl_info"] = rccl_info_lines()
@@ -628,28 +792,32 @@ def main():
     # shows what hiding the collective behind the per-Gaussian backward and Adam is worth on this fabric ----
     pipelined = None
     if world > 1 and use_fast and not args.no_extras and args.ar_chunks == 1:
-        red4 = fdist.ProducerPipelinedReducer(4)
-        tw = time.perf_counter()
-        for it in range(5):
-            stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
-        barrier()
-        # a transport that handles small collectives badly (gloo in the one-GPU smoke) gets 5 timed steps, not 40
-        slow = torch.tensor([float((time.perf_counter() - tw) / 5 > 5 * dt / args.steps)], device=device)
-        torch.distributed.all_reduce(slow, op=torch.distributed.ReduceOp.MAX)
-        # exactly as many steps as the timed loop above, bracketed the same way: the faster of the two exchanges is the line's
-        # `value` (config.exchange says which; both times are in `exchange_routes`)
-        npipe = 5 if float(slow.item()) > 0 else args.steps
-        tp = time.perf_counter()
-        for it in range(npipe):
-            stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
-        barrier()
-        dtp = time.perf_counter() - tp
-        tt = torch.tensor([dtp], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        pipelined = {"ar_chunks": 4, "steps": npipe, "seconds": float(tt.item()),
-                     "ms_per_step": float(tt.item()) / npipe * 1e3, "iters_per_sec": npipe * world / float(tt.item()),
-                     "what": "dist.ProducerPipelinedReducer(4): all-reduce of row chunk i beside the production of chunk "
-                             "i+1 and the Adam of chunk i-1 (python bench.py --ar-chunks 4 makes it the timed route)"}
+        try:
+            red4 = fdist.ProducerPipelinedReducer(4)
+            tw = time.perf_counter()
+            for it in range(5):
+                stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
+            barrier()
+            # a transport that handles small collectives badly (gloo in the one-GPU smoke) gets 5 timed steps, not 40
+            slow = torch.tensor([float((time.perf_counter() - tw) / 5 > 5 * dt / args.steps)], device=device)
+            torch.distributed.all_reduce(slow, op=torch.distributed.ReduceOp.MAX)
+            # as many steps as the timed loop above, bracketed the same way (reported beside the configured route, never
+            # instead of it: `value` is the route --ar-chunks / --ar-algo name)
+            npipe = 5 if float(slow.item()) > 0 else args.steps
+            tp = time.perf_counter()
+            for it in range(npipe):
+                stepper.mapping_step([(rank + it * world) % n_frames], reduce_compact=red4, collect_stats=not args.no_stats)
+            barrier()
+            dtp = time.perf_counter() - tp
+            tt = torch.tensor([dtp], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            pipelined = {"ar_chunks": 4, "steps": npipe, "seconds": float(tt.item()),
+                         "ms_per_step": float(tt.item()) / npipe * 1e3, "iters_per_sec": npipe * world / float(tt.item()),
+                         "what": "dist.ProducerPipelinedReducer(4): all-reduce of row chunk i beside the production of chunk "
+                                 "i+1 and the Adam of chunk i-1 (python bench.py --ar-chunks 4 makes it the timed route); timed "
+                                 "AFTER the configured route, on a cloud that has taken 2 K further steps"}
+        except Exception as e:  # noqa: BLE001  (an extra with collectives of its own must not cost the line)
+            pipelined = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -657,16 +825,15 @@ def main():
 
     if rank == 0:
         iters = args.steps * world
-        # N > 1: the exchange is a choice of algorithm over the same step.  Both were timed over the same K steps between
-        # the same barriers; the line reports the faster one and says so
+        # N > 1: `value` is the route the command line configured (--ar-algo / --ar-chunks; default: one RCCL all_reduce).  The
+        # x4 producer-pipelined route is timed behind it over the same K steps and reported beside it -- never instead of it:
+        # it runs later, on a further-trained cloud, and roofline / kernels_ms describe the first loop
         plain_route = "pipelined x%d" % args.ar_chunks if args.ar_chunks > 1 else args.ar_algo
         exchange, routes = (plain_route if world > 1 else None), None
         if world > 1:
             routes = {plain_route: dt / args.steps * 1e3}
             if pipelined is not None and pipelined.get("steps") == args.steps:
                 routes["pipelined x4"] = pipelined["ms_per_step"]
-                if pipelined["seconds"] < dt:
-                    dt, exchange = pipelined["seconds"], "pipelined x4 (dist.ProducerPipelinedReducer)"
         out = {
             "metric": "train_iters_per_sec", "value": iters / dt, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -688,7 +855,7 @@ def main():
                 "parallelism": "dp%d" % world, "exchange": exchange, "loss": float(loss)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels_ms": kernels,
             "raster_fwd_bwd_ms": None if raster is None else raster["raster_fwd_bwd_ms"], "raster": raster,
-            "tracking_step": tracking, "two_view_mapping_step": two_view, "dense_scene": dense, "densify": densify_log or None, "comm": comm,
+            "tracking_step": tracking, "two_view_mapping_step": two_view, "dense_scene": dense, "harness": harness, "densify": densify_log or None, "comm": comm,
             "comm_pipelined": pipelined, "exchange_routes_ms_per_step": routes,
             "extras_incomplete": False,
         }

@@ -23,19 +23,28 @@ FLAGS = [
     # blend_bwd 5 % and exposed a memory round trip per row in photometric_bwd (DESIGN s3, round 3)
     "-fno-slp-vectorize",
 ]
-# FSGS_DIAG=1: the diagnostics hooks of csrc/raster_kernels.h (diag_env) -- experiments only, objects kept apart
+# FSGS_DIAG=1: the diagnostics flavour -- the hooks of csrc/raster_kernels.h (diag_env: per-tile stamps, injected dispatch
+# orders, lane-utilisation counters) and the experiment switches (FSGS_EXP_*, honoured ONLY together with the hooks).  A
+# library of its own in a directory of its own (lib/diag/libfsgs_hip.diag.so, objects beside it): the product library and
+# its objects are never touched, nothing of the flavour is loaded unless FSGS_LIB_PATH names it, and `build.py --clean-diag`
+# removes it again (nothing of it is meant to be left in the tree that travels to the GPU box at round end).
 DIAG = os.environ.get("FSGS_DIAG") == "1"
-if DIAG:
-    FLAGS.append("-DFSGS_DIAG_HOOKS")
-# A/B experiments on one GPU box: FSGS_CFLAGS="-DFOO=1" FSGS_LIB_TAG=foo builds lib/libfsgs_hip.foo.so from objects of
-# its own (the product library is untouched); FSGS_LIB_PATH=<that file> makes fsgs_amd._lib load it.
+# A/B experiments on one GPU box: FSGS_DIAG=1 FSGS_CFLAGS="-DFSGS_EXP_FOO=1" FSGS_LIB_TAG=foo builds
+# lib/diag/libfsgs_hip.foo.so from objects of its own; FSGS_LIB_PATH=<that file> makes fsgs_amd._lib load it.
 EXTRA = os.environ.get("FSGS_CFLAGS", "").split()
 TAG = os.environ.get("FSGS_LIB_TAG", "")
-if EXTRA and not TAG:
-    raise SystemExit("FSGS_CFLAGS needs FSGS_LIB_TAG (the product library is only ever built with the default flags)")
-FLAGS += EXTRA
-if TAG:
-    LIB = os.path.join(OUT_DIR, "libfsgs_hip.%s.so" % TAG)
+if EXTRA and not (TAG and DIAG):
+    raise SystemExit("FSGS_CFLAGS needs FSGS_DIAG=1 and FSGS_LIB_TAG (the product library is only ever built with the default flags)")
+if TAG and not DIAG:
+    raise SystemExit("FSGS_LIB_TAG needs FSGS_DIAG=1 (tagged libraries are diagnostics builds)")
+DIAG_DIR = os.path.join(OUT_DIR, "diag")
+if DIAG:
+    FLAGS.append("-DFSGS_DIAG_HOOKS")
+    FLAGS += EXTRA
+    OBJ_DIR = DIAG_DIR
+    LIB = os.path.join(DIAG_DIR, "libfsgs_hip.%s.so" % (TAG or "diag"))
+else:
+    OBJ_DIR = OUT_DIR
 
 
 def sources():
@@ -57,7 +66,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", (".%s.o" % TAG) if TAG else (".diag.o" if DIAG else ".o")))
+    obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", (".%s.o" % TAG) if TAG else ".o"))
     if _stale(obj, [src] + headers()):
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -69,26 +78,34 @@ def _compile(src):
 
 
 def build(force=False, verbose=False):
-    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
-        for f in os.listdir(OUT_DIR):
+        for f in os.listdir(OBJ_DIR):
             if f.endswith((".o", ".so")):
-                os.remove(os.path.join(OUT_DIR, f))
+                os.remove(os.path.join(OBJ_DIR, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, sources()))
-    stamp, flavour = LIB + ".flavour", "diag" if DIAG else "product"
-    linked_as = open(stamp).read().strip() if os.path.exists(stamp) else "product"
-    if _stale(LIB, objs) or linked_as != flavour:  # (the two flavours keep separate objects but share the library name)
+    if _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-        with open(stamp, "w") as f:
-            f.write(flavour + "\n")
     if verbose:
         print("built", LIB)
     return LIB
 
 
+def clean_diag():
+    import shutil
+
+    shutil.rmtree(DIAG_DIR, ignore_errors=True)
+    for f in os.listdir(OUT_DIR) if os.path.isdir(OUT_DIR) else []:  # leftovers of the round-3 layout
+        if f.endswith((".diag.o", ".flavour")) or (f.startswith("libfsgs_hip.") and f != "libfsgs_hip.so"):
+            os.remove(os.path.join(OUT_DIR, f))
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--clean-diag" in sys.argv:
+        clean_diag()
+    else:
+        build(force="--force" in sys.argv, verbose=True)

@@ -235,7 +235,7 @@ __device__ __forceinline__ SplatCoef splat_coef(float A, float B, float Cc) {
   // exponent that much smaller and alpha = o 2^p about |power| x 1.3e-8 ~ 4e-8 too large -- a bias, not noise (measured
   // with fsgs_selftest_splat_alpha around the 1/255 threshold: of 122 decisions that differed from float64, 85 said
   // "blend").  Staged once per (tile, Gaussian) record, not per pixel: three f64 multiplies per 64 pairs.
-#ifdef FSGS_EXP_L2E_FLOAT  // experiment builds only: the fp32 constant of rounds 1-2
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_L2E_FLOAT)  // diagnostics flavour only: the fp32 constant of rounds 1-2
   const float L2Ef = 1.44269504088896340736f;
   SplatCoef kf;
   kf.a = __fmul_rn(-0.5f * L2Ef, A);

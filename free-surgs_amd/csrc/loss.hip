@@ -22,7 +22,7 @@ using namespace fsgs;
 
 namespace {
 
-#ifdef FSGS_EXP_LOSS_DYNLDS  // experiment builds only: unused dynamic LDS = fewer workgroups of the forward kernel per CU
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_DYNLDS)  // diagnostics flavour only: unused dynamic LDS = fewer workgroups of the forward kernel per CU
 constexpr int kFwdDynLds = FSGS_EXP_LOSS_DYNLDS;
 #else
 constexpr int kFwdDynLds = 0;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   // is handed one contiguous run of tiles in (channel, row, column) order -- a band of the image -- and the 5-pixel halos
   // two neighbouring tiles both read meet in ONE L2 instead of being fetched over the fabric by two of them
   const int tiles_x = (W + SS_TILE - 1) / SS_TILE, tiles_y = (H + SS_TILE - 1) / SS_TILE;
-#ifdef FSGS_EXP_LOSS_NO_XCD
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
   const int tile_id = blockIdx.x;
 #else
   const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
   }
   // XCD-aware placement (see the forward kernel): every XCD streams one band of vertically adjacent strips, whose 10 shared
   // halo rows per boundary then come out of its own L2
-#ifdef FSGS_EXP_LOSS_NO_XCD
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
   const int strip = blockIdx.x;
 #else
   const int strip = xcd_swizzle(blockIdx.x, nstrips);

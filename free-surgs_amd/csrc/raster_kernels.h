@@ -260,21 +260,13 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
           seg[u] = (uint32_t)bin_slot(ty * gx + tx, (int)klo[u]);
-#ifdef FSGS_EXP_SCATTER_NO_ATOMICS  // experiment builds only: the scatter's floor without its slot claims (results are garbage)
-          slot[u] = (item * 2654435761u) % cap_sub;
-#else
           slot[u] = atomicAdd(&cursors[seg[u]], 1u);
-#endif
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++)
-#ifdef FSGS_EXP_SCATTER_NO_STORE  // experiment builds only: what do the scattered 8-byte key stores cost? (results are garbage)
-      if (hit[u] && slot[u] == 0xFFFFFFF0u)
-#else
       if (hit[u] && slot[u] < cap_sub)  // an overflowing segment keeps counting (the sort kernel reports it)
-#endif
         keys[(size_t)seg[u] * cap_sub + slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
   }
 }
@@ -444,7 +436,7 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
   const uint32_t rev = fold ? s_rev : 0u;
   for (int i = (int)threadIdx.x; i < ntiles; i += 256) {
     const uint32_t rank = atomicAdd(&hist[bins[i]], 1u);
-#ifdef FSGS_EXP_NO_FOLD
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_NO_FOLD)  // diagnostics flavour only: plain longest-first (a valid order)
     order[rank] = (uint32_t)i;
 #else
     const uint32_t round = rank / ORDER_FOLD, idx = rank - round * ORDER_FOLD;
@@ -521,14 +513,10 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
       const unsigned long long key = mine ? lds[t] : 0ull;
       uint32_t rank = 0;
       const ulonglong2 *pairs = reinterpret_cast<const ulonglong2 *>(lds);
-#ifdef FSGS_EXP_SORT_NO_RANK  // experiment builds only: the tile sort's floor without its rank loop (lists stay unsorted)
-      rank = (uint32_t)t;
-#else
       for (int j = 0; j < (n + 1) >> 1; j++) {
         const ulonglong2 ab = pairs[j];
         rank += (ab.x < key) + (ab.y < key);
       }
-#endif
       if (mine) plist[base + rank] = (uint32_t)key;
     } else if (n <= 2 * SORT_RANK_KEYS) {
       // 257..512 keys: two rank-sorted halves A = keys [0,256), B = keys [256,n), merged by rank: a key's final
@@ -737,6 +725,58 @@ __device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, 
   return m;
 }
 
+#ifdef FSGS_DIAG_HOOKS
+// Lane utilisation of the blend kernels (diagnostics flavour only, scripts/lane_utilisation.py): per executed
+// 8x8 quadrant body the number of lanes that really blend (forward) / carry a non-zero alpha (backward), and per
+// (tile, Gaussian) pair what a body over 64 lanes chosen by 4x4-pixel blocks could save.  Lane l owns pixel (l & 7, l >> 3)
+// of every quadrant, so 4x4 block b = 2 (y >> 2) + (x >> 2) of a quadrant is a fixed set of 16 lanes; a packed body gives
+// lane set b the pixels of ONE quadrant, so a pair needs max_b #{quadrants whose block b is alive} bodies instead of one
+// per reachable quadrant.  "alive" by the lanes that contributed (the ceiling) and by the exact footprint test on the
+// 4x4 block (what a kernel could decide up front).  Wave-uniform counters, summed into a global block of 32 u64 at the end:
+//   0 pairs  1 bodies  2 contributing lanes  3..11 bodies by contributing lanes (0 | 1-8 | ... | 57-64)
+//   12 packed bodies (contributing blocks)  13 alive blocks (contributing)  14 packed bodies (footprint test)
+//   15 alive blocks (footprint test)  16 pairs whose packed count (footprint test) is below their body count
+struct DiagLanes {
+  uint32_t pairs, bodies, lanes, packed_true, blocks_true, packed_rect, blocks_rect, pairs_gain;
+};
+__device__ __forceinline__ uint32_t diag_block_bits(unsigned long long ballot) {  // 4 bits: 4x4 blocks with a set lane
+  const unsigned long long B0 = 0x0F0F0F0Full, B1 = 0xF0F0F0F0ull;
+  return ((ballot & B0) ? 1u : 0u) | ((ballot & B1) ? 2u : 0u) | ((ballot & (B0 << 32)) ? 4u : 0u) |
+         ((ballot & (B1 << 32)) ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t diag_packed(uint32_t m16) {  // bit 4 k + b: block b of quadrant k alive
+  uint32_t best = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) best = max(best, (uint32_t)__popc((m16 >> b) & 0x1111u));
+  return best;
+}
+// footprint test of the sixteen 4x4 blocks of a tile for one Gaussian (bit 4 k + b)
+__device__ __forceinline__ uint32_t diag_block_mask16(int tile, int gx, float2 gxy, float4 gco) {
+  const float tau = footprint_tau(gco.w);
+  const float x0 = (float)((tile % gx) * FSGS_TILE), y0 = (float)((tile / gx) * FSGS_TILE);
+  uint32_t m = 0;
+  for (int k = 0; k < 4; k++)
+    for (int b = 0; b < 4; b++)
+      m |= rect_touched(gxy.x, gxy.y, gco.x, gco.y, gco.z, tau, x0 + FSGS_QUAD * (k & 1) + 4.f * (b & 1),
+                        y0 + FSGS_QUAD * (k >> 1) + 4.f * (b >> 1), 4.f, 4.f)
+               ? (1u << (4 * k + b))
+               : 0u;
+  return m;
+}
+__device__ __forceinline__ void diag_flush(unsigned long long *out, const DiagLanes &d, const uint32_t *hist, int lane) {
+  if (!out || lane != 0) return;
+  atomicAdd(out + 0, (unsigned long long)d.pairs);
+  atomicAdd(out + 1, (unsigned long long)d.bodies);
+  atomicAdd(out + 2, (unsigned long long)d.lanes);
+  for (int i = 0; i < 9; i++) atomicAdd(out + 3 + i, (unsigned long long)hist[i]);
+  atomicAdd(out + 12, (unsigned long long)d.packed_true);
+  atomicAdd(out + 13, (unsigned long long)d.blocks_true);
+  atomicAdd(out + 14, (unsigned long long)d.packed_rect);
+  atomicAdd(out + 15, (unsigned long long)d.blocks_rect);
+  atomicAdd(out + 16, (unsigned long long)d.pairs_gain);
+}
+#endif
+
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
 template <int C, bool WITH_DEPTH>
@@ -744,12 +784,16 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
-    float *__restrict__ out_depth, unsigned long long *__restrict__ dbg_times) {
+    float *__restrict__ out_depth, unsigned long long *__restrict__ dbg_times,
+    unsigned long long *__restrict__ dbg_lanes = nullptr) {
   // dbg_times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only; NULL otherwise):
   // 100 MHz wall-clock stamps of this wave's start and end, to measure load balance and the kernel's tail
   const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;
 #ifdef FSGS_DIAG_HOOKS
   uint32_t dbg_bodies = 0, dbg_pairs = 0;  // quadrant bodies executed / pairs not skipped altogether (scalar counters)
+  DiagLanes dl{};
+  __shared__ uint32_t dbg_hist[9];
+  if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
 #endif
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
   constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
@@ -800,6 +844,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+#ifdef FSGS_DIAG_HOOKS
+    const uint32_t gmask16 = dbg_lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+#endif
     // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
     // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
     __syncthreads();  // previous batch fully consumed (single-wave workgroup: this is just a wait)
@@ -828,9 +875,39 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
       const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
+#ifdef FSGS_DIAG_HOOKS
+      uint32_t dbg_m16 = 0;
+#endif
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (!((bm >> k) & 1u)) continue;  // wave-uniform
+#ifdef FSGS_DIAG_HOOKS
+        bool dbg_c = false;  // (the product body below, its per-lane `continue`s written as `break`s of a one-trip loop)
+        do {
+          if (!(T[k] > 0.f)) break;
+          SplatEval e;
+          if (!splat_alpha(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, e)) break;
+          float test_T = T[k] * (1.0f - e.alpha);
+          if (test_T < 0.0001f) {
+            T[k] = -T[k];
+            break;
+          }
+          float w = e.alpha * T[k];
+#pragma unroll
+          for (int cp = 0; cp < CP; cp++) acc[k][cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[k][cp]);
+          if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
+          T[k] = test_T;
+          last[k] = pos;
+          dbg_c = true;
+        } while (false);
+        if (dbg_lanes) {
+          const unsigned long long bal = __ballot(dbg_c);
+          const int cnt = __popcll(bal);
+          dl.lanes += (uint32_t)cnt;
+          if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
+          dbg_m16 |= diag_block_bits(bal) << (4 * k);
+        }
+#else
         if (!(T[k] > 0.f)) continue;  // finished
         SplatEval e;
         if (!splat_alpha(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, e)) continue;
@@ -845,9 +922,26 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
         T[k] = test_T;
         last[k] = pos;
+#endif
       }
+#ifdef FSGS_DIAG_HOOKS
+      if (dbg_lanes) {
+        uint32_t qsel = 0;  // the 4-bit groups of the quadrants this pair executed
+        for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
+        const uint32_t r16 = readlane(gmask16, j) & qsel;
+        const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
+        dl.pairs += 1; dl.bodies += nb;
+        dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
+        dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
+        dl.pairs_gain += pr < nb ? 1u : 0u;
+      }
+#endif
     }
   }
+#ifdef FSGS_DIAG_HOOKS
+  __syncthreads();
+  diag_flush(dbg_lanes, dl, dbg_hist, lane);
+#endif
   const size_t HW = (size_t)H * W;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -925,10 +1019,13 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
     float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16,
-    unsigned long long *__restrict__ dbg_times) {
+    unsigned long long *__restrict__ dbg_times, unsigned long long *__restrict__ dbg_lanes = nullptr) {
   const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;  // see blend_fwd_kernel
 #ifdef FSGS_DIAG_HOOKS
   uint32_t dbg_bodies = 0, dbg_pairs = 0;
+  DiagLanes dl{};
+  __shared__ uint32_t dbg_hist[9];
+  if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
 #endif
   constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;  // compile-time: shifts, no 64-bit mads
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
@@ -1014,6 +1111,9 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+#ifdef FSGS_DIAG_HOOKS
+    const uint32_t gmask16 = dbg_lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+#endif
     __syncthreads();  // records of the previous batch fully consumed
     const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
     rec[lane * REC4 + 0] = make_float4(gxy.x, gxy.y, kf.a, kf.b);
@@ -1051,11 +1151,26 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         float *s = &v[SL * u];
         bool any = false;
         const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
+#ifdef FSGS_DIAG_HOOKS
+        uint32_t dbg_m16 = 0;
+#endif
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (!((bm >> k) & 1u)) continue;  // wave-uniform
           SplatEval e;  // alpha = G = 0 for lanes that do not contribute: the arithmetic below is a no-op for them
+#ifdef FSGS_DIAG_HOOKS
+          const bool dbg_c = splat_alpha_masked(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, pos < last[k], e);
+          any |= dbg_c;
+          if (dbg_lanes) {
+            const unsigned long long bal = __ballot(dbg_c);
+            const int cnt = __popcll(bal);
+            dl.lanes += (uint32_t)cnt;
+            if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
+            dbg_m16 |= diag_block_bits(bal) << (4 * k);
+          }
+#else
           any |= splat_alpha_masked(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, pos < last[k], e);
+#endif
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
           T[k] = T[k] * inv1ma;
           const float wgt = e.alpha * T[k];
@@ -1086,6 +1201,18 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
           }
         }
         any_group = any_group || (__ballot(any) != 0ull);
+#ifdef FSGS_DIAG_HOOKS
+        if (dbg_lanes) {
+          uint32_t qsel = 0;
+          for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
+          const uint32_t r16 = readlane(gmask16, j) & qsel;
+          const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
+          dl.pairs += 1; dl.bodies += nb;
+          dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
+          dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
+          dl.pairs_gain += pr < nb ? 1u : 0u;
+        }
+#endif
       }
       if (!any_group) continue;  // wave-uniform: none of the GP Gaussians touched any pixel of the tile
       // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
@@ -1100,10 +1227,6 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         const uint32_t gu = readlane(gid, max(jj - u, 0));
         gsel = my_u == u ? gu : gsel;
       }
-#ifdef FSGS_EXP_NO_ATOMICS  // experiment builds only (free-surgs_amd/build.py FSGS_CFLAGS): what do the accumulator atomics cost?
-      if (j_mine >= 0 && c_used && tot == 1.2345e33f) grad_acc[0] = tot;  // keeps the reduction alive, never stores
-      if (true) continue;
-#endif
       if (j_mine >= 0 && c_used && tot != 0.f) {
         if constexpr (ROW != 0) {
           // one row per Gaussian holds moments AND colour sums (dcolors = grad_acc + 8, stride ROW: launch_blend_bwd checks
@@ -1119,6 +1242,10 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     }
     hi = lo;
   }
+#ifdef FSGS_DIAG_HOOKS
+  __syncthreads();
+  diag_flush(dbg_lanes, dl, dbg_hist, lane);
+#endif
   if (dbg_times && lane == 0) {
     dbg_times[4 * blockIdx.x + 0] = dbg_t0;
     dbg_times[4 * blockIdx.x + 1] = wall_clock64();
@@ -1433,13 +1560,16 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_FWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_FWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_FWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_FWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
+  // lane-utilisation counters (scripts/lane_utilisation.py): 32 u64 on the device, summed over every launch
+  static unsigned long long *dbg_lanes =
+      diag_env("FSGS_DBG_LANES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_LANES_FWD"), nullptr, 0) : nullptr;
   if (done)  // the launch's own completion signals the event: no marker packet behind the kernel (fsgs_forward_done_event)
     hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam, ntiles,
                           dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
-                          dbg_times);
+                          dbg_times, dbg_lanes);
   else
     hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
-                       final_T, n_contrib, out_color, out_color2, out_depth, dbg_times);
+                       final_T, n_contrib, out_color, out_color2, out_depth, dbg_times, dbg_lanes);
   return 0;
 }
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
@@ -1454,8 +1584,10 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_BWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_BWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_BWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_BWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
+  static unsigned long long *dbg_lanes =  // lane-utilisation counters, see launch_blend_fwd
+      diag_env("FSGS_DBG_LANES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_LANES"), nullptr, 0) : nullptr;
   hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
-                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times);
+                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times, dbg_lanes);
   return 0;
 }
 
