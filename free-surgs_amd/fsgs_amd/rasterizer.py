@@ -71,6 +71,38 @@ def make_cfg(settings, channels):
     return cfg
 
 
+# ---- the configuration struct of a settings object, cached (the drop-in makes two rasteriser calls per
+# render() with the SAME settings tuple; rebuilding the 50-field ctypes struct for each was ~40 us of host time) ----------
+# Keyed like _host_cache: the settings object itself is kept in the entry (an id() alone can be recycled) together with
+# the version counters of its three tensors; the struct is handed out READ-ONLY (callers that set flags copy it).
+_cfg_cache = {}
+
+
+def cached_cfg(settings, channels):
+    key = (id(settings), int(channels))
+    vers = (settings.viewmatrix._version, settings.projmatrix._version, settings.bg._version)
+    hit = _cfg_cache.get(key)
+    if hit is None or hit[0] is not settings or hit[1] != vers:
+        if len(_cfg_cache) >= 256:
+            _cfg_cache.pop(next(iter(_cfg_cache)))
+        hit = _cfg_cache[key] = (settings, vers, make_cfg(settings, channels))
+    return hit[2]
+
+
+_sizes = {}  # (P, W, H, max_pairs) -> (state bytes, scratch bytes): pure functions of the shape, queried once
+
+
+def _raster_sizes(lib, P, W, H, cap):
+    hit = _sizes.get((P, W, H, cap))
+    if hit is None:
+        sb, xb = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(lib.fsgs_raster_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_raster_sizes")
+        if len(_sizes) >= 256:
+            _sizes.clear()
+        hit = _sizes[(P, W, H, cap)] = (sb.value, xb.value)
+    return hit
+
+
 last_num_rendered = 0  # R of the most recent forward (bench.py reports it)
 
 # ---- (tile, Gaussian) pair capacity: grow-only estimate per problem shape ----------------------
@@ -110,14 +142,13 @@ def raster_forward(cfg, means3D, colors, opacities, scales, rotations):
     with torch.cuda.device(dev):
         stream = _lib.current_stream()
         for _attempt in range(3):
-            sb, xb = C.c_size_t(0), C.c_size_t(0)
-            _lib.check(lib.fsgs_raster_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_raster_sizes")
-            state = torch.empty((sb.value,), dtype=torch.uint8, device=dev)
-            scratch = torch.empty((xb.value,), dtype=torch.uint8, device=dev)
+            sbytes, xbytes = _raster_sizes(lib, P, W, H, cap)
+            state = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+            scratch = torch.empty((xbytes,), dtype=torch.uint8, device=dev)
             rc = lib.fsgs_raster_forward(
                 C.byref(cfg), P, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opacities), _lib.ptr(scales),
                 _lib.ptr(rotations), _lib.ptr(out_color), _lib.ptr(out_depth), _lib.ptr(radii), _lib.ptr(state),
-                sb.value, _lib.ptr(scratch), xb.value, cap, C.byref(nr), stream,
+                sbytes, _lib.ptr(scratch), xbytes, cap, C.byref(nr), stream,
             )
             if rc == _lib.FSGS_ERR_CAPACITY and nr.value > cap:
                 cap = int(nr.value * 1.25) + 1024
@@ -130,7 +161,7 @@ def raster_forward(cfg, means3D, colors, opacities, scales, rotations):
     global last_num_rendered
     last_num_rendered = int(nr.value)
     st = RasterState()
-    st.buf, st.state_bytes, st.max_pairs, st.num_rendered, st.cfg, st.P = state, sb.value, cap, int(nr.value), cfg, P
+    st.buf, st.state_bytes, st.max_pairs, st.num_rendered, st.cfg, st.P = state, sbytes, cap, int(nr.value), cfg, P
     return out_color, out_depth, radii, st
 
 
@@ -209,7 +240,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         col = _f32c(colors_precomp)
         col = col.reshape(P, -1) if P > 0 else col.reshape(0, 3)
         op, sc, rot = _f32c(opacities).reshape(P), _f32c(scales), _f32c(rotations)
-        cfg = make_cfg(raster_settings, col.shape[1] if P > 0 else 3)
+        cfg = cached_cfg(raster_settings, col.shape[1] if P > 0 else 3)
         color, depth, radii, st = raster_forward(cfg, m3, col, op, sc, rot)
         ctx.st = st
         ctx.save_for_backward(m3, col, sc, rot, radii)

@@ -21,6 +21,20 @@ def _args_struct(xyz, f_dc, f_rest, opacity, scaling, rotation, w2c, cam_center,
     return a
 
 
+_sizes = {}  # (P, W, H, max_pairs) -> (state bytes, scratch bytes) of the fused render: queried once per shape
+
+
+def _render_sizes(lib, P, W, H, cap):
+    hit = _sizes.get((P, W, H, cap))
+    if hit is None:
+        sb, xb = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(lib.fsgs_render_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_render_sizes")
+        if len(_sizes) >= 256:
+            _sizes.clear()
+        hit = _sizes[(P, W, H, cap)] = (sb.value, xb.value)
+    return hit
+
+
 class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, f_dc, f_rest, opacity, scaling, rotation, w2c, means2D, cam_center, settings, active_deg,
@@ -31,7 +45,7 @@ class _FusedRender(torch.autograd.Function):
         dev = xyz.device
         t = [_f32c(v) for v in (xyz, f_dc, f_rest, opacity, scaling, rotation, w2c, cam_center)]
         P = int(t[0].shape[0])
-        cfg = rasterizer.make_cfg(settings, 6)
+        cfg = rasterizer.cached_cfg(settings, 6)  # read-only here; shared with every other call on this settings object
         H, W = cfg.image_height, cfg.image_width
         image = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth_sil = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -42,12 +56,11 @@ class _FusedRender(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = _lib.current_stream()
             for _attempt in range(3):
-                sb, xb = C.c_size_t(0), C.c_size_t(0)
-                _lib.check(lib.fsgs_render_sizes(P, W, H, cap, C.byref(sb), C.byref(xb)), "fsgs_render_sizes")
-                state = torch.empty((sb.value,), dtype=torch.uint8, device=dev)
-                scratch = torch.empty((xb.value,), dtype=torch.uint8, device=dev)
+                sbytes, xbytes = _render_sizes(lib, P, W, H, cap)
+                state = torch.empty((sbytes,), dtype=torch.uint8, device=dev)
+                scratch = torch.empty((xbytes,), dtype=torch.uint8, device=dev)
                 rc = lib.fsgs_render_forward(C.byref(cfg), P, C.byref(args), _lib.ptr(image), _lib.ptr(depth_sil),
-                                             _lib.ptr(radii), _lib.ptr(state), sb.value, _lib.ptr(scratch), xb.value,
+                                             _lib.ptr(radii), _lib.ptr(state), sbytes, _lib.ptr(scratch), xbytes,
                                              cap, C.byref(nr), stream)
                 if rc == _lib.FSGS_ERR_CAPACITY and nr.value > cap:
                     cap = int(nr.value * 1.25) + 1024
@@ -59,7 +72,7 @@ class _FusedRender(torch.autograd.Function):
                 raise _lib.FsgsError(_lib.FSGS_ERR_CAPACITY, "fsgs_render_forward")
         rasterizer.last_num_rendered = int(nr.value)
         ctx.save_for_backward(*t, radii)
-        ctx.misc = (cfg, state, sb.value, cap, int(nr.value), int(active_deg), int(max_deg), bool(gs_grad),
+        ctx.misc = (cfg, state, sbytes, cap, int(nr.value), int(active_deg), int(max_deg), bool(gs_grad),
                     bool(cam_grad), bool(param_grads))
         ctx.mark_non_differentiable(radii)
         return image, depth_sil, radii

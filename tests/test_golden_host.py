@@ -440,7 +440,7 @@ def test_eval_pose_aligns_every_run_on_its_own_and_global_run_starts_at_iteratio
     assert run.eval_pose()[2] > 1e-2
     # the iterations of the global phase
     seen = []
-    run.mapping = lambda ts, n, progressive: seen.append(ts)
+    run.mapping = lambda ts, n, progressive, want_pkg=True: seen.append(ts)
     pc.training_setup(fused=False)
     pc.initialize_optimizer = lambda fused=True: None
     deg0 = pc.active_sh_degree
