@@ -124,9 +124,53 @@ __global__ __launch_bounds__(256) void pose_adam_kernel(float *r, float *t, int 
   }
 }
 
+// The start of a tracked frame (train.py:322-331) in one launch: PoseModel.initialize_pose (scene/pose_optimizer.py:498-516;
+// constant-velocity extrapolation of frames id-1, id-2 for id > 1, a copy of frame id-1 otherwise) and the moments of the
+// FRESH Adam that initialize_tracking_optimizer builds for every frame (:489-496): zero.  In torch: ~20 small kernels for
+// the pose + a new optimizer + scheduler object per frame (2.3 ms of host time per frame at C2, round 4).
+__global__ __launch_bounds__(256) void pose_frame_begin_kernel(float *r, float *t, int N, int id, int extrapolate, float *m_r,
+                                                               float *v_r, float *m_t, float *v_t) {
+  if (m_r)
+    for (int e = threadIdx.x; e < 4 * N; e += blockDim.x) m_r[e] = v_r[e] = 0.f;
+  if (m_t)
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) m_t[e] = v_t[e] = 0.f;
+  if (threadIdx.x != 0 || id < 1) return;
+  if (extrapolate && id > 1) {
+    // F.normalize(x) = x / max(|x|_2, 1e-12), three times (both previous rotations, then their extrapolation)
+    float a[4], b[4], c[4];
+    float na = 0.f, nb = 0.f, nc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = r[k * N + id - 1]; b[k] = r[k * N + id - 2]; na += a[k] * a[k]; nb += b[k] * b[k]; }
+    na = fmaxf(sqrtf(na), 1e-12f); nb = fmaxf(sqrtf(nb), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] /= na; b[k] /= nb; c[k] = a[k] + (a[k] - b[k]); nc += c[k] * c[k]; }
+    nc = fmaxf(sqrtf(nc), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k * N + id] = c[k] / nc;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float t1 = t[k * N + id - 1]; t[k * N + id] = t1 + (t1 - t[k * N + id - 2]); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k * N + id] = r[k * N + id - 1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k * N + id] = t[k * N + id - 1];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int fsgs_pose_frame_begin(float *r, float *t, int num_cams, int cam_id, int extrapolate, float *exp_avg_r,
+                          float *exp_avg_sq_r, float *exp_avg_t, float *exp_avg_sq_t, fsgs_stream_t stream) {
+  if (!r || !t || num_cams <= 0 || cam_id < 0 || cam_id >= num_cams) return FSGS_ERR_INVALID;
+  if ((exp_avg_r == nullptr) != (exp_avg_sq_r == nullptr) || (exp_avg_t == nullptr) != (exp_avg_sq_t == nullptr))
+    return FSGS_ERR_INVALID;
+  hipLaunchKernelGGL(pose_frame_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, r, t, num_cams, cam_id,
+                     extrapolate, exp_avg_r, exp_avg_sq_r, exp_avg_t, exp_avg_sq_t);
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
 
 int fsgs_pose_adam_step(float *r, float *t, int num_cams, int cam_id, const float *dw2c_a, float weight_a,
                         const float *dw2c_b, float *exp_avg_r, float *exp_avg_sq_r, float *exp_avg_t,

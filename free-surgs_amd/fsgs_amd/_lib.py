@@ -177,6 +177,7 @@ _PROTOTYPES = {
     "fsgs_pose_backward": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fsgs_pose_adam_step": (_i, [_vp, _vp, _i, _i, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _i,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),
+    "fsgs_pose_frame_begin": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_adam_step": (_i, [_i, C.POINTER(FsgsAdamGroup), C.c_double, C.c_double, C.c_double, _vp]),
     "fsgs_densify_plan": (_i, [_i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp, _vp]),
     "fsgs_densify_apply": (_i, [_i, _vp, _vp, C.POINTER(C.c_int32), _i, C.POINTER(FsgsDensifyGroup), _vp, _vp, _vp,

@@ -110,9 +110,10 @@ class StagedLane:
             buf.copy_(self.host[i])
         self.cache[i] = (buf, done)
 
-    def prefetch(self, i, fence=None, protect=False):
-        """start copying frame i (no-op when it is resident, out of range or absent); protect=True keeps it resident until
-        its first lookup"""
+    def prefetch(self, i, fence=None, protect=True):
+        """start copying frame i (no-op when it is resident, out of range or absent).  A prefetched frame stays resident
+        until its first lookup (protect=False: it ages out like any other) -- least-recently-USED order alone would evict
+        exactly the frames that were fetched ahead and not read yet: they are older than everything touched since"""
         if i is None or i < 0 or i >= len(self.host) or self.host[i] is None:
             return
         if protect and len(self.protected) < self.capacity - 1:  # (at least one buffer stays evictable)
@@ -195,15 +196,19 @@ class StagedFrames(FrameData):
         self.pred_depths = RecentWindow(len(lanes[0]), keep=cap)
         self.device = dev
 
-    def prefetch(self, t, flows=True, protect=False):
+    def prefetch(self, t, flows=True, protect=True, colors=True, monodeps=True):
         """frame t's colours and mono-depth and, with `flows`, the flows its tracking reads (t-1 -> t for the flow loss,
-        t-2 -> t-1 for the rigid mask; trainer.Runner.tracking) -- a mapping view needs the first two only.
-        protect=True: what is fetched stays resident until it is first read (the next FRAME, asked for a frame cycle ahead)"""
+        t-2 -> t-1 for the rigid mask; trainer.Runner.tracking) -- a mapping view needs the first two only, a tracking
+        frame no mono-depth.  What is fetched stays resident until it is first read (the next FRAME is asked for a whole
+        frame cycle ahead, the next keyframe one iteration ahead), so only ask for what WILL be read: a lane whose
+        prefetched frame is never looked up keeps one buffer less for everything else."""
         if t is None:
             return
         fence = Fence()
-        self.colors.prefetch(t, fence, protect)
-        self.monodeps.prefetch(t, fence, protect)
+        if colors:
+            self.colors.prefetch(t, fence, protect)
+        if monodeps:
+            self.monodeps.prefetch(t, fence, protect)
         if flows and self.flows_fw is not None:
             self.flows_fw.prefetch(t - 1, fence, protect)
             self.flows_fw.prefetch(t - 2, fence, protect)

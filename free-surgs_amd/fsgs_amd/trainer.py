@@ -101,6 +101,78 @@ class PoseTrack:
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(
             self.optimizer, milestones=list(range(0, int(tracking_iter), step)), gamma=0.5)
 
+    @staticmethod
+    def _lr_table(tracking_iter):
+        """the learning rates the reference's Adam(lr .01) + MultiStepLR(milestones 0, s, 2s, ..; gamma .5) pair shows after
+        its construction and after each scheduler.step() -- recorded ONCE from the torch objects themselves
+        (scene/pose_optimizer.py:489-496), so a frame does not have to build them again to get the same floats"""
+        import warnings
+
+        dummy = [torch.zeros(1, requires_grad=True), torch.zeros(1, requires_grad=True)]
+        opt = torch.optim.Adam([{"params": dummy[0], "lr": 0.01}, {"params": dummy[1], "lr": 0.01}], lr=0.001, eps=1e-15)
+        step = int(tracking_iter / 3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(range(0, int(tracking_iter), step)), gamma=0.5)
+            table = [tuple(float(g["lr"]) for g in opt.param_groups)]
+            for _ in range(int(tracking_iter) + 1):
+                sch.step()
+                table.append(tuple(float(g["lr"]) for g in opt.param_groups))
+        return table
+
+    class _TableScheduler:
+        """scheduler.step() of the per-frame MultiStepLR, replayed from PoseTrack._lr_table"""
+
+        def __init__(self, optimizer, table):
+            self.optimizer, self.table, self.pos = optimizer, table, 0
+            self._apply()
+
+        def _apply(self):
+            row = self.table[min(self.pos, len(self.table) - 1)]
+            for g, lr in zip(self.optimizer.param_groups, row):
+                g["lr"] = lr
+
+        def step(self):
+            self.pos += 1
+            self._apply()
+
+        def rewind(self):
+            self.pos = 0
+            self._apply()
+
+    def begin_frame(self, i, tracking_iter=50):
+        """Start of a tracked frame (train.py:322-331): initialize_pose(i) -- constant velocity for i > 1, a copy of frame
+        i-1 for i = 1 -- and initialize_tracking_optimizer(tracking_iter), i.e. an Adam with zero moments and the
+        schedule back at its start.  On the device: ONE launch (fsgs_pose_frame_begin) on an optimizer / schedule that are
+        built once and reset, instead of ~20 small torch kernels and two new Python objects per frame."""
+        i = int(i)
+        if not self.r.is_cuda:  # CPU (gloo tests): the torch statements
+            self.initialize_pose(i)
+            self.initialize_tracking_optimizer(tracking_iter)
+            return
+        from . import _lib
+        from .optim import FusedAdam, mark_updated
+
+        hit = self.__dict__.get("_frame_opt")
+        if hit is None or hit[0] != int(tracking_iter) or hit[1] is not self.r or hit[2] is not self.t:
+            opt = FusedAdam([{"params": self.r, "lr": 0.01}, {"params": self.t, "lr": 0.01}], lr=0.001, eps=1e-15)
+            for p in (self.r, self.t):
+                opt.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p, memory_format=torch.preserve_format),
+                                "exp_avg_sq": torch.zeros_like(p, memory_format=torch.preserve_format)}
+            hit = self._frame_opt = (int(tracking_iter), self.r, self.t, opt,
+                                     PoseTrack._TableScheduler(opt, self._lr_table(tracking_iter)))
+        opt, sch = hit[3], hit[4]
+        self.optimizer, self.scheduler = opt, sch
+        sch.rewind()
+        sr, st_ = opt.state[self.r], opt.state[self.t]
+        sr["step"] = st_["step"] = 0
+        with torch.cuda.device(self.r.device):
+            _lib.check(_lib.load().fsgs_pose_frame_begin(
+                _lib.ptr(self.r), _lib.ptr(self.t), int(self.r.shape[-1]), i, 1, _lib.ptr(sr["exp_avg"]),
+                _lib.ptr(sr["exp_avg_sq"]), _lib.ptr(st_["exp_avg"]), _lib.ptr(st_["exp_avg_sq"]), _lib.current_stream()),
+                "fsgs_pose_frame_begin")
+        mark_updated([self.r, self.t])
+
     def fused_step(self, i, dw2c_a, weight_a, dw2c_b):
         """scheduler-independent tail of a tracking iteration in one launch (csrc/pose.hip pose_adam_kernel):
         dW = weight_a * dw2c_a + dw2c_b -> LearnPose adjoint -> Adam on r, t -> the new w2c of frame i (cached for the
@@ -441,19 +513,26 @@ class Runner:
             self.poses.get_pose(0)
         train = self._train_set()
         for t in range(n):
-            # staged sequences (fsgs_amd/staging.py): the next frame's inputs travel while this one is optimised, and stay
-            # resident until frame t + 1 reads them whatever keyframes the mapping iterations in between pull through the lanes
-            self._prefetch(t + 1, protect=True)
+            # staged sequences (fsgs_amd/staging.py): what the NEXT frame's tracking reads (colours, flows) travels while this
+            # frame is optimised and stays resident until it is read, whatever keyframes the mapping iterations in between pull
+            # through the lanes; the mono-depth is read by a frame's MAPPING only: asked for at the start of the frame's own
+            # cycle (its 50 tracking iterations ahead), and only for a training frame
+            self._prefetch(t + 1, monodeps=False)
+            if t in train:
+                self._prefetch(t, flows=False, colors=False)
             self.pc.update_learning_rate(self.iteration)
             if t > 0:
                 with self._phase("frame.setup", t):
-                    if t > 1:
-                        self.poses.initialize_pose(t)
+                    if self.fast is not None and hasattr(self.poses, "begin_frame"):
+                        self.poses.begin_frame(t, self.tracking_iter)  # pose initialisation + fresh Adam / schedule: one launch
                     else:
-                        with torch.no_grad():
-                            self.poses.r[..., t] = self.poses.r[..., t - 1]
-                            self.poses.t[..., t] = self.poses.t[..., t - 1]
-                    self.poses.initialize_tracking_optimizer(self.tracking_iter)
+                        if t > 1:
+                            self.poses.initialize_pose(t)
+                        else:
+                            with torch.no_grad():
+                                self.poses.r[..., t] = self.poses.r[..., t - 1]
+                                self.poses.t[..., t] = self.poses.t[..., t - 1]
+                        self.poses.initialize_tracking_optimizer(self.tracking_iter)
                 with self._phase("frame.tracking", t):
                     loss, rgb, flow, _ = self.tracking(t)
                 # the three logged values in ONE device-to-host copy (three float() calls are three synchronisations)
@@ -475,13 +554,10 @@ class Runner:
                         pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
                     self.frames.pred_depths[t] = self._stored_depth(pkg)
 
-    def _prefetch(self, t, flows=True, protect=False):
+    def _prefetch(self, t, flows=True, **lanes):
         pf = getattr(self.frames, "prefetch", None)
         if pf is not None and t is not None and 0 <= t < len(self.frames.colors):
-            if protect:
-                pf(int(t), flows=flows, protect=True)
-            else:
-                pf(int(t), flows=flows)
+            pf(int(t), flows=flows, **lanes)
 
     def _frames_device(self):
         return getattr(self.frames, "device", None) or self.frames.colors[0].device

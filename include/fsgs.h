@@ -442,6 +442,15 @@ int fsgs_pose_adam_step(float *r, float *t, int num_cams, int cam_id, const floa
                         float *exp_avg_sq_t, float lr_r, float lr_t, int step_r, int step_t, double beta1, double beta2,
                         double eps, float *w2c_next, fsgs_stream_t stream);
 
+/* The start of a tracked frame in ONE launch (train.py:322-331): PoseModel.initialize_pose for frame cam_id
+ * (scene/pose_optimizer.py:498-516: with `extrapolate` and cam_id > 1 the constant-velocity rule
+ * r_i = normalize(normalize(r_{i-1}) + (normalize(r_{i-1}) - normalize(r_{i-2}))), t_i = 2 t_{i-1} - t_{i-2}; otherwise a
+ * copy of frame cam_id - 1; cam_id = 0 leaves the poses alone) and the state of the fresh Adam the reference builds per
+ * frame (initialize_tracking_optimizer, :489-496): the four moment tensors are zeroed when given (NULL pairs are left
+ * alone; the caller restarts its step counters).  All pointers DEVICE; r [1,4,N], t [3,N] as in fsgs_pose_forward. */
+int fsgs_pose_frame_begin(float *r, float *t, int num_cams, int cam_id, int extrapolate, float *exp_avg_r,
+                          float *exp_avg_sq_r, float *exp_avg_t, float *exp_avg_sq_t, fsgs_stream_t stream);
+
 /* ---- optimiser step and densification statistics -------------------------------------------------- */
 
 /* One parameter group of torch.optim.Adam (no weight decay, no amsgrad): all DEVICE pointers of n

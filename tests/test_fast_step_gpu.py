@@ -662,6 +662,50 @@ def test_an_aborted_backward_does_not_poison_the_following_steps():
         assert bad < 1e-2, (n, bad)
 
 
+def test_begin_frame_is_initialize_pose_plus_a_fresh_optimizer():
+    """PoseTrack.begin_frame (one launch: fsgs_pose_frame_begin, on an optimizer / schedule built once and reset) against
+    what train.py:322-331 does per frame -- initialize_pose + a NEW Adam + MultiStepLR: same initial pose, same first
+    iterations, also when the reused optimizer comes back dirty from the previous frame."""
+    from fsgs_amd.flow import FlowTargets
+
+    pc, poses, frames, cam = _world(n=4)
+    H, W = 256, 320
+    twin = PoseTrack(4, DEV)
+    with torch.no_grad():
+        twin.r.copy_(poses.r)
+        twin.t.copy_(poses.t)
+    tg = FlowTargets(frames.monodeps[2].reshape(1, H, W), np.eye(4, dtype=np.float32), cam["K"], frames.flows_fw[2], None)
+
+    def track(pt, n=6):
+        fs = FastStepper(pc, pt, frames)
+        for _ in range(n):
+            fs.tracking_step(3, tg, None, want_losses=False)
+        torch.cuda.synchronize()
+        return pt.r.detach()[0, :, 3].clone(), pt.t.detach()[:, 3].clone()
+
+    # the reference's sequence
+    twin.initialize_pose(3)
+    twin.initialize_tracking_optimizer(50)
+    # the one-launch form
+    poses.begin_frame(3, 50)
+    assert torch.allclose(poses.r, twin.r, atol=1e-7, rtol=0) and torch.allclose(poses.t, twin.t, atol=1e-7, rtol=0)
+    assert not torch.equal(poses.r[0, :, 3], poses.r[0, :, 2])  # (extrapolated, not copied)
+    ra, ta = track(twin)
+    rb, tb = track(poses)
+    # six Adam steps of lr 5e-3 move the pose by ~1e-2; the two runs differ by the order of the blend's float atomics
+    assert (ra - rb).abs().max().item() < 2e-5 and (ta - tb).abs().max().item() < 2e-5, ((ra - rb).abs().max(), (ta - tb).abs().max())
+    assert [g["lr"] for g in poses.optimizer.param_groups] == [g["lr"] for g in twin.optimizer.param_groups]
+    assert poses.optimizer.state[poses.r]["step"] == 6
+    # the same frame again on the now dirty optimizer: moments, step counters and schedule start over
+    poses.begin_frame(3, 50)
+    assert poses.optimizer.state[poses.r]["step"] == 0 and float(poses.optimizer.state[poses.t]["exp_avg"].abs().sum()) == 0.0
+    rc, tc = track(poses)
+    assert (rc - rb).abs().max().item() < 2e-5 and (tc - tb).abs().max().item() < 2e-5
+    # frame 1 copies frame 0 (scene/pose_optimizer.py:513-516)
+    poses.begin_frame(1, 50)
+    assert torch.equal(poses.r[0, :, 1], poses.r[0, :, 0]) and torch.equal(poses.t[:, 1], poses.t[:, 0])
+
+
 def test_forward_done_event_orders_another_stream_behind_the_forward_blend():
     """fsgs_forward_done_event: the next fused forward signals the event with its blend launch (no marker packet behind
     it); a second stream that waits for it must see the finished image -- also when the forward is repeated on the same

@@ -49,11 +49,16 @@ def test_a_protected_prefetch_survives_the_keyframes_pulled_through_the_lane_unt
     random keyframes of those iterations must not push it out of a 4-buffer lane"""
     lane = StagedLane(_items(12), "cpu", capacity=4)
     lane[5]                                 # the current frame
-    lane.prefetch(6, protect=True)          # the next frame, a whole cycle ahead
-    for k in (0, 1, 2, 3, 0, 2, 1, 3, 0, 1):  # keyframes of the mapping iterations, each prefetched one iteration ahead
-        lane.prefetch(k)
-        lane[5]
+    lane.prefetch(6)                        # the next frame, a whole cycle ahead
+    keys = (0, 1, 2, 3, 0, 2, 1, 3, 0, 1)   # keyframes of the mapping iterations, each prefetched one iteration ahead:
+    lane.prefetch(keys[0])                  # Runner.mapping asks for iteration i+1's BEFORE iteration i reads its own
+    misses = lane.misses
+    for i, k in enumerate(keys):
+        if i + 1 < len(keys):
+            lane.prefetch(keys[i + 1])
         lane[k]
+        lane[5]
+    assert lane.misses == misses            # not one keyframe was evicted between its prefetch and its read
     assert 6 in lane.cache and 6 in lane.protected
     misses = lane.misses
     assert float(lane[6].mean()) == 6.0 and lane.misses == misses  # a hit, and the protection ends with the first read
@@ -63,11 +68,51 @@ def test_a_protected_prefetch_survives_the_keyframes_pulled_through_the_lane_unt
     assert 6 not in lane.cache              # ... after which it ages out like any other frame
     # never more than capacity - 1 protected frames: one buffer always stays evictable
     small = StagedLane(_items(6), "cpu", capacity=2)
-    small.prefetch(0, protect=True)
-    small.prefetch(1, protect=True)
+    small.prefetch(0)
+    small.prefetch(1)
     assert small.protected == {0}
-    small.prefetch(2)
+    small.prefetch(2, protect=False)
     assert set(small.cache) == {0, 2} and float(small[0].mean()) == 0.0
+
+
+def test_the_lookups_of_a_progressive_run_all_find_their_frame_resident_in_four_buffers():
+    """the order in which Runner.progressive_run / mapping ask for and read frames (trainer.py), replayed on CPU lanes with
+    FOUR buffers each over 17 frames with a random keyframe per two-view iteration: apart from frame 0's colours nothing
+    is ever missed, and no protection is left behind (a frame's mono-depth is only fetched for its own mapping)"""
+    n, H, W = 17, 4, 6
+    rng = np.random.default_rng(0)
+    fr = StagedFrames([rng.random((3, H, W), dtype=np.float32) for _ in range(n)],
+                      [rng.random((H, W), dtype=np.float32) for _ in range(n)],
+                      flows_fw=[rng.random((2, H, W), dtype=np.float32) for _ in range(n - 1)],
+                      K=np.eye(3, dtype=np.float32), device="cpu", capacity=4)
+    r, keys, train = random.Random(0), [], set(int(i) for i in fr.i_train)
+    for t in range(n):
+        if t + 1 < n:
+            fr.prefetch(t + 1, monodeps=False)       # progressive_run, top of the frame cycle
+        if t in train:
+            fr.prefetch(t, flows=False, colors=False)
+        if t > 0:                                    # tracking(t)
+            if t > 1:
+                fr.flows_fw[t - 2]
+            fr.flows_fw[t - 1]
+            for _ in range(6):
+                fr.colors[t]
+        if t in train:                               # mapping(t)
+            iters, views = (10, 1) if t == 0 else (12, 2)
+            nxt = r.choice(keys) if views == 2 else None
+            fr.prefetch(nxt, flows=False)
+            for k in range(iters):
+                ts = [nxt, t] if views == 2 else [t]
+                if views == 2:
+                    nxt = r.choice(keys) if k + 1 < iters else None
+                    fr.prefetch(nxt, flows=False)
+                for v in ts:
+                    fr.colors[v]
+                    fr.monodeps[v]
+            keys.append(t)
+    st = fr.stats()
+    assert st["colors"]["misses"] == 1 and st["monodeps"]["misses"] == 0 and st["flows_fw"]["misses"] == 0, st
+    assert not (fr.colors.protected or fr.monodeps.protected or fr.flows_fw.protected)
 
 
 def test_absent_entries_and_mismatched_shapes():
