@@ -282,6 +282,55 @@ def comm_model(nbytes, world, step_ms_one_gpu=0.651):
 
 
 
+def drop_in_breakdown(pc, poses, frames, reps=5):
+    """Where a step of the unchanged-checkout route spends its wall time: the phases of trainer.mapping_step(fused=False,
+    hip_losses=False), each bracketed by a device synchronisation, and the HOST time inside this library's own operator
+    calls (GaussianRasterizer forward x2 / backward x2) -- everything else is the reference's own torch code."""
+    from fsgs_amd import optim, rasterizer
+    from fsgs_amd.render import render_two_pass
+    from fsgs_amd.trainer import mapping_loss
+
+    acc = {"render_fwd_two_pass": 0.0, "torch_losses_fwd": 0.0, "backward": 0.0, "stats_and_torch_adam": 0.0,
+           "of_which_host_inside_rasteriser_fwd_calls": 0.0, "of_which_host_inside_rasteriser_bwd_calls": 0.0}
+    orig_f, orig_b = rasterizer.raster_forward, rasterizer.raster_backward
+
+    def wrap(fn, key):
+        def w(*a, **k):
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            acc[key] += (time.perf_counter() - t) * 1e3
+            return r
+        return w
+
+    rasterizer.raster_forward = wrap(orig_f, "of_which_host_inside_rasteriser_fwd_calls")
+    rasterizer.raster_backward = wrap(orig_b, "of_which_host_inside_rasteriser_bwd_calls")
+    try:
+        n = len(frames.colors)
+        for it in range(reps):
+            ts = it % n
+            marks = []
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            pkg = render_two_pass(poses, ts, pc, gs_grad=True, cam_grad=False)
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            loss = mapping_loss(pkg, frames.colors[ts], frames.monodeps[ts], hip_losses=False)
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            loss.backward()
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            with torch.no_grad():
+                optim.densify_stats(pkg["radii"], pkg["viewspace_points"].grad, pc.variables["max_radii2D"],
+                                    pc.variables["xyz_gradient_accum"], pc.variables["denom"])
+                pc.optimizer.step()
+                pc.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize(); marks.append(time.perf_counter())
+            for k, (a, b) in zip(("render_fwd_two_pass", "torch_losses_fwd", "backward", "stats_and_torch_adam"),
+                                 zip(marks, marks[1:])):
+                acc[k] += (b - a) * 1e3
+    finally:
+        rasterizer.raster_forward, rasterizer.raster_backward = orig_f, orig_b
+    return {k: v / reps for k, v in acc.items()}
+
+
+
 def drop_in_extra(cfg_name, device, steps=30, warmup=5):
     """The route an UNCHANGED reference checkout takes (one PYTHONPATH entry, nothing else) and the route
     with INTEGRATION.md s3's three one-line edits, both under torch.autograd at this configuration:
@@ -307,6 +356,8 @@ def drop_in_extra(cfg_name, device, steps=30, warmup=5):
         dt = time.perf_counter() - t0
         out[name] = {"ms_per_step": dt / steps * 1e3, "iters_per_sec": steps / dt, "host_issue_ms_per_step": t_issue / steps * 1e3,
                      "steps": steps}
+        if name == "unchanged":
+            out[name]["breakdown_ms"] = drop_in_breakdown(pc, poses, frames)
         del pc, poses, frames
         torch.cuda.empty_cache()
     out["what"] = ("trainer.mapping_step under torch.autograd at %s: `unchanged` = two drop-in GaussianRasterizer calls + torch glue "

@@ -259,3 +259,66 @@ def load_inputs(fx, device):
 
 # what the pinned run does (shared by the fixture script and the GPU test)
 PIN = dict(tracking_iter=5, mapping_iter=5, first_mapping_iter=5, densify_interval=8, rng_seed=11, seed=0)
+
+
+# ---- BASELINE.json configs[0] as stated: 8 frames, 640x512, 20 k initial Gaussians, the reference's own schedule ----------
+C1 = dict(W=640, H=512, n_frames=8, P=20_000, tracking_iter=50, mapping_iter=30, first_mapping_iter=200,
+          densify_interval=300, rng_seed=11, seed=0, P_scene=60_000, input_seed=3)
+
+
+def make_c1_inputs(oracle):
+    """the C1 sequence, regenerated from its seed wherever the oracle runs (~10 s): a fixture of 8 frames at 640x512 would be
+    7.8 MB compressed; tests/golden/harness_c1.npz stores coarse fingerprints of it instead (c1_input_stats)"""
+    ratio = C1["P"] / float(C1["W"] * C1["H"])
+    return make_inputs(oracle, W=C1["W"], H=C1["H"], n_frames=C1["n_frames"], P_scene=C1["P_scene"], ratio=ratio,
+                       seed=C1["input_seed"])
+
+
+def c1_input_stats(fx):
+    """coarse fingerprints of the regenerated sequence: per-frame means of colours / mono-depth / flow, the first points"""
+    return np.concatenate([fx["colors_u8"].astype(np.float64).mean(axis=(1, 2, 3)) / 255.0,
+                           fx["monodeps_f16"].astype(np.float64).mean(axis=(1, 2)),
+                           np.abs(fx["flows_fw_f16"].astype(np.float64)).mean(axis=(1, 2, 3)),
+                           fx["_xyz"][:16].astype(np.float64).reshape(-1), fx["_scaling"][:16, 0].astype(np.float64)])
+
+
+def c1_outcome(trace, pc, poses, frames, render_fn):
+    """What a C1 run is judged by, from a harness's trace (CpuHarness and fsgs_amd.trainer.Runner share the format) and its
+    final state: per tracked frame the first / last iteration's losses, per mapped frame the mean and last mapping loss,
+    the densification record, the tracked poses, RPE / ATE against the ground truth (train.py:492-506), PSNR of the test
+    frame(s) at their tracked pose (train.py:401-432).  render_fn(t) -> the rendered [3,H,W] image of frame t."""
+    from fsgs_amd import metrics
+
+    n = len(frames.colors)
+    maps = [e for e in trace if e[0] == "map"]
+    tracks = [e for e in trace if e[0] == "track"]
+    out = {}
+    out["track_last"] = np.array([[e[3], e[4], e[5]] for e in tracks if e[2] == C1["tracking_iter"] - 1], np.float64)
+    out["track_first"] = np.array([[e[3], e[4], e[5]] for e in tracks if e[2] == 0], np.float64)
+    bounds, it = [], 0
+    train = set(int(i) for i in frames.i_train)
+    for t in range(n):
+        if t in train:
+            k = C1["first_mapping_iter"] if t == 0 else C1["mapping_iter"]
+            bounds.append((t, it, it + k))
+            it += k
+    ml = np.array([e[3] for e in maps], np.float64)
+    out["map_mean"] = np.array([[t, ml[a:b].mean(), ml[b - 1]] for t, a, b in bounds], np.float64)
+    out["densify"] = np.array([[e[1], e[2]] for e in trace if e[0] == "densify"], np.int64)
+    out["final_P"] = pc.num_points
+    out["pose_r"] = poses.r.detach().cpu().numpy()
+    out["pose_t"] = poses.t.detach().cpu().numpy()
+    from fsgs_amd.pose import pose_to_w2c
+
+    with torch.no_grad():  # (the torch statement on host copies: the same arithmetic for both harnesses)
+        r_, t_ = poses.r.detach().cpu(), poses.t.detach().cpu()
+        pred = np.stack([pose_to_w2c(r_, t_, i).numpy() for i in range(n)])
+    gt = np.stack([np.asarray(g, np.float32) for g in frames.gt_w2c])
+    out["pose_metrics"] = np.array(metrics.pose_metrics(pred, gt)[1], np.float64)  # rpe_t, rpe_r (deg), ate
+    ps = []
+    with torch.no_grad():
+        for i in frames.i_test:
+            img = render_fn(int(i))
+            ps.append(metrics.psnr(frames.colors[int(i)].detach().cpu().numpy()[None], img.detach().cpu().numpy()[None]))
+    out["psnr_test"] = np.array(ps, np.float64)
+    return out

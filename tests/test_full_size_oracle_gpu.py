@@ -55,7 +55,7 @@ def _scene(cfg):
 def _report(name, rec):
     line = json.dumps(dict(test=name, **rec))
     print(line)
-    dump_attribution_log("r03_full_size_parity", json.loads(line))
+    dump_attribution_log("r04_full_size_parity", json.loads(line))
 
 
 def _assert_mostly_plain(stats, what):
@@ -68,8 +68,11 @@ def _assert_mostly_plain(stats, what):
 
 
 def _summary(stats):
+    # max_err / p9999: the achieved error over ALL elements (witnessed outliers included) and its 99.99th percentile,
+    # max_err_plain: over the elements whose allowance does not reach the tolerance -- all relative to `scale`
     return {k: dict(outliers=v.outliers, fragile=v.fragile, size=v.size, pos=v.pos, neg=v.neg,
-                    witnessed_fraction=v.outliers / max(v.size, 1)) for k, v in stats.items()}
+                    witnessed_fraction=v.outliers / max(v.size, 1), max_err=v.max_err, p9999=v.p9999,
+                    max_err_plain=v.max_err_plain, scale=v.scale) for k, v in stats.items()}
 
 
 @pytest.mark.parametrize("cfg,pose", [("C2", "identity"), ("C2", "perturbed"), ("C4", "perturbed")])

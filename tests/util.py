@@ -43,11 +43,17 @@ def c1_poses():
     return poses
 
 
-Attribution = collections.namedtuple("Attribution", "outliers fragile size pos neg")
+# outliers .. neg: see assert_close_attributed; max_err / p9999 / max_err_plain: the ACHIEVED error of the tensor relative to
+# the scale the tolerance is taken of (max |want| + floor) -- over all elements, its 99.99th percentile, and over the elements
+# that carry no allowance reaching the tolerance (what the plain 1e-4 criterion alone is up against); scale itself last
+Attribution = collections.namedtuple("Attribution", "outliers fragile size pos neg max_err p9999 max_err_plain scale",
+                                     defaults=(0.0, 0.0, 0.0, 0.0))
 # every call of assert_close_attributed leaves a record here (what, the counts above, the caller's tag); the sweep-level
 # statistics tests read it (fraction of witnessed outliers, sign balance of got - want over them), and
 # dump_attribution_log() writes it out next to the profiles
 ATTRIBUTION_LOG = []
+# ... and one with the achieved error of EVERY comparison, passed or not (max / 99.99th percentile / scale)
+ACHIEVED_LOG = []
 # Bounds on the WITNESSED outliers of one tensor.  Same inputs on both sides (the operator-boundary rasteriser against the
 # oracle): 1e-4 of the elements -- measured 8e-7 (image) ... 1.2e-5 (gradients) at C2 / C4, 5e-5 at C1.  One flipped
 # (pixel, Gaussian) pair moves every gradient component of that Gaussian and of the ones behind it at that pixel, so
@@ -85,6 +91,13 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
     diff = got - want
     err = np.abs(diff)
     assert np.isfinite(err).all(), "%s: non-finite values" % what
+    # the achieved error, published whatever the verdict below (how much slack does the tolerance leave?)
+    flat = err.reshape(-1)
+    k = max(0, min(flat.size - 1, int(np.ceil(0.9999 * flat.size)) - 1))
+    achieved = dict(max_err=float(flat.max() / scale), p9999=float(np.partition(flat, k)[k] / scale),
+                    max_err_plain=float((err[factor * amp < tol * scale].max() if (factor * amp < tol * scale).any() else 0.0) / scale),
+                    scale=scale)
+    ACHIEVED_LOG.append(dict(what=str(what), tag=None if tag is None else str(tag), tol=tol, size=int(got.size), **achieved))
     rogue = err > tol * scale + factor * amp
     if rogue.any():
         idx = np.argwhere(rogue)
@@ -102,7 +115,7 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
     # fragile = elements whose allowance is as large as the plain tolerance itself, i.e. where the witness can decide anything
     # (the round-off term makes the allowance non-zero almost everywhere; what matters is where it is not negligible)
     res = Attribution(int(out.sum()), int((factor * amp >= tol * scale).sum()), int(got.size), int((diff[out] > 0).sum()),
-                      int((diff[out] < 0).sum()))
+                      int((diff[out] < 0).sum()), **achieved)
     ATTRIBUTION_LOG.append(dict(what=str(what), tag=None if tag is None else str(tag), **res._asdict()))
     frac = MAX_OUTLIER_FRACTION if max_fraction is None else max_fraction
     assert res.outliers <= max(MIN_OUTLIER_COUNT, frac * res.size), \
