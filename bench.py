@@ -337,11 +337,15 @@ def drop_in_extra(cfg_name, device, steps=30, warmup=5):
       unchanged   : render() = the reference's own sequence of ~40 small torch ops around TWO GaussianRasterizer calls
                     (fsgs_amd.render.render_two_pass restates it, gaussian_renderer/__init__.py:49-92), the losses as plain
                     torch (utils/loss_utils.py:41-127), torch.optim.Adam on six groups -- only the rasteriser is this library;
+      losses_edit_only : as above with INTEGRATION.md s3's second edit alone (the three loss imports): what the reference's
+                    own torch losses -- 40 patch crops with a host synchronisation each, ~1500 small launches forward and
+                    backward -- cost in the unchanged route;
       three_edits : the fused render op + the HIP loss kernels + FusedAdam, still driven by loss.backward()."""
     from fsgs_amd.trainer import mapping_step
 
     out = {}
-    for name, fused, hip_losses, fused_adam in (("unchanged", False, False, False), ("three_edits", True, True, True)):
+    for name, fused, hip_losses, fused_adam in (("unchanged", False, False, False), ("losses_edit_only", False, True, False),
+                                                ("three_edits", True, True, True)):
         pc, poses, frames, cam, sc = build_problem(cfg_name, device, 0, 1)
         pc.training_setup(eps=1e-8, fused=fused_adam)
         n = len(frames.colors)
@@ -361,8 +365,8 @@ def drop_in_extra(cfg_name, device, steps=30, warmup=5):
         del pc, poses, frames
         torch.cuda.empty_cache()
     out["what"] = ("trainer.mapping_step under torch.autograd at %s: `unchanged` = two drop-in GaussianRasterizer calls + torch glue "
-                   "+ torch losses + torch.optim.Adam (INTEGRATION s2); `three_edits` = fused render + HIP losses + FusedAdam "
-                   "(INTEGRATION s3)" % cfg_name)
+                   "+ torch losses + torch.optim.Adam (INTEGRATION s2); `losses_edit_only` = the same with the HIP loss kernels; "
+                   "`three_edits` = fused render + HIP losses + FusedAdam (INTEGRATION s3)" % cfg_name)
     return out
 
 

@@ -72,7 +72,8 @@ def _summary(stats):
     # max_err_plain: over the elements whose allowance does not reach the tolerance -- all relative to `scale`
     return {k: dict(outliers=v.outliers, fragile=v.fragile, size=v.size, pos=v.pos, neg=v.neg,
                     witnessed_fraction=v.outliers / max(v.size, 1), max_err=v.max_err, p9999=v.p9999,
-                    max_err_plain=v.max_err_plain, scale=v.scale) for k, v in stats.items()}
+                    max_err_plain=v.max_err_plain, scale=v.scale, max_err_zero_amp=v.max_err_zero_amp,
+                    zero_amp_fraction=v.zero_amp_fraction) for k, v in stats.items()}
 
 
 @pytest.mark.parametrize("cfg,pose", [("C2", "identity"), ("C2", "perturbed"), ("C4", "perturbed")])

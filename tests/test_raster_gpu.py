@@ -106,7 +106,8 @@ def test_c1_init_scene_eight_poses(oracle32):
         dump_attribution_log("r04_full_size_parity", dict(
             test="raster_op", cfg="C1", pose=i, P=P, num_rendered_upstream=R,
             tensors={k: dict(outliers=v.outliers, size=v.size, max_err=v.max_err, p9999=v.p9999,
-                             max_err_plain=v.max_err_plain, scale=v.scale) for k, v in stats.items()}))
+                             max_err_plain=v.max_err_plain, scale=v.scale, max_err_zero_amp=v.max_err_zero_amp,
+                             zero_amp_fraction=v.zero_amp_fraction) for k, v in stats.items()}))
 
 
 def test_trained_like_scene_with_view_matrix(oracle32):

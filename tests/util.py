@@ -46,8 +46,11 @@ def c1_poses():
 # outliers .. neg: see assert_close_attributed; max_err / p9999 / max_err_plain: the ACHIEVED error of the tensor relative to
 # the scale the tolerance is taken of (max |want| + floor) -- over all elements, its 99.99th percentile, and over the elements
 # that carry no allowance reaching the tolerance (what the plain 1e-4 criterion alone is up against); scale itself last
-Attribution = collections.namedtuple("Attribution", "outliers fragile size pos neg max_err p9999 max_err_plain scale",
-                                     defaults=(0.0, 0.0, 0.0, 0.0))
+# max_err_zero_amp: over the elements NO near-tie reaches at all (allowance exactly zero; None when there are none) and
+# zero_amp_fraction, their share of the tensor
+Attribution = collections.namedtuple(
+    "Attribution", "outliers fragile size pos neg max_err p9999 max_err_plain scale max_err_zero_amp zero_amp_fraction",
+    defaults=(0.0, 0.0, 0.0, 0.0, None, 0.0))
 # every call of assert_close_attributed leaves a record here (what, the counts above, the caller's tag); the sweep-level
 # statistics tests read it (fraction of witnessed outliers, sign balance of got - want over them), and
 # dump_attribution_log() writes it out next to the profiles
@@ -96,7 +99,8 @@ def assert_close_attributed(got, want, amp, what, tol=1e-4, floor=0.0, factor=2.
     k = max(0, min(flat.size - 1, int(np.ceil(0.9999 * flat.size)) - 1))
     achieved = dict(max_err=float(flat.max() / scale), p9999=float(np.partition(flat, k)[k] / scale),
                     max_err_plain=float((err[factor * amp < tol * scale].max() if (factor * amp < tol * scale).any() else 0.0) / scale),
-                    scale=scale)
+                    scale=scale, max_err_zero_amp=(float(err[amp == 0].max() / scale) if (amp == 0).any() else None),
+                    zero_amp_fraction=float((amp == 0).mean()))
     ACHIEVED_LOG.append(dict(what=str(what), tag=None if tag is None else str(tag), tol=tol, size=int(got.size), **achieved))
     rogue = err > tol * scale + factor * amp
     if rogue.any():
