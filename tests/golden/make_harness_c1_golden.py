@@ -23,61 +23,16 @@ for p in (ROOT, os.path.join(ROOT, "free-surgs_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from fsgs_amd import metrics  # noqa: E402
 from oracle.fsgs_oracle import Oracle  # noqa: E402
 from tests import ref_harness  # noqa: E402
 
-C1 = dict(W=640, H=512, n_frames=8, P=20_000, tracking_iter=50, mapping_iter=30, first_mapping_iter=200,
-          densify_interval=300, rng_seed=11, seed=0)
+C1 = ref_harness.C1
+make_c1_inputs, input_stats = ref_harness.make_c1_inputs, ref_harness.c1_input_stats
 
 
 def outcome(h, frames):
-    """what the GPU test compares: see the module docstring"""
-    tr = h.trace
-    n = len(frames.colors)
-    maps = [e for e in tr if e[0] == "map"]
-    tracks = [e for e in tr if e[0] == "track"]
-    out = {}
-    out["track_last"] = np.array([[e[3], e[4], e[5]] for e in tracks if e[2] == C1["tracking_iter"] - 1], np.float64)  # [n-1, 3]
-    out["track_first"] = np.array([[e[3], e[4], e[5]] for e in tracks if e[2] == 0], np.float64)
-    # mean mapping loss of every mapped frame's block of iterations (frame 0: 200, then 30 each)
-    bounds, it = [], 0
-    for t in range(n):
-        if t in set(int(i) for i in frames.i_train):
-            k = C1["first_mapping_iter"] if t == 0 else C1["mapping_iter"]
-            bounds.append((t, it, it + k))
-            it += k
-    ml = np.array([e[3] for e in maps], np.float64)
-    out["map_mean"] = np.array([[t, ml[a:b].mean(), ml[b - 1]] for t, a, b in bounds], np.float64)
-    out["densify"] = np.array([[e[1], e[2]] for e in tr if e[0] == "densify"], np.int64)
-    out["final_P"] = h.pc.num_points
-    out["pose_r"] = h.poses.r.detach().cpu().numpy()
-    out["pose_t"] = h.poses.t.detach().cpu().numpy()
-    with torch.no_grad():
-        pred = np.stack([h.poses.get_pose(i).detach().cpu().numpy() for i in range(n)])
-    gt = np.stack([np.asarray(g, np.float32) for g in frames.gt_w2c])
-    out["pose_metrics"] = np.array(metrics.pose_metrics(pred, gt)[1], np.float64)  # rpe_t, rpe_r (deg), ate
-    # PSNR of the test frame(s) at their tracked pose (train.py:401-432 evaluates exactly these)
-    ps = []
-    with torch.no_grad():
-        for i in frames.i_test:
-            pkg = h.render(int(i), False, False)
-            ps.append(metrics.psnr(frames.colors[int(i)].cpu().numpy()[None], pkg["render"].detach().cpu().numpy()[None]))
-    out["psnr_test"] = np.array(ps, np.float64)
-    return out
-
-
-def make_c1_inputs(oracle):
-    ratio = C1["P"] / float(C1["W"] * C1["H"])
-    return ref_harness.make_inputs(oracle, W=C1["W"], H=C1["H"], n_frames=C1["n_frames"], P_scene=60_000, ratio=ratio, seed=3)
-
-
-def input_stats(fx):
-    """coarse fingerprints of the regenerated sequence: per-frame means of colours / mono-depth / flow, the first points"""
-    return np.concatenate([fx["colors_u8"].astype(np.float64).mean(axis=(1, 2, 3)) / 255.0,
-                           fx["monodeps_f16"].astype(np.float64).mean(axis=(1, 2)),
-                           np.abs(fx["flows_fw_f16"].astype(np.float64)).mean(axis=(1, 2, 3)),
-                           fx["_xyz"][:16].astype(np.float64).reshape(-1), fx["_scaling"][:16, 0].astype(np.float64)])
+    """what the GPU test compares (ref_harness.c1_outcome: one definition for both harnesses)"""
+    return ref_harness.c1_outcome(h.trace, h.pc, h.poses, frames, lambda t: h.render(t, False, False)["render"])
 
 
 def run(fx, oracle):
