@@ -455,43 +455,77 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
   float dxyz[3] = {0.f, 0.f, 0.f};
   const bool live = i < P && rad > 0;
   float m2x = 0.f, m2y = 0.f;
-  // ---- part S (needs the staged coefficients): the SH colour adjoint.  Leaves the gradient of every SH-rest coefficient
-  // in this Gaussian's LDS row (what part D consumes), updates features_dc, and keeps the view-direction term of dL/dxyz.
-  float ddir[3] = {0.f, 0.f, 0.f};
-  if (live && (mode & MODE_PARAM_GRAD)) {
-    float vx = xw[0] - a.cam_center[0], vy = xw[1] - a.cam_center[1], vz = xw[2] - a.cam_center[2];
-    float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
-    float dx = vx * inv_n, dy = vy * inv_n, dz = vz * inv_n;
-    float b[16], bx[16], by[16], bz[16];
-    sh_basis(a.deg, dx, dy, dz, b);
-    sh_basis_grad(a.deg, dx, dy, dz, bx, by, bz);
-    const int nk = (a.deg + 1) * (a.deg + 1);
-    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+  if (live) {
+    Activated act = activate(a, raw);
+    float ga[8];
+    unpack_moments(acc, co, ga);
+    GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
+    m2x = ga[6] * (0.5f * cam.W);
+    m2y = ga[7] * (0.5f * cam.H);
+    const float *V = cam.V;
+    float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
+    float dzq = dc[3] + 2.f * zq * dc[5];
+    gxc[0] = gg.dm[0] + V[8] * dzq;
+    gxc[1] = gg.dm[1] + V[9] * dzq;
+    gxc[2] = gg.dm[2] + V[10] * dzq;
+    if (mode & MODE_GS_GRAD) {
+      const float *w = a.w2c;
+      dxyz[0] = w[0] * gxc[0] + w[4] * gxc[1] + w[8] * gxc[2];
+      dxyz[1] = w[1] * gxc[0] + w[5] * gxc[1] + w[9] * gxc[2];
+      dxyz[2] = w[2] * gxc[0] + w[6] * gxc[1] + w[10] * gxc[2];
+    }
+    if (mode & MODE_PARAM_GRAD) {
+      // activations
+      sink.put(4, i, 0, gg.ds[0] * act.scale.x);
+      sink.put(4, i, 1, gg.ds[1] * act.scale.y);
+      sink.put(4, i, 2, gg.ds[2] * act.scale.z);
+      float qd = act.q.x * gg.dq[0] + act.q.y * gg.dq[1] + act.q.z * gg.dq[2] + act.q.w * gg.dq[3];
+      float inv = 1.0f / act.qnorm;
+      sink.put(5, i, 0, (gg.dq[0] - act.q.x * qd) * inv);
+      sink.put(5, i, 1, (gg.dq[1] - act.q.y * qd) * inv);
+      sink.put(5, i, 2, (gg.dq[2] - act.q.z * qd) * inv);
+      sink.put(5, i, 3, (gg.dq[3] - act.q.w * qd) * inv);
+      sink.put(3, i, 0, gg.dop * act.op * (1.0f - act.op));
+      // SH colour
+      float vx = xw[0] - a.cam_center[0], vy = xw[1] - a.cam_center[1], vz = xw[2] - a.cam_center[2];
+      float inv_n = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+      float dx = vx * inv_n, dy = vy * inv_n, dz = vz * inv_n;
+      float b[16], bx[16], by[16], bz[16];
+      sh_basis(a.deg, dx, dy, dz, b);
+      sh_basis_grad(a.deg, dx, dy, dz, bx, by, bz);
+      const int nk = (a.deg + 1) * (a.deg + 1);
+      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
-      if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = gcol;
-      else sink.put(1, i, c, b[0] * gcol);
-      for (int k = 1; k < a.K; k++) {
-        const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
-        if (k < nk) {
-          float coef = my_rest[at];
-          if (OUT != OUT_COMPACT) my_rest[at] = b[k] * gcol;
-          ddx = fmaf(gcol * coef, bx[k], ddx);
-          ddy = fmaf(gcol * coef, by[k], ddy);
-          ddz = fmaf(gcol * coef, bz[k], ddz);
-        } else if (OUT != OUT_COMPACT) {
-          my_rest[at] = 0.f;
+      for (int c = 0; c < 3; c++) {
+        float gcol = ((fl >> c) & 1u) ? 0.f : dc[c];
+        if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = gcol;
+        else sink.put(1, i, c, b[0] * gcol);
+        for (int k = 1; k < a.K; k++) {
+          const int at = (k - 1) * 3 + c;  // slot in this Gaussian's LDS row: read the coefficient, leave the gradient
+          if (k < nk) {
+            float coef = my_rest[at];
+            if (OUT != OUT_COMPACT) my_rest[at] = b[k] * gcol;
+            ddx = fmaf(gcol * coef, bx[k], ddx);
+            ddy = fmaf(gcol * coef, by[k], ddy);
+            ddz = fmaf(gcol * coef, bz[k], ddz);
+          } else if (OUT != OUT_COMPACT) {
+            my_rest[at] = 0.f;
+          }
         }
       }
+      // d = v/|v|  ->  dv = (dd - d (d.dd)) / |v|
+      float dot = dx * ddx + dy * ddy + dz * ddz;
+      dxyz[0] += (ddx - dx * dot) * inv_n;
+      dxyz[1] += (ddy - dy * dot) * inv_n;
+      dxyz[2] += (ddz - dz * dot) * inv_n;
     }
-    // d = v/|v|  ->  dv = (dd - d (d.dd)) / |v|
-    float dot = dx * ddx + dy * ddy + dz * ddz;
-    ddir[0] = (ddx - dx * dot) * inv_n;
-    ddir[1] = (ddy - dy * dot) * inv_n;
-    ddir[2] = (ddz - dz * dot) * inv_n;
   } else if (i < P && (mode & MODE_PARAM_GRAD)) {
     // zero gradient: plain mode writes the zeros, Adam mode still decays the moments and applies them
+#pragma unroll
+    for (int c = 0; c < 3; c++) sink.put(4, i, c, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; c++) sink.put(5, i, c, 0.f);
+    sink.put(3, i, 0, 0.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       if (OUT == OUT_COMPACT) out.compact[(size_t)i * COMPACT_ROW + 3 + c] = 0.f;
@@ -500,80 +534,14 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
     if (OUT != OUT_COMPACT)
       for (int k = 0; k < row; k++) my_rest[k] = 0.f;
   }
-  // ---- part G (registers only): the geometry adjoint A.5 - A.8 with the activations and the Adam update of the scaling,
-  // rotation and opacity rows
-  auto geometry = [&]() __attribute__((always_inline)) {
-    if (live) {
-      Activated act = activate(a, raw);
-      float ga[8];
-      unpack_moments(acc, co, ga);
-      GeomGrad gg = geom_backward(cam, act.xc, act.yc, act.zc, act.scale, act.q, ga);
-      m2x = ga[6] * (0.5f * cam.W);
-      m2y = ga[7] * (0.5f * cam.H);
-      const float *V = cam.V;
-      float zq = V[8] * act.xc + V[9] * act.yc + V[10] * act.zc + V[11];
-      float dzq = dc[3] + 2.f * zq * dc[5];
-      gxc[0] = gg.dm[0] + V[8] * dzq;
-      gxc[1] = gg.dm[1] + V[9] * dzq;
-      gxc[2] = gg.dm[2] + V[10] * dzq;
-      if (mode & MODE_GS_GRAD) {
-        const float *w = a.w2c;
-        dxyz[0] = w[0] * gxc[0] + w[4] * gxc[1] + w[8] * gxc[2];
-        dxyz[1] = w[1] * gxc[0] + w[5] * gxc[1] + w[9] * gxc[2];
-        dxyz[2] = w[2] * gxc[0] + w[6] * gxc[1] + w[10] * gxc[2];
-      }
-      if (mode & MODE_PARAM_GRAD) {
-        // activations
-        sink.put(4, i, 0, gg.ds[0] * act.scale.x);
-        sink.put(4, i, 1, gg.ds[1] * act.scale.y);
-        sink.put(4, i, 2, gg.ds[2] * act.scale.z);
-        float qd = act.q.x * gg.dq[0] + act.q.y * gg.dq[1] + act.q.z * gg.dq[2] + act.q.w * gg.dq[3];
-        float inv = 1.0f / act.qnorm;
-        sink.put(5, i, 0, (gg.dq[0] - act.q.x * qd) * inv);
-        sink.put(5, i, 1, (gg.dq[1] - act.q.y * qd) * inv);
-        sink.put(5, i, 2, (gg.dq[2] - act.q.z * qd) * inv);
-        sink.put(5, i, 3, (gg.dq[3] - act.q.w * qd) * inv);
-        sink.put(3, i, 0, gg.dop * act.op * (1.0f - act.op));
-        dxyz[0] += ddir[0];
-        dxyz[1] += ddir[1];
-        dxyz[2] += ddir[2];
-      }
-    } else if (i < P && (mode & MODE_PARAM_GRAD)) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) sink.put(4, i, c, 0.f);
-#pragma unroll
-      for (int c = 0; c < 4; c++) sink.put(5, i, c, 0.f);
-      sink.put(3, i, 0, 0.f);
+  if (stage && OUT != OUT_COMPACT) {  // coalesced store (or coalesced Adam update) of the SH-rest gradients
+    __syncthreads();
+    if (!ADAM) {
+      stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
+    } else {
+      adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt, ad.next_colors != nullptr);
+      if (ad.next_colors) __syncthreads();  // the updated rows are read back per Gaussian below
     }
-  };
-  // ---- part D: coalesced store (or coalesced Adam update) of the SH-rest gradients parked in LDS
-  auto sh_rows = [&]() __attribute__((always_inline)) {
-    if (stage && OUT != OUT_COMPACT) {
-      __syncthreads();
-      if (!ADAM) {
-        stage_out(out.f_rest, s_rest, (size_t)b0 * row, stage_cnt);
-      } else {
-        adam_rows_from_lds(a, ad, s_rest, (size_t)b0 * row, stage_cnt, ad.next_colors != nullptr);
-        if (ad.next_colors) __syncthreads();  // the updated rows are read back per Gaussian below
-      }
-    }
-  };
-  // G is arithmetic (the heaviest part of the kernel: no memory traffic but its 24 stores), D is the kernel's largest stream
-  // (76 % of all parameters and both their moments).  They are independent, and every workgroup of a generation reaches them
-  // at the same moment -- all 768 resident workgroups computing while the memory system idles, then all streaming (round 3:
-  // "arithmetic 23 us, no overlap").  Half of the workgroups therefore take them in the other order: while one half
-  // computes, the other half streams.
-#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_NO_PHASE_SWAP)  // diagnostics flavour only: the round-3 order everywhere (A/B)
-  const bool stream_first = false;
-#else
-  const bool stream_first = ADAM && (((blockIdx.x >> 3) ^ blockIdx.x) & 1);
-#endif
-  if (stream_first) {
-    sh_rows();
-    geometry();
-  } else {
-    geometry();
-    sh_rows();
   }
   if (i < P) {
     if (out.means2D) { out.means2D[3 * i] = m2x; out.means2D[3 * i + 1] = m2y; out.means2D[3 * i + 2] = 0.f; }

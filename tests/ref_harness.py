@@ -23,12 +23,17 @@ from fsgs_amd.trainer import LOSS_W_MAPPING, LOSS_W_TRACKING, FrameData, PoseTra
 from tests import ref_cpu
 
 
-# How far two CORRECT fp32 runs of the pinned schedule may differ in a per-iteration loss once the cloud has been
-# densified: the children start with zero Adam moments, their first steps are lr * sign(gradient), and a last-bit
-# difference in a near-zero gradient becomes a full-size step.  Measured on the reference itself (this harness with 8
-# OpenMP threads in the oracle's backward against its own 1-thread fixture): 0.9e-4 .. 5.4e-4 after the densification,
-# 6e-7 before it (tests/test_harness_pin_cpu.py).  Four times the largest value seen.
-POST_DENSIFY_RTOL = 2e-3
+# How far the HIP harness may sit from the recorded trajectory in a per-iteration loss once the cloud has been densified: the
+# children start with zero Adam moments, their first steps are lr * sign(gradient), and a last-bit difference in a near-zero
+# gradient becomes a full-size step.  MEASURED (round 4): 200 runs of tests/test_harness_pin_gpu.py's schedule
+# on one MI355X (profiles/r04_pin_deviation_200runs.txt; the runs differ by the arrival order of the blend's float atomics)
+# leave the fixture by 0.47e-4 .. 3.32e-4 after the densification (median 1.8e-4, 99th percentile 3.25e-4; tracking losses
+# <= 2.8e-4) and by <= 1.3e-5 before it.  The bound is 1.5 x the worst of those 200.  (Rounds 2-3 carried 5e-4, then 2e-3.)
+POST_DENSIFY_RTOL = 5e-4
+# ... and how far the REFERENCE moves against itself there (this CPU harness with 8 OpenMP threads in the oracle's backward
+# against its own 1-thread fixture: 0.9e-4 .. 5.4e-4 over the thread counts tried, 6e-7 before the densification;
+# tests/test_harness_pin_cpu.py): the yardstick that says the number above is not a property of the HIP path
+REFERENCE_SELF_RTOL = 1e-3
 
 
 @contextlib.contextmanager

@@ -27,6 +27,9 @@ def _settings(cam):
         debug=False)
 
 
+IMAGE_TOL = 1e-5  # of (max |want| + 1): image and depth at the operator boundary (same fp32 inputs on both sides)
+
+
 def _run_hip(cam, xyz, col, op, sc, rot, dL):
     from diff_gaussian_rasterization import GaussianRasterizer
 
@@ -65,9 +68,12 @@ def _compare(oracle, cam, xyz, col, op, sc, rot, seed=0, strict=False, tag=None)
         assert not rogue_r.any(), "radii differ at %s without a ceil() near-tie" % np.nonzero(rogue_r)[0][:8].tolist()
         assert int(((radii > 0) != (orad > 0)).sum()) == 0, "visibility filter differs"
         stats = {}
-        # colours live in [0,1]: abs 1e-4 of full scale
-        stats["image"] = assert_close_attributed(img, oi, zero(oi) if amp is None else amp["image"], "image", floor=1.0, tag=tag)
-        stats["depth"] = assert_close_attributed(dep, od, zero(od) if amp is None else amp["depth"], "depth", floor=1.0, tag=tag)
+        # image / depth: IMAGE_TOL of (max + 1) -- ten times the largest error measured where no near-tie is in play (C1 poses
+        # 2 and 6: image 4.8e-7, depth 8.2e-7 of that scale; the 99.99th percentile at C2 / C4 is 1.1e-6 .. 2.3e-6;
+        # profiles/r04_full_size_parity.jsonl), not SURVEY's blanket 1e-4, which left two orders of magnitude of slack
+        # (VERDICT r3 #3).  Whatever lies beyond needs a witness like any other element.
+        stats["image"] = assert_close_attributed(img, oi, zero(oi) if amp is None else amp["image"], "image", tol=IMAGE_TOL, floor=1.0, tag=tag)
+        stats["depth"] = assert_close_attributed(dep, od, zero(od) if amp is None else amp["depth"], "depth", tol=IMAGE_TOL, floor=1.0, tag=tag)
         # an analytically-zero gradient (d/drotation of an isotropic Gaussian) is cancellation round-off of
         # terms of size ~|dL/dscale|*|scale| in both implementations: floor each norm at 1e-3 of the largest
         # gradient tensor, i.e. an absolute tolerance of 1e-7 of that for such tensors
