@@ -234,9 +234,15 @@ def ptr(t):
 
 
 def current_stream():
+    """raw handle of the calling thread's current stream on the current device (torch.cuda.current_stream() builds a Stream
+    object and resolves the device three times over: ~10 us a call, six calls per step; the private accessor underneath it
+    is ~1 us -- with the public route as the fallback should it ever go away)"""
     import torch
 
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def profile_enable(names=None, stride=1):

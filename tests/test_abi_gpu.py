@@ -91,3 +91,19 @@ def test_fused_entry_points_reject_bad_arguments():
     assert _lib.check(0, "ok") is None
     with pytest.raises(_lib.FsgsError):
         _lib.check(_lib.FSGS_ERR_INVALID, "demo")
+
+
+def test_current_stream_handle_follows_torch_stream_contexts():
+    """_lib.current_stream() reads the raw handle through torch's private accessor (1 us instead of 10): it must name the
+    stream the calling thread has current, inside and outside `with torch.cuda.stream(...)`, on the current device."""
+    from fsgs_amd import _lib
+
+    assert (_lib.current_stream().value or 0) == torch.cuda.current_stream().cuda_stream  # (the default stream: handle 0 = NULL)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert (_lib.current_stream().value or 0) == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+        inner = torch.cuda.Stream()
+        with torch.cuda.stream(inner):
+            assert (_lib.current_stream().value or 0) == inner.cuda_stream
+        assert (_lib.current_stream().value or 0) == side.cuda_stream
+    assert (_lib.current_stream().value or 0) == torch.cuda.current_stream().cuda_stream
