@@ -1,7 +1,7 @@
 """Load balance of blend_bwd: every wave (= tile) stamps its start / end (100 MHz wall clock) into a buffer handed over
 through FSGS_DBG_TILE_TIMES.  Prints the makespan, the mean number of resident waves, the occupancy over time and how well
 the LPT key (list length) predicts a tile's duration compared with the depth actually walked (max n_contrib).
-    gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && python scripts/dev/diag_tile_times.py [--fwd]'
+    gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/dev/diag_tile_times.py [--fwd]'
 (the stamps are a diagnostics hook: only a library built with FSGS_DIAG=1 looks at the environment variable)"""
 import os
 import sys
@@ -41,7 +41,7 @@ def main():
         t0, t1 = d[:, 0].astype(np.float64) * 0.01, d[:, 1].astype(np.float64) * 0.01  # us
         ok = d[:, 1] > 0
         if not ok.any():
-            sys.exit("no stamps: the library was built without FSGS_DIAG=1 (FSGS_DIAG=1 python free-surgs_amd/build.py)")
+            sys.exit("no stamps: needs the diagnostics flavour (FSGS_DIAG=1 python free-surgs_amd/build.py; FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so)")
         lst = (d[:, 3] >> 32).astype(np.float64)
         walked = (d[:, 3] & 0xFFFFFFFF).astype(np.float64)
         start, end = t0[ok].min(), t1[ok].max()

@@ -1,7 +1,7 @@
 """Which dispatch order would the blend kernels like?  (FSGS_DIAG=1 build: FSGS_DBG_ORDER_FWD / _BWD inject an order made
 here on the host.)  One frame of C2, the cloud frozen (lr 0): the list lengths are read back from the state, several orders
 are formed from them and each is timed over 30 forward + backward passes with the library's own HIP events.
-    gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && python scripts/dev/order_experiment.py'"""
+    gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/dev/order_experiment.py'"""
 import os
 import sys
 
