@@ -463,7 +463,7 @@ def main():
                     help="N > 1: > 1 produces the compact gradient in that many row chunks and starts each chunk's "
                          "all-reduce while the next is produced, Adam per chunk behind it (dist.ProducerPipelinedReducer); "
                          "default one collective in the first timed loop; every N > 1 run then times the x4 pipelined route over "
-                         "the same K steps as well and reports the faster of the two (config.exchange, exchange_routes_ms_per_step)")
+                         "the same K steps as well and reports it beside the configured route (exchange_routes_ms_per_step); `value` is always the configured route")
     ap.add_argument("--ar-algo", default="rccl", choices=["rccl", "direct"],
                     help="N > 1: the step's exchange -- `rccl`: one torch.distributed all_reduce (RCCL picks algorithm and "
                          "protocol); `direct`: dist.DirectAllReduce, an explicit all-to-all of shards + local sum + all-gather "
