@@ -128,8 +128,9 @@ class CpuHarness:
     def tracking(self, t):
         rigid = None
         if t > 1:
-            with torch.no_grad():
-                Fm = epipolar.fundamental_from_w2c(self.poses.get_pose(t - 2), self.poses.get_pose(t - 1), self.frames.K)
+            with torch.no_grad():  # get_fundamental_matrix asks the network directly: pred_w2c is NOT refreshed
+                # (scene/pose_optimizer.py:640-648; the same values as get_pose for every frame that has been mapped)
+                Fm = epipolar.fundamental_from_w2c(self.poses.peek_pose(t - 2), self.poses.peek_pose(t - 1), self.frames.K)
             rigid = epipolar.rigid_mask_torch(epipolar.sampson_distance_torch(self.frames.flows_fw[t - 2], Fm))
         depth_prev = self.frames.pred_depths[t - 1].reshape(1, self.h, self.w)
         w2c_prev = self.poses.pred_w2c[t - 1]
@@ -181,6 +182,11 @@ class CpuHarness:
                 d = pkg["render_dep"].detach().float()
                 self.frames.pred_depths[t] = d[0].expand(self.h, self.w).contiguous() if self.row0_depth_quirk else d.contiguous()
                 self.keyframes.append(t)
+            elif self.frames.pred_depths[t] is None:
+                # a TEST frame (every 8th) is never mapped: record_data['pred_depths'][t] keeps its initial zeros, the next
+                # frame's flow loss finds no valid pixel and is the constant 0 (train.py:333-343,
+                # scene/pose_optimizer.py:176-186); its recorded pose is the one its last tracking iteration rendered with
+                self.frames.pred_depths[t] = torch.zeros((self.h, self.w), dtype=torch.float32)
 
 
 # ---- the pinned inputs: a tiny synthetic sequence made entirely on CPU ----------------------------------------------
