@@ -91,7 +91,9 @@ def test_runner_reaches_the_outcome_of_the_cpu_oracle_harness_on_c1_as_stated(or
     # train.py:492-506 / 401-432: RPE_t, RPE_r (degrees), ATE and the PSNR of the test frame
     _within(got["pose_metrics"], ref["pose_metrics"], alt["pose_metrics"], 3.0, np.array([0.05 * step, 0.01, 0.05 * step]), "RPE / ATE")
     _within(got["psnr_test"], ref["psnr_test"], alt["psnr_test"], 3.0, 0.5, "PSNR of the test frame (dB)")
-    assert got["pose_metrics"][2] < 0.25 * step, "ATE %.2e against a ground-truth step of %.2e" % (got["pose_metrics"][2], step)
+    # (no absolute bar on the ATE: the mono-depth of every frame is min-max normalised on its own, as the reference's loader
+    # does, scene/pose_optimizer.py:406-407, so the map's gauge is not a similarity of the ground truth and the REFERENCE's
+    # own ATE on this sequence is about one ground-truth step -- what is asserted is that the HIP harness lands where it does)
 
 
 def _record(got, ref, alt):
