@@ -91,7 +91,10 @@ def test_runner_reaches_the_outcome_of_the_cpu_oracle_harness_on_c1_as_stated(or
     gt = np.stack([np.asarray(g, np.float32) for g in frames.gt_w2c])
     step = float(np.mean([np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(len(gt) - 1)]))
     _within(got["pose_t"], ref["pose_t"], alt["pose_t"], 3.0, 0.15 * step, "tracked translations")
-    _within(got["pose_r"], ref["pose_r"], alt["pose_r"], 3.0, 1e-3, "tracked quaternions")
+    # (the stored quaternions are NOT unit: LearnPose normalises on use, Adam moves the raw parameter, and its norm is a gauge
+    # that drifts with the run -- 1.049 against 1.058 in one HIP run -- so the rotations are compared normalised)
+    unit = lambda q: q / np.linalg.norm(q, axis=1, keepdims=True)
+    _within(unit(got["pose_r"]), unit(ref["pose_r"]), unit(alt["pose_r"]), 3.0, 1e-3, "tracked rotations (unit quaternions)")
     # train.py:492-506 / 401-432: RPE_t, RPE_r (degrees), ATE and the PSNR of the test frame
     _within(got["pose_metrics"], ref["pose_metrics"], alt["pose_metrics"], 3.0, np.array([0.1 * step, 0.03, 0.1 * step]), "RPE / ATE")
     _within(got["psnr_test"], ref["psnr_test"], alt["psnr_test"], 3.0, 2.5, "PSNR of the test frame (dB)")
@@ -110,9 +113,10 @@ def _record(got, ref, alt):
     rec = {"test": "harness_c1"}
     for k in ("track_first", "track_last", "map_mean", "pose_metrics", "psnr_test"):
         rec[k] = {"hip_vs_reference_max_rel": rel(got[k], ref[k]), "reference_vs_itself_max_rel": rel(alt[k], ref[k])}
-    for k in ("pose_t", "pose_r"):
-        rec[k] = {"hip_vs_reference_max_abs": float(np.abs(got[k] - ref[k]).max()),
-                  "reference_vs_itself_max_abs": float(np.abs(alt[k] - ref[k]).max())}
+    unit = lambda q: q / np.linalg.norm(q, axis=1, keepdims=True)
+    for k, f in (("pose_t", lambda a: a), ("pose_r", unit)):
+        rec[k] = {"hip_vs_reference_max_abs": float(np.abs(f(got[k]) - f(ref[k])).max()),
+                  "reference_vs_itself_max_abs": float(np.abs(f(alt[k]) - f(ref[k])).max())}
     rec["final_P"] = [int(got["final_P"]), int(ref["final_P"]), int(alt["final_P"])]
     rec["pose_metrics_values"] = {"hip": np.asarray(got["pose_metrics"]).tolist(), "reference": np.asarray(ref["pose_metrics"]).tolist(),
                                   "reference_second_run": np.asarray(alt["pose_metrics"]).tolist()}
