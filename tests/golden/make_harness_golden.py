@@ -28,6 +28,11 @@ def run(fx, oracle):
     torch.manual_seed(0)
     with ref_harness.deterministic_rng(pin["rng_seed"]):
         h.progressive_run()
+        # what the progressive phase leaves behind, before the global phase moves on from it
+        h.after_progressive = dict(n_trace=len(h.trace), pose_r=h.poses.r.detach().numpy().copy(),
+                                   pose_t=h.poses.t.detach().numpy().copy(), final_P=h.pc.num_points,
+                                   final_xyz_mean=h.pc.params["_xyz"].detach().mean(0).numpy().copy())
+        h.global_run(pin["global_iters"])  # train.py:378-443 behind it: same generator, same iteration counter
     return h
 
 
@@ -36,7 +41,8 @@ def main():
     oracle.set_threads(1)  # deterministic accumulation order
     fx = ref_harness.make_inputs(oracle)
     h = run(fx, oracle)
-    tr = h.trace
+    tr = h.trace[:h.after_progressive["n_trace"]]
+    gl = h.trace[h.after_progressive["n_trace"]:]
     out = dict(fx)
     out["map_loss"] = np.array([e[3] for e in tr if e[0] == "map"], np.float64)
     out["map_iter"] = np.array([e[1] for e in tr if e[0] == "map"], np.int64)
@@ -44,14 +50,22 @@ def main():
     out["track_loss"] = np.array([[e[3], e[4], e[5]] for e in tr if e[0] == "track"], np.float64)
     out["track_frame_iter"] = np.array([[e[1], e[2]] for e in tr if e[0] == "track"], np.int64)
     out["densify"] = np.array([[e[1], e[2]] for e in tr if e[0] == "densify"], np.int64)
-    out["pose_r"] = h.poses.r.detach().numpy()
-    out["pose_t"] = h.poses.t.detach().numpy()
-    out["final_P"] = h.pc.num_points
-    out["final_xyz_mean"] = h.pc.params["_xyz"].detach().mean(0).numpy()
+    for k in ("pose_r", "pose_t", "final_P", "final_xyz_mean"):
+        out[k] = h.after_progressive[k]
+    # the global phase (ref_harness.PIN["global_iters"]): per-iteration frame and loss, densifications, the cloud at the end
+    out["global_map_loss"] = np.array([e[3] for e in gl if e[0] == "map"], np.float64)
+    out["global_map_iter"] = np.array([e[1] for e in gl if e[0] == "map"], np.int64)
+    out["global_map_view"] = np.array([e[2][0] for e in gl if e[0] == "map"], np.int64)
+    out["global_densify"] = np.array([[e[1], e[2]] for e in gl if e[0] == "densify"], np.int64).reshape(-1, 2)
+    out["global_final_P"] = h.pc.num_points
+    out["global_final_xyz_mean"] = h.pc.params["_xyz"].detach().mean(0).numpy()
+    out["global_sh_degree"] = h.pc.active_sh_degree
     np.savez_compressed(os.path.join(HERE, "harness_pin.npz"), **out)
     print("P0 %d -> densify %s -> final %d" % (fx["_xyz"].shape[0], out["densify"].tolist(), out["final_P"]))
     print("map loss", np.round(out["map_loss"], 5).tolist())
     print("track loss", np.round(out["track_loss"][:, 0], 5).tolist())
+    print("global: views %s loss %s densify %s final P %d" % (out["global_map_view"].tolist(), np.round(out["global_map_loss"], 5).tolist(),
+                                                            out["global_densify"].tolist(), out["global_final_P"]))
     print("fixture bytes", os.path.getsize(os.path.join(HERE, "harness_pin.npz")))
 
 

@@ -189,6 +189,21 @@ class CpuHarness:
                 self.frames.pred_depths[t] = torch.zeros((self.h, self.w), dtype=torch.float32)
 
 
+    # ---- train.py:378-443 (the training part: evaluation / checkpoints are not on the path) ----
+    def global_run(self, iterations, first_iter=0):
+        """`for iter in range(first_iter, iterations + 1)`: a fresh Adam with default eps (scene/gaussian_model.py:372-378), per
+        iteration a random training frame, the SH degree raised when iter % 1000 == 0 (so at iteration 0), the xyz learning
+        rate of that iteration, ONE one-view mapping iteration -- self.iteration keeps counting from the progressive phase, so
+        the densification schedule does too (train.py:236,305)."""
+        self.pc.initialize_optimizer(fused=False)
+        for it in range(int(first_iter), iterations + 1):
+            ts = int(self.rng.choice(list(self.frames.i_train)))
+            if it % 1000 == 0:
+                self.pc.oneupSHdegree()
+            self.pc.update_learning_rate(it)
+            self.mapping(ts, 1, progressive=False)
+
+
 # ---- the pinned inputs: a tiny synthetic sequence made entirely on CPU ----------------------------------------------
 def make_inputs(oracle, W=256, H=192, n_frames=3, P_scene=3000, ratio=0.02, seed=0):
     """A hidden opaque scene rendered along a smooth trajectory by the CPU reference render -> per frame colours
@@ -269,7 +284,8 @@ def load_inputs(fx, device):
 
 
 # what the pinned run does (shared by the fixture script and the GPU test)
-PIN = dict(tracking_iter=5, mapping_iter=5, first_mapping_iter=5, densify_interval=8, rng_seed=11, seed=0)
+# (global_iters: Runner.global_run(6) behind the progressive phase = 7 iterations, counter 16 .. 22: the first one densifies)
+PIN = dict(tracking_iter=5, mapping_iter=5, first_mapping_iter=5, densify_interval=8, rng_seed=11, seed=0, global_iters=6)
 
 
 # ---- BASELINE.json configs[0] as stated: 8 frames, 640x512, 20 k initial Gaussians, the reference's own schedule ----------

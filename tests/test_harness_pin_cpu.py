@@ -16,13 +16,20 @@ def test_cpu_oracle_harness_regenerates_the_fixture(oracle32):
     fx = dict(np.load(os.path.join(HERE, "golden", "harness_pin.npz")))
     oracle32.set_threads(1)
     h = M.run(fx, oracle32)
-    maps = np.array([e[3] for e in h.trace if e[0] == "map"])
+    n = h.after_progressive["n_trace"]
+    maps = np.array([e[3] for e in h.trace[:n] if e[0] == "map"])
     tracks = np.array([[e[3], e[4], e[5]] for e in h.trace if e[0] == "track"])
     np.testing.assert_allclose(maps, fx["map_loss"], rtol=1e-6)
     np.testing.assert_allclose(tracks, fx["track_loss"], rtol=1e-6, atol=1e-9)
-    assert [[e[1], e[2]] for e in h.trace if e[0] == "densify"] == fx["densify"].tolist()
-    np.testing.assert_allclose(h.poses.t.detach().numpy(), fx["pose_t"], atol=1e-7)
-    assert h.pc.num_points == int(fx["final_P"]) and int(fx["_xyz"].shape[0]) == 983
+    assert [[e[1], e[2]] for e in h.trace[:n] if e[0] == "densify"] == fx["densify"].tolist()
+    np.testing.assert_allclose(h.after_progressive["pose_t"], fx["pose_t"], atol=1e-7)
+    assert h.after_progressive["final_P"] == int(fx["final_P"]) and int(fx["_xyz"].shape[0]) == 983
+    # the global phase behind it
+    gl = h.trace[n:]
+    np.testing.assert_allclose(np.array([e[3] for e in gl if e[0] == "map"]), fx["global_map_loss"], rtol=1e-6)
+    assert [e[2][0] for e in gl if e[0] == "map"] == fx["global_map_view"].tolist()
+    assert [[e[1], e[2]] for e in gl if e[0] == "densify"] == fx["global_densify"].tolist()
+    assert h.pc.num_points == int(fx["global_final_P"])
     # the stored cloud is the INITIAL one (the run must not have written through to the arrays)
     assert float(np.abs(fx["_rotation"][:, 1:]).max()) == 0.0
 
@@ -45,11 +52,11 @@ def test_the_reference_trajectory_is_only_that_reproducible_after_a_densificatio
         h = M.run(fx, oracle32)
     finally:
         oracle32.set_threads(1)
-    maps = np.array([e[3] for e in h.trace if e[0] == "map"])
+    maps = np.array([e[3] for e in h.trace[:h.after_progressive["n_trace"]] if e[0] == "map"])
     n_pre = int((fx["map_iter"] < fx["densify"][0, 0]).sum())
     rel = np.abs(maps - fx["map_loss"]) / np.abs(fx["map_loss"])
     print("reference vs itself (%d threads): per-iteration loss off by %.1e before, %.1e after the densification" % (
         n, rel[:n_pre].max(), rel[n_pre:].max()))
-    assert [[e[1], e[2]] for e in h.trace if e[0] == "densify"] == fx["densify"].tolist()
+    assert [[e[1], e[2]] for e in h.trace[:h.after_progressive["n_trace"]] if e[0] == "densify"] == fx["densify"].tolist()
     assert rel[:n_pre].max() <= 1e-5
     assert rel[n_pre:].max() <= ref_harness.REFERENCE_SELF_RTOL

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 FX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness_pin.npz")
 
 
-def _run_gpu(fx, fused=True):
+def _run_gpu(fx, fused=True, with_global=False):
     from fsgs_amd.trainer import Runner
 
     pin = ref_harness.PIN
@@ -29,14 +29,21 @@ def _run_gpu(fx, fused=True):
     torch.manual_seed(0)
     with ref_harness.deterministic_rng(pin["rng_seed"]):
         run.progressive_run()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        # what the progressive phase leaves behind, before the global phase (same generator, same iteration counter) moves on
+        run.after_progressive = dict(n_trace=len(run.trace), pose_r=run.poses.r.detach().cpu().numpy().copy(),
+                                     pose_t=run.poses.t.detach().cpu().numpy().copy(), final_P=run.pc.num_points,
+                                     final_xyz_mean=run.pc.params["_xyz"].detach().mean(0).cpu().numpy().copy())
+        if with_global:
+            run.global_run(pin["global_iters"], eval_every=0)
+            torch.cuda.synchronize()
     return run
 
 
 def test_runner_reproduces_the_cpu_oracle_trajectory():
     fx = dict(np.load(FX))
-    run = _run_gpu(fx)
-    tr = run.trace
+    run = _run_gpu(fx, with_global=True)
+    tr = run.trace[:run.after_progressive["n_trace"]]
     maps = [e for e in tr if e[0] == "map"]
     tracks = [e for e in tr if e[0] == "track"]
     dens = [e for e in tr if e[0] == "densify"]
@@ -46,7 +53,7 @@ def test_runner_reproduces_the_cpu_oracle_trajectory():
     assert [[e[1], e[2]] for e in tracks] == fx["track_frame_iter"].tolist()
     # cloud size after densify_and_prune: EXACT (same clone / split / prune decisions from the accumulated statistics)
     assert [[e[1], e[2]] for e in dens] == fx["densify"].tolist(), (dens, fx["densify"].tolist())
-    assert run.pc.num_points == int(fx["final_P"])
+    assert run.after_progressive["final_P"] == int(fx["final_P"])
     # per-iteration losses.  Before the densification the two runs differ by fp32 rounding only (measured 1.3e-5); Adam
     # (eps 1e-15) turns a rounding-sized gradient difference on a parameter the image does not depend on (the quaternion
     # of an isotropic Gaussian) into a full-size step of that parameter, which the loss does not see.  AFTER the
@@ -66,9 +73,22 @@ def test_runner_reproduces_the_cpu_oracle_trajectory():
     np.testing.assert_allclose(got_trk[first_post:], fx["track_loss"][first_post:], rtol=ref_harness.POST_DENSIFY_RTOL, atol=1e-6)
     # the poses of all three frames after the run (quaternion r, translation t): each took 5 Adam steps of 5e-3 .. 6e-4
     # (lr 0.01 halved at 0, 1, 2, 3, 4 -- MultiStepLR(range(0, 5, 1))); 3e-5 is half a percent of one step
-    np.testing.assert_allclose(run.poses.r.detach().cpu().numpy(), fx["pose_r"], atol=3e-5)
-    np.testing.assert_allclose(run.poses.t.detach().cpu().numpy(), fx["pose_t"], atol=3e-5)
-    np.testing.assert_allclose(run.pc.params["_xyz"].detach().mean(0).cpu().numpy(), fx["final_xyz_mean"], atol=5e-5)
+    np.testing.assert_allclose(run.after_progressive["pose_r"], fx["pose_r"], atol=3e-5)
+    np.testing.assert_allclose(run.after_progressive["pose_t"], fx["pose_t"], atol=3e-5)
+    np.testing.assert_allclose(run.after_progressive["final_xyz_mean"], fx["final_xyz_mean"], atol=5e-5)
+    # ---- the global phase behind it (train.py:378-443; Runner.global_run against CpuHarness.global_run): a fresh Adam with
+    # default eps, the SH degree raised at its iteration 0, the xyz learning rate of the iteration, a random TRAINING frame per
+    # iteration (same draws in the same order although Runner draws one iteration ahead), one one-view mapping iteration each
+    # -- the first of them densifies (counter 16) --, the poses untouched
+    gl = run.trace[run.after_progressive["n_trace"]:]
+    gmaps = [e for e in gl if e[0] == "map"]
+    assert [e[1] for e in gmaps] == fx["global_map_iter"].tolist()
+    assert [e[2][0] for e in gmaps] == fx["global_map_view"].tolist()
+    assert [[e[1], e[2]] for e in gl if e[0] == "densify"] == fx["global_densify"].tolist()
+    assert run.pc.num_points == int(fx["global_final_P"]) and run.pc.active_sh_degree == int(fx["global_sh_degree"]) == 1
+    np.testing.assert_allclose(np.array([e[3] for e in gmaps]), fx["global_map_loss"], rtol=ref_harness.POST_DENSIFY_RTOL)
+    np.testing.assert_allclose(run.pc.params["_xyz"].detach().mean(0).cpu().numpy(), fx["global_final_xyz_mean"], atol=5e-5)
+    assert np.array_equal(run.poses.t.detach().cpu().numpy(), run.after_progressive["pose_t"])
 
 
 def test_autograd_harness_route_reproduces_it_too():
