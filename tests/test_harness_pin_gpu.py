@@ -35,6 +35,7 @@ def _run_gpu(fx, fused=True, with_global=False):
                                      pose_t=run.poses.t.detach().cpu().numpy().copy(), final_P=run.pc.num_points,
                                      final_xyz_mean=run.pc.params["_xyz"].detach().mean(0).cpu().numpy().copy())
         if with_global:
+            run.densify_until = run.iteration + 1  # (as the fixture: no second densification inside the pinned global iterations)
             run.global_run(pin["global_iters"], eval_every=0)
             torch.cuda.synchronize()
     return run
@@ -78,8 +79,8 @@ def test_runner_reproduces_the_cpu_oracle_trajectory():
     np.testing.assert_allclose(run.after_progressive["final_xyz_mean"], fx["final_xyz_mean"], atol=5e-5)
     # ---- the global phase behind it (train.py:378-443; Runner.global_run against CpuHarness.global_run): a fresh Adam with
     # default eps, the SH degree raised at its iteration 0, the xyz learning rate of the iteration, a random TRAINING frame per
-    # iteration (same draws in the same order although Runner draws one iteration ahead), one one-view mapping iteration each
-    # -- the first of them densifies (counter 16) --, the poses untouched
+    # iteration (same draws in the same order although Runner draws one iteration ahead), one one-view mapping iteration each,
+    # the poses untouched.  (No densification in here: see tests/golden/make_harness_golden.py.)
     gl = run.trace[run.after_progressive["n_trace"]:]
     gmaps = [e for e in gl if e[0] == "map"]
     assert [e[1] for e in gmaps] == fx["global_map_iter"].tolist()
