@@ -34,6 +34,10 @@ POST_DENSIFY_RTOL = 5e-4
 # against its own 1-thread fixture: 0.9e-4 .. 5.4e-4 over the thread counts tried, 6e-7 before the densification;
 # tests/test_harness_pin_cpu.py): the yardstick that says the number above is not a property of the HIP path
 REFERENCE_SELF_RTOL = 1e-3
+# The pinned GLOBAL iterations (Runner.global_run behind the progressive phase: a fresh Adam, i.e. zero moments for EVERY
+# Gaussian, not only for the children of a densification): 100 runs leave the fixture by up to 7.0e-4 in a per-iteration loss
+# (median of the per-run maximum 3.0e-4, 90th percentile 4.8e-4; profiles/r04_pin_global_deviation_100runs.txt).  1.5 x the worst.
+GLOBAL_PHASE_RTOL = 1.1e-3
 
 
 @contextlib.contextmanager
