@@ -86,7 +86,7 @@ def test_runner_reproduces_the_cpu_oracle_trajectory():
     assert [e[1] for e in gmaps] == fx["global_map_iter"].tolist()
     assert [e[2][0] for e in gmaps] == fx["global_map_view"].tolist()
     assert [[e[1], e[2]] for e in gl if e[0] == "densify"] == fx["global_densify"].tolist()
-    assert run.pc.num_points == int(fx["global_final_P"]) and run.pc.active_sh_degree == int(fx["global_sh_degree"]) == 1
+    assert run.pc.num_points == int(fx["global_final_P"]) and run.pc.active_sh_degree == int(fx["global_sh_degree"]) == 2  # (raised at frame 0 and at global iteration 0)
     np.testing.assert_allclose(np.array([e[3] for e in gmaps]), fx["global_map_loss"], rtol=ref_harness.GLOBAL_PHASE_RTOL)
     np.testing.assert_allclose(run.pc.params["_xyz"].detach().mean(0).cpu().numpy(), fx["global_final_xyz_mean"], atol=5e-5)
     assert np.array_equal(run.poses.t.detach().cpu().numpy(), run.after_progressive["pose_t"])
