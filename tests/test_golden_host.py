@@ -538,3 +538,55 @@ def test_covariance_matches_the_reference_and_the_oracle_follows_it(oracle32):
     # the reference normalises inside build_rotation: raw and normalised quaternions give the same Sigma there
     q = g["rotation_raw"].astype(np.float64)
     assert np.allclose(q / np.linalg.norm(q, axis=1, keepdims=True), g["rotation_normalised"], atol=1e-6)
+
+
+def test_pose_lr_table_is_the_multisteplr_sequence_of_the_reference():
+    """PoseTrack.begin_frame replays the learning rates of Adam(lr .01) + MultiStepLR(milestones 0, s, 2s, ..; gamma .5) from a
+    table recorded once (scene/pose_optimizer.py:489-496): the table must be what a freshly built pair shows at construction
+    and after every scheduler.step() -- for the reference's 50 iterations and for the pinned test's 5."""
+    import warnings
+
+    from fsgs_amd.trainer import PoseTrack
+
+    for n_it in (50, 5, 30):
+        table = PoseTrack._lr_table(n_it)
+        p = PoseTrack(2, "cpu")
+        p.initialize_tracking_optimizer(n_it)  # the reference's construction, on torch.optim.Adam here (CPU)
+        seq = [tuple(float(g["lr"]) for g in p.optimizer.param_groups)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(n_it):
+                p.scheduler.step()
+                seq.append(tuple(float(g["lr"]) for g in p.optimizer.param_groups))
+        assert table[:n_it + 1] == seq, n_it
+        # milestone 0 halves the rate at construction: the first iteration already runs at 0.005 (train.py:189,194)
+        assert table[0] == (0.005, 0.005)
+    sch = PoseTrack._TableScheduler(torch.optim.SGD([{"params": [torch.zeros(1, requires_grad=True)], "lr": 1.0},
+                                                     {"params": [torch.zeros(1, requires_grad=True)], "lr": 1.0}], lr=1.0),
+                                    PoseTrack._lr_table(5))
+    lrs = [sch.optimizer.param_groups[0]["lr"]]
+    for _ in range(7):  # past the end of the table: the last rate stays
+        sch.step()
+        lrs.append(sch.optimizer.param_groups[0]["lr"])
+    assert lrs[-1] == lrs[5] and lrs[0] == 0.005
+    sch.rewind()
+    assert sch.optimizer.param_groups[1]["lr"] == 0.005 and sch.pos == 0
+
+
+def test_comm_model_of_the_bench_line():
+    """bench.comm_model (the prediction a scaling record is held against, DESIGN s6): same wire term for both routes, the
+    ring pays 2 (N - 1) dependent hops, the direct form two launches; efficiency falls with the exchange time."""
+    import bench
+
+    nbytes = 300_000 * 14 * 4
+    prev = None
+    for n in (2, 4, 8):
+        m = bench.comm_model(nbytes, n)
+        wire = 2.0 * (n - 1) / n * nbytes / ((n - 1) * 64e9) * 1e3
+        assert abs(m["wire_ms"] - wire) < 1e-12 and m["rccl_ms"] > wire and m["direct_ms"] > wire
+        assert abs((m["rccl_ms"] - m["wire_ms"]) - (0.020 + 2 * (n - 1) * 0.005)) < 1e-12
+        assert 0.5 < m["weak_scaling_efficiency"] < 1.0
+        if prev is not None:
+            assert m["wire_ms"] < prev["wire_ms"] and m["weak_scaling_efficiency"] > prev["weak_scaling_efficiency"]
+        prev = m
+    assert bench.comm_model(nbytes, 8)["direct_ms"] < bench.comm_model(nbytes, 8)["rccl_ms"]  # 14 hops against 2
