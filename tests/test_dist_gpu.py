@@ -23,12 +23,12 @@ def _free_port():
     return p
 
 
-def _world(dev):
+def _world(dev, n=2):
     from fsgs_amd import synth
     from fsgs_amd.model import GaussianCloud
     from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
 
-    W, H, P, n = 320, 256, 4000, 2
+    W, H, P = 320, 256, 4000
     cam = synth.make_camera(W, H)
     sc = synth.trained_like_scene(W, H, P, seed=0)
     pc = GaussianCloud(sc, sh_degree=3, device=dev)
@@ -37,6 +37,9 @@ def _world(dev):
     pc.training_setup()
     poses = PoseTrack(n, dev)
     poses.set_pose(1, q=synth.PERTURBED_POSE["q"], t=synth.PERTURBED_POSE["t"])
+    rng = np.random.default_rng(7)
+    for i in range(2, n):  # (world 8: one camera per rank)
+        poses.set_pose(i, q=np.array([1.0, 0, 0, 0]) + 0.01 * rng.standard_normal(4), t=0.02 * rng.standard_normal(3))
     g = torch.Generator().manual_seed(0)
     colors = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(n)]
     monos = [(torch.rand(H, W, generator=g) + 0.5).to(dev) for _ in range(n)]
@@ -59,7 +62,7 @@ def _worker(rank, world, port, out_dir, mode):
     dev = "cuda:0"
     torch.cuda.set_device(0)
     fdist.init_from_env(backend="gloo")
-    pc, poses, frames, (H, W) = _world(dev)
+    pc, poses, frames, (H, W) = _world(dev, n=max(2, world))
     cr = _corners(H, W, dev)
     fs = FastStepper(pc, poses, frames)
     if mode == "bucket":
@@ -107,6 +110,33 @@ def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
         ref = pc.params[k].detach().cpu()
         # Adam divides by sqrt(v): elements whose gradient is rounding noise can move by lr either way
         frac_off = ((a[k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
+        assert frac_off < 2e-3, (k, frac_off)
+
+
+@pytest.mark.parametrize("mode", ["compact", "direct", "producer"])
+def test_eight_ranks_on_the_one_gpu_match_the_eight_view_step(tmp_path, mode):
+    """The world size of configuration C3 (8 ranks, one camera each) with the HIP step driver: eight processes on the one
+    test GPU over gloo.  Replicas bit-identical after two steps for the one-collective, the direct (shards padded for 8) and
+    the producer-pipelined exchange, and equal to ONE process taking the same eight views in a step (summed loss, one Adam
+    step: the reference's two-view rule extended to N, DESIGN s6) up to the order of the float atomics."""
+    from fsgs_amd.fast_step import FastStepper
+    from fsgs_amd.model import PARAM_NAMES
+
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
+    for r in ranks[1:]:
+        for k in PARAM_NAMES:
+            assert torch.equal(ranks[0][k], r[k]), k
+    pc, poses, frames, (H, W) = _world("cuda:0", n=world)
+    cr = _corners(H, W, "cuda:0")
+    fs = FastStepper(pc, poses, frames)
+    for step in range(2):
+        total = fs.mapping_step(list(range(world)), corners=cr)
+    assert abs(sum(float(r["loss"]) for r in ranks) - total.item()) <= 1e-5 * abs(total.item())
+    for k in PARAM_NAMES:
+        ref = pc.params[k].detach().cpu()
+        frac_off = ((ranks[0][k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
         assert frac_off < 2e-3, (k, frac_off)
 
 
