@@ -964,8 +964,10 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                      grads->rotation, grads->means2D, grads->w2c, compact};
   if (row_hi > row_lo) {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
+    // (diagnostics flavour only: unused dynamic LDS = fewer resident workgroups, the occupancy experiment of DESIGN s3 round 4)
+    static const int dbg_lds = diag_env("FSGS_DBG_LDS_PRE_BWD") ? atoi(diag_env("FSGS_DBG_LDS_PRE_BWD")) : 0;
     if (adam)
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_ADAM>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), dbg_lds, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
     else if (compact)
