@@ -37,6 +37,11 @@ CONFIGS = {
     "C2": (1280, 1024, 300_000, "trained"),
     "C4": (1920, 1080, 1_000_000, "trained"),
     "C4x4": (1920, 1080, 4_000_000, "trained"),  # size stress only (tests); not a BASELINE.json configuration
+    # tile-grid sizes between C1 and C2, to place the crossover of the two blend-kernel flavours (scripts/gpu_blend_variants.sh);
+    # not BASELINE.json configurations
+    "X1": (832, 640, 60_000, "trained"),    # 2080 tiles
+    "X2": (960, 768, 120_000, "trained"),   # 2880 tiles
+    "X3": (1088, 896, 200_000, "trained"),  # 3808 tiles
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_SIMDS, VALU_CYCLES_PER_WAVE_INST, VALU_CLOCK_HZ = 1024, 2.0, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md

@@ -777,23 +777,66 @@ __device__ __forceinline__ void diag_flush(unsigned long long *out, const DiagLa
 }
 #endif
 
+// The ONE per-(pixel, Gaussian) forward blend step, shared by every flavour of the forward blend (one wave
+// per tile, four waves per tile, diagnostics): returns whether the lane blended the Gaussian into its pixel.
+// T > 0: transmittance of a pixel that is still blending; a FINISHED pixel keeps its transmittance with the sign flipped.
+template <int CP, bool WITH_DEPTH>
+__device__ __forceinline__ bool blend_fwd_pixel(float &T, float &D, float2v (&acc)[CP], uint32_t &last, float dx, float dy,
+                                                float bA, float bB, float bC, float bo, float bz,
+                                                const float2v (&bcol2)[4], uint32_t pos) {
+  if (!(T > 0.f)) return false;  // finished
+  SplatEval e;
+  if (!splat_alpha(dx, dy, bA, bB, bC, bo, e)) return false;
+  const float test_T = T * (1.0f - e.alpha);
+  if (test_T < 0.0001f) {
+    T = -T;
+    return false;
+  }
+  const float w = e.alpha * T;
+#pragma unroll
+  for (int cp = 0; cp < CP; cp++) acc[cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[cp]);
+  if (WITH_DEPTH) D = fmaf(bz, w, D);
+  T = test_T;
+  last = pos;
+  return true;
+}
+
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
-template <int C, bool WITH_DEPTH>
+// DIAG (diagnostics flavour of the library only, `FSGS_DIAG=1 python free-surgs_amd/build.py`): the SAME instruction stream
+// plus wave-uniform counters / time stamps behind `if constexpr (DIAG)`; the product library instantiates DIAG = false only.
+template <bool DIAG>
+struct DiagPtrs {};
+template <>
+struct DiagPtrs<true> {
+  unsigned long long *times;  // FSGS_DBG_TILE_TIMES*: 4 u64 per workgroup (start, end, pairs << 32 | bodies, list << 32 | walked)
+  unsigned long long *lanes;  // FSGS_DBG_LANES*: 32 u64 lane-utilisation counters (diag_flush)
+};
+#ifdef FSGS_DIAG_HOOKS
+constexpr bool kDiagBuild = true;
+#else
+constexpr bool kDiagBuild = false;
+#endif
+
+template <int C, bool WITH_DEPTH, bool DIAG = false>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
     uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
-    float *__restrict__ out_depth, unsigned long long *__restrict__ dbg_times,
-    unsigned long long *__restrict__ dbg_lanes = nullptr) {
-  // dbg_times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only; NULL otherwise):
+    float *__restrict__ out_depth, DiagPtrs<DIAG> dbg) {
+  // dbg.times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only):
   // 100 MHz wall-clock stamps of this wave's start and end, to measure load balance and the kernel's tail
-  const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;
-#ifdef FSGS_DIAG_HOOKS
+  unsigned long long dbg_t0 = 0ull;
   uint32_t dbg_bodies = 0, dbg_pairs = 0;  // quadrant bodies executed / pairs not skipped altogether (scalar counters)
+#ifdef FSGS_DIAG_HOOKS
   DiagLanes dl{};
   __shared__ uint32_t dbg_hist[9];
-  if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+  if constexpr (DIAG) {
+    if (dbg.times) dbg_t0 = wall_clock64();
+    if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+  }
+#else
+  static_assert(!DIAG, "the diagnostics flavour needs FSGS_DIAG_HOOKS");
 #endif
   // one 64-lane workgroup per tile: the dispatcher refills a SIMD slot as soon as ONE tile is done
   constexpr int REC4 = C > 4 ? 4 : 3;  // float4s per staged record
@@ -844,8 +887,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    uint32_t gmask16 = 0;
 #ifdef FSGS_DIAG_HOOKS
-    const uint32_t gmask16 = dbg_lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+    if constexpr (DIAG) gmask16 = dbg.lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
 #endif
     // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
     // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
@@ -867,80 +911,56 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t bm = readlane(gmask, j) & alive;  // scalar
       if (bm == 0) continue;
-#ifdef FSGS_DIAG_HOOKS
-      dbg_bodies += (uint32_t)__popc(bm);
-      dbg_pairs += 1;
-#endif
+      if constexpr (DIAG) {
+        dbg_bodies += (uint32_t)__popc(bm);
+        dbg_pairs += 1;
+      }
       const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y, bz = r1.z;
       const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
       const uint32_t pos = (uint32_t)(base + j - rg.x + 1);
       const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
-#ifdef FSGS_DIAG_HOOKS
       uint32_t dbg_m16 = 0;
-#endif
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (!((bm >> k) & 1u)) continue;  // wave-uniform
+        const bool contributed = blend_fwd_pixel<CP, WITH_DEPTH>(T[k], D[k], acc[k], last[k], quad_offset(dx0, k & 1),
+                                                                 quad_offset(dy0, k >> 1), bA, bB, bC, bo, bz, bcol2, pos);
 #ifdef FSGS_DIAG_HOOKS
-        bool dbg_c = false;  // (the product body below, its per-lane `continue`s written as `break`s of a one-trip loop)
-        do {
-          if (!(T[k] > 0.f)) break;
-          SplatEval e;
-          if (!splat_alpha(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, e)) break;
-          float test_T = T[k] * (1.0f - e.alpha);
-          if (test_T < 0.0001f) {
-            T[k] = -T[k];
-            break;
+        if constexpr (DIAG) {
+          if (dbg.lanes) {
+            const unsigned long long bal = __ballot(contributed);
+            const int cnt = __popcll(bal);
+            dl.lanes += (uint32_t)cnt;
+            if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
+            dbg_m16 |= diag_block_bits(bal) << (4 * k);
           }
-          float w = e.alpha * T[k];
-#pragma unroll
-          for (int cp = 0; cp < CP; cp++) acc[k][cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[k][cp]);
-          if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
-          T[k] = test_T;
-          last[k] = pos;
-          dbg_c = true;
-        } while (false);
-        if (dbg_lanes) {
-          const unsigned long long bal = __ballot(dbg_c);
-          const int cnt = __popcll(bal);
-          dl.lanes += (uint32_t)cnt;
-          if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
-          dbg_m16 |= diag_block_bits(bal) << (4 * k);
         }
 #else
-        if (!(T[k] > 0.f)) continue;  // finished
-        SplatEval e;
-        if (!splat_alpha(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, e)) continue;
-        float test_T = T[k] * (1.0f - e.alpha);
-        if (test_T < 0.0001f) {
-          T[k] = -T[k];
-          continue;
-        }
-        float w = e.alpha * T[k];
-#pragma unroll
-        for (int cp = 0; cp < CP; cp++) acc[k][cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[k][cp]);
-        if (WITH_DEPTH) D[k] = fmaf(bz, w, D[k]);
-        T[k] = test_T;
-        last[k] = pos;
+        (void)contributed;
 #endif
       }
 #ifdef FSGS_DIAG_HOOKS
-      if (dbg_lanes) {
-        uint32_t qsel = 0;  // the 4-bit groups of the quadrants this pair executed
-        for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
-        const uint32_t r16 = readlane(gmask16, j) & qsel;
-        const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
-        dl.pairs += 1; dl.bodies += nb;
-        dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
-        dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
-        dl.pairs_gain += pr < nb ? 1u : 0u;
+      if constexpr (DIAG) {
+        if (dbg.lanes) {
+          uint32_t qsel = 0;  // the 4-bit groups of the quadrants this pair executed
+          for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
+          const uint32_t r16 = readlane(gmask16, j) & qsel;
+          const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
+          dl.pairs += 1; dl.bodies += nb;
+          dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
+          dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
+          dl.pairs_gain += pr < nb ? 1u : 0u;
+        }
       }
 #endif
+      (void)dbg_m16; (void)gmask16;
     }
   }
 #ifdef FSGS_DIAG_HOOKS
-  __syncthreads();
-  diag_flush(dbg_lanes, dl, dbg_hist, lane);
+  if constexpr (DIAG) {
+    __syncthreads();
+    diag_flush(dbg.lanes, dl, dbg_hist, lane);
+  }
 #endif
   const size_t HW = (size_t)H * W;
 #pragma unroll
@@ -959,16 +979,118 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
       if (WITH_DEPTH) out_depth[pix] = D[k];
     }
   }
-  if (dbg_times && lane == 0) {
-    dbg_times[4 * blockIdx.x + 0] = dbg_t0;
-    dbg_times[4 * blockIdx.x + 1] = wall_clock64();
 #ifdef FSGS_DIAG_HOOKS
-    dbg_times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
-#else
-    dbg_times[4 * blockIdx.x + 2] = 0;
+  if constexpr (DIAG) {
+    if (dbg.times && lane == 0) {
+      dbg.times[4 * blockIdx.x + 0] = dbg_t0;
+      dbg.times[4 * blockIdx.x + 1] = wall_clock64();
+      dbg.times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+      dbg.times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
+                                      max(max(last[0], last[1]), max(last[2], last[3]));
+    }
+  }
 #endif
-    dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
-                                    max(max(last[0], last[1]), max(last[2], last[3]));
+  (void)dbg_t0; (void)dbg_bodies; (void)dbg_pairs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R6 for SMALL tile grids: four waves per tile (FSGS_FLAG_BLEND_QUAD_WAVES / auto below kQuadWavesMaxTiles)
+// ------------------------------------------------------------------------------------------------
+// One wave per tile leaves the chip idle when the grid is small: C1 (640x512) has 1280 tiles for 1024 SIMDs with 5-6 wave
+// slots each, and the kernel lasts as long as its LONGEST list walked by ONE wave doing ~2.2 quadrant bodies per pair
+// (profiles/r04_bench_C1.json: 0.6 - 1.0 ns per pair against 0.14 - 0.24 at C2).  Here a tile is a 256-thread workgroup:
+//   * wave q owns quadrant q with ONE pixel per lane (same pixel <-> lane map as the one-wave kernel's quadrant q, and the
+//     same arithmetic through blend_fwd_pixel / quad_offset: the two flavours' outputs are bit-identical);
+//   * a batch is 256 records, thread t gathers and stages record t ONCE for all four waves, its 4-bit quadrant mask beside it;
+//   * a wave ballots bit q of the masks of 64 records at a time and walks only the SET bits (s_ff1): a pair that cannot reach
+//     its quadrant costs it nothing -- not even the broadcast reads;
+//   * a wave whose quadrant is finished keeps gathering / staging for the others; the workgroup stops when all four are.
+// Per pair this is MORE issue slots than the one-wave kernel on a full chip (each wave pays its own loop and record reads),
+// which is why the big grids keep the one-wave kernel: launch_blend_fwd picks by the number of tiles.
+constexpr int QW_BATCH = 256;
+template <int C, bool WITH_DEPTH>
+__global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
+    CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
+    const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
+    uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, float *__restrict__ out_color2,
+    float *__restrict__ out_depth) {
+  constexpr int REC4 = C > 4 ? 4 : 3;
+  constexpr int CP = (C + 1) / 2;
+  __shared__ float4 rec[QW_BATCH * REC4];
+  __shared__ uint32_t reach[QW_BATCH];  // 4-bit quadrant masks of the staged records (0 beyond the batch's end)
+  __shared__ uint32_t wave_alive[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's quadrant (scalar)
+  const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile_u >= (uint32_t)ntiles) return;
+  const int tile = (int)tile_u;
+  const int W = cam.W, H = cam.H;
+  const int x0 = (tile % cam.gx) * FSGS_TILE + (lane & 7), y0 = (tile / cam.gx) * FSGS_TILE + (lane >> 3);
+  const int x = x0 + FSGS_QUAD * (q & 1), y = y0 + FSGS_QUAD * (q >> 1);
+  const float px0 = (float)x0, py0 = (float)y0;  // the lane's pixel in quadrant 0, as in the one-wave kernel
+  const bool inside = x < W && y < H;
+  float T = inside ? 1.0f : -1.0f, D = 0.0f;
+  float2v acc[CP];
+  uint32_t last = 0;
+#pragma unroll
+  for (int cp = 0; cp < CP; cp++) acc[cp] = float2v{0.0f, 0.0f};
+  const int2 rg = ranges[tile];
+  for (int base = rg.x; base < rg.y; base += QW_BATCH) {
+    const bool my_alive = __ballot(T > 0.f) != 0ull;
+    if (lane == 0) wave_alive[q] = my_alive ? 1u : 0u;
+    const int n = min(QW_BATCH, rg.y - base);
+    const uint32_t g = plist[base + (tid < n ? tid : 0)];
+    const float4 *rp = grec + (size_t)g * kRecF4;
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    const float4 q3 = C > 4 ? rp[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 gxy = make_float2(q0.x, q0.y);
+    const float4 gco = make_float4(q0.z, q0.w, q1.x, q1.y);
+    const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    __syncthreads();  // the previous batch is consumed; the four alive flags are in place
+    if ((wave_alive[0] | wave_alive[1] | wave_alive[2] | wave_alive[3]) == 0u) break;  // uniform over the workgroup
+    const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
+    rec[tid * REC4 + 0] = make_float4(gxy.x, gxy.y, kf.a, kf.b);
+    rec[tid * REC4 + 1] = make_float4(kf.c, gco.w, WITH_DEPTH ? q1.z : 0.f, 0.f);
+    {
+      const float g8[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      float c6[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ch++) c6[ch] = ch < C ? g8[ch] : 0.f;
+      rec[tid * REC4 + 2] = make_float4(c6[0], c6[1], c6[2], c6[3]);
+      if (C > 4) rec[tid * REC4 + 3] = make_float4(c6[4], c6[5], c6[6], c6[7]);
+    }
+    reach[tid] = tid < n ? gmask : 0u;
+    __syncthreads();
+    if (my_alive) {
+      const int nsub = (n + 63) >> 6;
+      for (int sub = 0; sub < nsub; sub++) {
+        unsigned long long bits = __ballot(((reach[sub * 64 + lane] >> q) & 1u) != 0u);
+        while (bits) {
+          const int j = sub * 64 + (int)__builtin_ctzll(bits);  // scalar
+          bits &= bits - 1ull;
+          const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
+          const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
+          const float dx0 = __fsub_rn(r0.x, px0), dy0 = __fsub_rn(r0.y, py0);
+          blend_fwd_pixel<CP, WITH_DEPTH>(T, D, acc, last, quad_offset(dx0, q & 1), quad_offset(dy0, q >> 1), r0.z, r0.w,
+                                          r1.x, r1.y, r1.z, bcol2, (uint32_t)(base + j - rg.x + 1));
+        }
+        if (__ballot(T > 0.f) == 0ull) break;  // the quadrant finished inside this batch
+      }
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
+    const float Tf = fabsf(T);
+    final_T[pix] = Tf;
+    n_contrib[pix] = last;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+      const float v = fmaf(Tf, cam.bg[ch], acc[ch >> 1][ch & 1]);
+      if (ch < 3) out_color[ch * HW + pix] = v;
+      else out_color2[(ch - 3) * HW + pix] = v;
+    }
+    if (WITH_DEPTH) out_depth[pix] = D;
   }
 }
 
@@ -1010,7 +1132,85 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
 // and depth^2 planes: CGRAD = 4 drops their two FMAs in the colour dot product and their two dcolour sums).
 // ROW: floats per accumulator row when moments and colour sums share one row per Gaussian (kFusedRow, the fused
 // render); 0 = the operator boundary's layout (moments [P,8] in scratch, colour sums straight into dcolors [P,C]).
-template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
+// The ONE per-(pixel, Gaussian) backward blend step, shared by every flavour of the backward blend: replays the pixel's
+// transmittance backwards and adds the lane's terms of the Gaussian's SL gradient slots into s[].  Branch-free: a lane that
+// does not contribute runs it with alpha = a = 0 (splat_alpha_masked).  Returns whether the lane contributed.
+//   T: transmittance in front of the Gaussians replayed so far; gB (gBr): the running colour-behind sums (all / RGB channels)
+template <int CG, bool SPLIT, bool POSE_ONLY>
+__device__ __forceinline__ bool blend_bwd_pixel(float *s, float &T, float &gB, float &gBr, const float (&g)[CG], float dx,
+                                                float dy, float bA, float bB, float bC, float bo, const float (&bcol)[6],
+                                                bool live) {
+  SplatEval e;  // alpha = G = 0 for lanes that do not contribute: the arithmetic below is a no-op for them
+  const bool contributed = splat_alpha_masked(dx, dy, bA, bB, bC, bo, live, e);
+  const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
+  T = T * inv1ma;
+  const float wgt = e.alpha * T;
+  float gc = 0.0f, gc_rgb = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < CG; ch++) {
+    gc = fmaf(g[ch], bcol[ch], gc);
+    if (SPLIT && ch == 2) gc_rgb = gc;
+    if (!POSE_ONLY) s[8 + ch] = fmaf(wgt, g[ch], s[8 + ch]);
+  }
+  const float dL_dalpha = fmaf(T, gc, -inv1ma * gB);
+  gB = fmaf(wgt, gc, gB);
+  // moments of w = o G dL/dalpha over the pixels; the conic / opacity factors are per-Gaussian constants
+  // and are applied once, after the tile and atomic sums, by unpack_moments()
+  const float w = e.a * dL_dalpha;
+  const float wdx = w * e.dx, wdy = w * e.dy;
+  if (!POSE_ONLY) s[5] += w;
+  s[0] += wdx;
+  s[1] += wdy;
+  s[2] = fmaf(wdx, e.dx, s[2]);
+  s[3] = fmaf(wdx, e.dy, s[3]);
+  s[4] = fmaf(wdy, e.dy, s[4]);
+  if (SPLIT) {
+    const float wr = e.a * fmaf(T, gc_rgb, -inv1ma * gBr);
+    gBr = fmaf(wgt, gc_rgb, gBr);
+    s[6] = fmaf(wr, e.dx, s[6]);
+    s[7] = fmaf(wr, e.dy, s[7]);
+  }
+  return contributed;
+}
+
+// Slot bookkeeping of the transposing reductions, shared by the flavours of the backward blend.
+//   gradient component slots of one Gaussian (SL per Gaussian, GP = 2 Gaussians per transposing reduction):
+//   0..4 moments of w (mean2D x,y | conic A,B,C) | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
+//   POSE_ONLY: the five moments only
+// after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
+// (the 12-of-16 reduction folds the cheap lane bits first and leaves its totals in another lane order: transpose12_slot)
+template <bool SPLIT, bool POSE_ONLY, int CG>
+struct BwdSlots {
+  static constexpr int GP = 2;                   // Gaussians per transposing reduction
+  static constexpr int SL = POSE_ONLY ? 8 : 16;  // slots per Gaussian
+  static constexpr int NV = GP * SL;             // values per lane entering the reduction
+  static constexpr int REP = 64 / NV;            // lanes that end up with the same total
+  static constexpr bool CHEAP_FIRST = !POSE_ONLY && CG <= 4;
+  // The cheap-first reductions leave the DPP banks of their UNUSED slots (12..15 of 16, 5..7 of 8) unwritten: those lanes
+  // hold undefined register contents, possibly NaN.  That is safe only while `used` below masks exactly those slots out
+  // of the atomics -- tie the slot map to the variants, so a change of SL / CG / GP cannot let garbage through
+  // (fsgs_selftest_transpose_reduce_n widths 3212 / 1605 check the used slots, tests/test_raster_gpu.py).
+  static_assert(GP == 2, "both cheap-first reductions transpose two Gaussians at a time");
+  static_assert(!CHEAP_FIRST || (SL == 16 && 8 + CG <= 12), "12-of-16 reduction: slots 12..15 must be unused");
+  static_assert(!POSE_ONLY || SL == 8, "5-of-8 reduction: slots 5..7 must be unused");
+  int u, c;   // the (Gaussian, component) this lane ends up owning
+  bool used;  // this lane issues the atomic of its slot (one lane of those that hold the same total, used slots only)
+  __device__ __forceinline__ explicit BwdSlots(int lane) {
+    const int slot = POSE_ONLY ? transpose5_slot(lane) : CHEAP_FIRST ? transpose12_slot(lane) : lane / REP;
+    u = slot / SL;
+    c = slot % SL;
+    const bool owner = POSE_ONLY ? !(lane & 0x21) : !(lane & (REP - 1));
+    used = owner && (POSE_ONLY ? c < 5 : (c < 6 || (SPLIT && c < 8) || (c >= 8 && c < 8 + CG)));
+  }
+  static __device__ __forceinline__ float reduce(const float (&v)[NV], int lane) {
+    // 64 x NV transposing reduction: lanes (u, c) receive the wave's total of component c of Gaussian u
+    if constexpr (POSE_ONLY) return wave_transpose_reduce16_5of8_cheap_first(v, lane);  // slots 5..7 stay undefined
+    else if constexpr (CG <= 4) return wave_transpose_reduce32_12of16_cheap_first(v, lane);  // slots 12..15 stay undefined
+    else return wave_transpose_reduce32(v, lane);
+  }
+};
+
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, bool DIAG = false>
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
 #endif
@@ -1018,14 +1218,18 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
-    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16,
-    unsigned long long *__restrict__ dbg_times, unsigned long long *__restrict__ dbg_lanes = nullptr) {
-  const unsigned long long dbg_t0 = dbg_times ? wall_clock64() : 0ull;  // see blend_fwd_kernel
-#ifdef FSGS_DIAG_HOOKS
+    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16, DiagPtrs<DIAG> dbg) {
+  unsigned long long dbg_t0 = 0ull;  // see blend_fwd_kernel
   uint32_t dbg_bodies = 0, dbg_pairs = 0;
+#ifdef FSGS_DIAG_HOOKS
   DiagLanes dl{};
   __shared__ uint32_t dbg_hist[9];
-  if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+  if constexpr (DIAG) {
+    if (dbg.times) dbg_t0 = wall_clock64();
+    if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+  }
+#else
+  static_assert(!DIAG, "the diagnostics flavour needs FSGS_DIAG_HOOKS");
 #endif
   constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;  // compile-time: shifts, no 64-bit mads
   static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
@@ -1033,10 +1237,8 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) clear16[threadIdx.x] = 0.f;
   constexpr int REC4 = C > 4 ? 4 : 3;
   constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : CGRAD;  // channels that carry dL/dpixel
-  constexpr int GP = 2;                                // Gaussians per transposing reduction
-  constexpr int SL = POSE_ONLY ? 8 : 16;               // slots per Gaussian
-  constexpr int NV = GP * SL;                          // values per lane entering the reduction
-  constexpr int REP = 64 / NV;                         // lanes that end up with the same total
+  using Slots = BwdSlots<SPLIT, POSE_ONLY, CG>;
+  constexpr int GP = Slots::GP, SL = Slots::SL, NV = Slots::NV;
   __shared__ float4 rec[64 * REC4];
   const int lane = threadIdx.x;
   const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1078,25 +1280,9 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   const int2 rg = ranges[tile];
   int hi = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));  // nothing deeper matters to anyone in the tile
   const int dbg_walked = hi;
-  // gradient component slots of one Gaussian (SL per Gaussian, GP Gaussians per transposing reduction):
-  //   0..4 moments of w (mean2D x,y | conic A,B,C) | 5 opacity | 6,7 RGB-only mean2D (SPLIT) | 8..8+C colours
-  //   POSE_ONLY: the five moments only
-  // after the reduction REP neighbouring lanes own (Gaussian u = (l / REP) / SL, component c = (l / REP) % SL)
-  // (the 12-of-16 reduction folds the cheap lane bits first and leaves its totals in another lane order: transpose12_slot)
-  constexpr bool CHEAP_FIRST = !POSE_ONLY && CG <= 4;
-  // The cheap-first reductions leave the DPP banks of their UNUSED slots (12..15 of 16, 5..7 of 8) unwritten: those lanes
-  // hold undefined register contents, possibly NaN.  That is safe only while `c_used` below masks exactly those slots out
-  // of the atomics -- tie the slot map to the variants, so a change of SL / CG / GP cannot let garbage through
-  // (fsgs_selftest_transpose_reduce_n widths 3212 / 1605 check the used slots, tests/test_raster_gpu.py).
-  static_assert(GP == 2, "both cheap-first reductions transpose two Gaussians at a time");
-  static_assert(!CHEAP_FIRST || (SL == 16 && 8 + CG <= 12), "12-of-16 reduction: slots 12..15 must be unused");
-  static_assert(!POSE_ONLY || SL == 8, "5-of-8 reduction: slots 5..7 must be unused");
-  const int my_slot = POSE_ONLY ? transpose5_slot(lane) : CHEAP_FIRST ? transpose12_slot(lane) : lane / REP;
-  const int my_u = my_slot / SL, my_c = my_slot % SL;
-  // one lane of those that hold the same total issues the atomic
-  const bool owner = POSE_ONLY ? !(lane & 0x21) : !(lane & (REP - 1));
-  const bool c_used = owner && (POSE_ONLY ? my_c < 5
-                                                : (my_c < 6 || (SPLIT && my_c < 8) || (my_c >= 8 && my_c < 8 + CG)));
+  const Slots slots(lane);
+  const int my_u = slots.u, my_c = slots.c;
+  const bool c_used = slots.used;
   while (hi > 0) {
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
@@ -1111,8 +1297,9 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
 #pragma unroll
     for (int ch = 0; ch < C; ch++) gcol[ch] = g8[ch];
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    uint32_t gmask16 = 0;
 #ifdef FSGS_DIAG_HOOKS
-    const uint32_t gmask16 = dbg_lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+    if constexpr (DIAG) gmask16 = dbg.lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
 #endif
     __syncthreads();  // records of the previous batch fully consumed
     const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
@@ -1140,10 +1327,10 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         for (int k = 0; k < 4; k++)
           if (pos >= qlast[k]) bm &= ~(1u << k);  // ... and in which somebody blended it or something behind it
         if (bm == 0) continue;
-#ifdef FSGS_DIAG_HOOKS
-        dbg_bodies += (uint32_t)__popc(bm);
-        dbg_pairs += 1;
-#endif
+        if constexpr (DIAG) {
+          dbg_bodies += (uint32_t)__popc(bm);
+          dbg_pairs += 1;
+        }
         // broadcast reads of record j (same LDS address in every lane)
         const float4 r0 = rec[j * REC4 + 0], r1 = rec[j * REC4 + 1], r2 = rec[j * REC4 + 2];
         const float bx = r0.x, by = r0.y, bA = r0.z, bB = r0.w, bC = r1.x, bo = r1.y;
@@ -1151,75 +1338,45 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         float *s = &v[SL * u];
         bool any = false;
         const float dx0 = __fsub_rn(bx, px0), dy0 = __fsub_rn(by, py0);
-#ifdef FSGS_DIAG_HOOKS
         uint32_t dbg_m16 = 0;
-#endif
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (!((bm >> k) & 1u)) continue;  // wave-uniform
-          SplatEval e;  // alpha = G = 0 for lanes that do not contribute: the arithmetic below is a no-op for them
+          const bool contributed = blend_bwd_pixel<CG, SPLIT, POSE_ONLY>(s, T[k], gB[k], gBr[k], g[k], quad_offset(dx0, k & 1),
+                                                                         quad_offset(dy0, k >> 1), bA, bB, bC, bo, bcol,
+                                                                         pos < last[k]);
+          any |= contributed;
 #ifdef FSGS_DIAG_HOOKS
-          const bool dbg_c = splat_alpha_masked(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, pos < last[k], e);
-          any |= dbg_c;
-          if (dbg_lanes) {
-            const unsigned long long bal = __ballot(dbg_c);
-            const int cnt = __popcll(bal);
-            dl.lanes += (uint32_t)cnt;
-            if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
-            dbg_m16 |= diag_block_bits(bal) << (4 * k);
+          if constexpr (DIAG) {
+            if (dbg.lanes) {
+              const unsigned long long bal = __ballot(contributed);
+              const int cnt = __popcll(bal);
+              dl.lanes += (uint32_t)cnt;
+              if (lane == 0) dbg_hist[(cnt + 7) >> 3] += 1;
+              dbg_m16 |= diag_block_bits(bal) << (4 * k);
+            }
           }
-#else
-          any |= splat_alpha_masked(quad_offset(dx0, k & 1), quad_offset(dy0, k >> 1), bA, bB, bC, bo, pos < last[k], e);
 #endif
-          const float inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
-          T[k] = T[k] * inv1ma;
-          const float wgt = e.alpha * T[k];
-          float gc = 0.0f, gc_rgb = 0.0f;
-#pragma unroll
-          for (int ch = 0; ch < CG; ch++) {
-            gc = fmaf(g[k][ch], bcol[ch], gc);
-            if (SPLIT && ch == 2) gc_rgb = gc;
-            if (!POSE_ONLY) s[8 + ch] = fmaf(wgt, g[k][ch], s[8 + ch]);
-          }
-          const float dL_dalpha = fmaf(T[k], gc, -inv1ma * gB[k]);
-          gB[k] = fmaf(wgt, gc, gB[k]);
-          // moments of w = o G dL/dalpha over the pixels; the conic / opacity factors are per-Gaussian constants
-          // and are applied once, after the tile and atomic sums, by unpack_moments()
-          const float w = e.a * dL_dalpha;
-          const float wdx = w * e.dx, wdy = w * e.dy;
-          if (!POSE_ONLY) s[5] += w;
-          s[0] += wdx;
-          s[1] += wdy;
-          s[2] = fmaf(wdx, e.dx, s[2]);
-          s[3] = fmaf(wdx, e.dy, s[3]);
-          s[4] = fmaf(wdy, e.dy, s[4]);
-          if (SPLIT) {
-            const float wr = e.a * fmaf(T[k], gc_rgb, -inv1ma * gBr[k]);
-            gBr[k] = fmaf(wgt, gc_rgb, gBr[k]);
-            s[6] = fmaf(wr, e.dx, s[6]);
-            s[7] = fmaf(wr, e.dy, s[7]);
-          }
         }
         any_group = any_group || (__ballot(any) != 0ull);
 #ifdef FSGS_DIAG_HOOKS
-        if (dbg_lanes) {
-          uint32_t qsel = 0;
-          for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
-          const uint32_t r16 = readlane(gmask16, j) & qsel;
-          const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
-          dl.pairs += 1; dl.bodies += nb;
-          dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
-          dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
-          dl.pairs_gain += pr < nb ? 1u : 0u;
+        if constexpr (DIAG) {
+          if (dbg.lanes) {
+            uint32_t qsel = 0;
+            for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
+            const uint32_t r16 = readlane(gmask16, j) & qsel;
+            const uint32_t nb = (uint32_t)__popc(bm), pr = diag_packed(r16);
+            dl.pairs += 1; dl.bodies += nb;
+            dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
+            dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
+            dl.pairs_gain += pr < nb ? 1u : 0u;
+          }
         }
 #endif
+        (void)dbg_m16;
       }
       if (!any_group) continue;  // wave-uniform: none of the GP Gaussians touched any pixel of the tile
-      // 64 x NV transposing reduction: lanes (u, c) receive the tile total of component c of Gaussian jj-u
-      float tot;
-      if constexpr (POSE_ONLY) tot = wave_transpose_reduce16_5of8_cheap_first(v, lane);  // slots 5..7 stay zero
-      else if constexpr (CG <= 4) tot = wave_transpose_reduce32_12of16_cheap_first(v, lane);  // slots 12..15 stay zero
-      else tot = wave_transpose_reduce32(v, lane);
+      const float tot = Slots::reduce(v, lane);
       const int j_mine = jj - my_u;
       uint32_t gsel = readlane(gid, jj);
 #pragma unroll
@@ -1243,18 +1400,145 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     hi = lo;
   }
 #ifdef FSGS_DIAG_HOOKS
+  if constexpr (DIAG) {
+    __syncthreads();
+    diag_flush(dbg.lanes, dl, dbg_hist, lane);
+    if (dbg.times && lane == 0) {
+      dbg.times[4 * blockIdx.x + 0] = dbg_t0;
+      dbg.times[4 * blockIdx.x + 1] = wall_clock64();
+      dbg.times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+      dbg.times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
+    }
+  }
+#endif
+  (void)dbg_t0; (void)dbg_bodies; (void)dbg_pairs; (void)dbg_walked;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R7 for SMALL tile grids: four waves per tile (see blend_fwd_quad_kernel)
+// ------------------------------------------------------------------------------------------------
+// Wave q replays quadrant q (one pixel per lane) back to front over the records that reach it AND that somebody in it
+// blended or blended behind (bit q of the staged mask, pos < the quadrant's deepest contributor): two such records per
+// transposing reduction, exactly as the one-wave kernel pairs them, but every wave reduces and issues the atomics of ITS
+// quadrant's share of a Gaussian's sums (the one-wave kernel sums the four quadrants in registers first: ~2.2x fewer
+// reductions per pair -- the price of the parallelism, paid only on grids that cannot fill the chip otherwise).
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
+__global__ __launch_bounds__(256) void blend_bwd_quad_kernel(
+    CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
+    const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
+    float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16) {
+  constexpr uint32_t acc_stride = ROW ? ROW : kAccStride, col_stride = ROW ? ROW : C;
+  static_assert(!(SPLIT && POSE_ONLY), "the densification statistic is a mapping-only output");
+  if (clear16 && blockIdx.x == 0 && threadIdx.x < 16) clear16[threadIdx.x] = 0.f;
+  constexpr int CG = POSE_ONLY ? (C < 3 ? C : 3) : CGRAD;
+  using Slots = BwdSlots<SPLIT, POSE_ONLY, CG>;
+  constexpr int SL = Slots::SL, NV = Slots::NV;
+  __shared__ float4 rec[QW_BATCH * 3];
+  __shared__ uint32_t reach[QW_BATCH];
+  __shared__ uint32_t gids[QW_BATCH];
+  __shared__ int wave_last[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tile_u = order ? order[blockIdx.x] : (uint32_t)xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile_u >= (uint32_t)ntiles) return;
+  const int tile = (int)tile_u;
+  const int W = cam.W, H = cam.H;
+  const size_t HW = (size_t)H * W;
+  const int x0 = (tile % cam.gx) * FSGS_TILE + (lane & 7), y0 = (tile / cam.gx) * FSGS_TILE + (lane >> 3);
+  const int x = x0 + FSGS_QUAD * (q & 1), y = y0 + FSGS_QUAD * (q >> 1);
+  const float px0 = (float)x0, py0 = (float)y0;
+  const bool inside = x < W && y < H;
+  const size_t pix = inside ? (size_t)y * W + x : 0;
+  float T = inside ? final_T[pix] : 0.0f;
+  const int last = inside ? (int)n_contrib[pix] : 0;
+  const int qlast = wave_max(last);  // deepest contributor of this wave's quadrant (scalar)
+  float g[CG], gB, gBr;
+  {
+    float bgdot = 0.0f, bgdot_rgb = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < CG; ch++) {
+      const float *gp = ch < 3 ? dL_dcolor : dL_dcolor2;
+      g[ch] = (inside && gp) ? gp[(ch < 3 ? ch : ch - 3) * HW + pix] : 0.0f;
+      bgdot = fmaf(cam.bg[ch], g[ch], bgdot);
+      if (SPLIT && ch < 3) bgdot_rgb = fmaf(cam.bg[ch], g[ch], bgdot_rgb);
+    }
+    gB = T * bgdot;
+    gBr = T * bgdot_rgb;
+  }
+  if (lane == 0) wave_last[q] = qlast;
   __syncthreads();
-  diag_flush(dbg_lanes, dl, dbg_hist, lane);
-#endif
-  if (dbg_times && lane == 0) {
-    dbg_times[4 * blockIdx.x + 0] = dbg_t0;
-    dbg_times[4 * blockIdx.x + 1] = wall_clock64();
-#ifdef FSGS_DIAG_HOOKS
-    dbg_times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
-#else
-    dbg_times[4 * blockIdx.x + 2] = 0;
-#endif
-    dbg_times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
+  int hi = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));  // uniform over the workgroup
+  const int2 rg = ranges[tile];
+  const Slots slots(lane);
+  while (hi > 0) {
+    const int lo = max(0, hi - QW_BATCH);
+    const int n = hi - lo;
+    const uint32_t gid = plist[rg.x + lo + (tid < n ? tid : 0)];
+    const float4 *rp = grec + (size_t)gid * kRecF4;
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    const float4 q3 = C > 4 ? rp[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 gxy = make_float2(q0.x, q0.y);
+    const float4 gco = make_float4(q0.z, q0.w, q1.x, q1.y);
+    const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
+    __syncthreads();  // records of the previous batch fully consumed
+    const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
+    rec[tid * 3 + 0] = make_float4(gxy.x, gxy.y, kf.a, kf.b);
+    {
+      const float g8[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      float c6[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ch++) c6[ch] = ch < C ? g8[ch] : 0.f;
+      rec[tid * 3 + 1] = make_float4(kf.c, gco.w, c6[0], c6[1]);
+      rec[tid * 3 + 2] = make_float4(c6[2], c6[3], c6[4], c6[5]);
+    }
+    reach[tid] = tid < n ? gmask : 0u;
+    gids[tid] = gid;
+    __syncthreads();
+    if (qlast > lo) {  // wave-uniform: something in this batch matters to this quadrant
+      for (int sub = (n - 1) >> 6; sub >= 0; sub--) {
+        const int idx = sub * 64 + lane;
+        unsigned long long bits = __ballot(((reach[idx] >> q) & 1u) != 0u && lo + idx < qlast);
+        while (bits) {
+          // the two deepest records left: Gaussian u = 0 is replayed first (it lies behind u = 1)
+          const int j0 = sub * 64 + 63 - (int)__builtin_clzll(bits);
+          bits &= ~(1ull << (j0 & 63));
+          int j1 = -1;
+          if (bits) {
+            j1 = sub * 64 + 63 - (int)__builtin_clzll(bits);
+            bits &= ~(1ull << (j1 & 63));
+          }
+          float v[NV];
+#pragma unroll
+          for (int i = 0; i < NV; i++) v[i] = 0.f;
+          bool any = false;
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int j = u ? j1 : j0;
+            if (j < 0) continue;  // wave-uniform
+            const float4 r0 = rec[j * 3 + 0], r1 = rec[j * 3 + 1], r2 = rec[j * 3 + 2];
+            const float bcol[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const float dx0 = __fsub_rn(r0.x, px0), dy0 = __fsub_rn(r0.y, py0);
+            any |= blend_bwd_pixel<CG, SPLIT, POSE_ONLY>(&v[SL * u], T, gB, gBr, g, quad_offset(dx0, q & 1),
+                                                         quad_offset(dy0, q >> 1), r0.z, r0.w, r1.x, r1.y, bcol, lo + j < last);
+          }
+          if (__ballot(any) == 0ull) continue;  // wave-uniform: neither Gaussian touched a pixel of the quadrant
+          const float tot = Slots::reduce(v, lane);
+          const int j_mine = slots.u ? j1 : j0;
+          if (j_mine >= 0 && slots.used && tot != 0.f) {
+            const uint32_t gsel = gids[j_mine];
+            if constexpr (ROW != 0) {
+              atomicAdd(grad_acc + (gsel * (uint32_t)ROW + (uint32_t)slots.c), tot);
+            } else {
+              float *dst = (POSE_ONLY || slots.c < 8) ? grad_acc + (size_t)gsel * acc_stride + slots.c
+                                                      : dcolors + (size_t)gsel * col_stride + (slots.c - 8);
+              atomicAdd(dst, tot);
+            }
+          }
+        }
+      }
+    }
+    hi = lo;
   }
 }
 
@@ -1549,27 +1833,64 @@ inline int finish_binning(const CamParams &cam, FwdBuffers &B, int64_t max_pairs
   return FSGS_OK;
 }
 
+// Which flavour of the blend kernels a launch takes: one wave per tile or four waves per tile (blend_*_quad_kernel).
+// FsgsRasterCfg.flags can force either for both directions; otherwise, measured on MI355X (profiles/r05_blend_flavours.txt,
+// blend kernel us, one wave -> four waves, mapping step of bench.py):
+//     tiles    1280 (C1)   2080      2880      3808      5120 (C2)   8160 (C4)
+//     forward  81 -> 37    118 -> 50 128 -> 71 136 -> 88 162 -> 123  331 -> 286
+//     backward 98 -> 59    154 -> 90 178 -> 156 214 -> 201 257 -> 292 592 -> 699
+//   * forward: four waves everywhere -- a wave only ever walks the records that reach ITS quadrant and stops with it;
+//   * backward: four waves while one wave per tile cannot fill the chip (5 waves x 1024 SIMDs = 5120 one-wave workgroups);
+//     from there on the one-wave kernel's single transposing reduction per pair (instead of one per quadrant reached)
+//     is worth more than the parallelism.
+#ifndef FSGS_QUAD_BWD_MAX_TILES
+#define FSGS_QUAD_BWD_MAX_TILES 4096
+#endif
+inline bool use_quad_waves(const CamParams &cam, int ntiles, bool backward) {
+  if (cam.flags & FSGS_FLAG_BLEND_ONE_WAVE) return false;
+  if (cam.flags & FSGS_FLAG_BLEND_QUAD_WAVES) return true;
+  return backward ? ntiles <= FSGS_QUAD_BWD_MAX_TILES : true;
+}
+
+template <bool DIAG>
+inline DiagPtrs<DIAG> diag_ptrs(const char *times_var, const char *lanes_var) {
+  DiagPtrs<DIAG> d{};
+  if constexpr (DIAG) {
+    // load-balance experiments only: a device buffer of 4 * ntiles uint64 whose ADDRESS comes from the environment;
+    // lane-utilisation counters (scripts/lane_utilisation.py): 32 u64 on the device, summed over every launch
+    d.times = diag_env(times_var) ? (unsigned long long *)strtoull(diag_env(times_var), nullptr, 0) : nullptr;
+    d.lanes = diag_env(lanes_var) ? (unsigned long long *)strtoull(diag_env(lanes_var), nullptr, 0) : nullptr;
+  }
+  return d;
+}
+
 template <int C, bool WITH_DEPTH = true>
 int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
                      const float4 *rec, float *final_T, uint32_t *n_contrib,
                      float *out_color, float *out_color2, float *out_depth, hipStream_t s, hipEvent_t done = nullptr) {
+  if (use_quad_waves(cam, ntiles, false)) {
+    if (done)  // the launch's own completion signals the event: no marker packet behind the kernel (fsgs_forward_done_event)
+      hipExtLaunchKernelGGL((blend_fwd_quad_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(256), 0, s, nullptr, done, 0, cam, ntiles,
+                            order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth);
+    else
+      hipLaunchKernelGGL((blend_fwd_quad_kernel<C, WITH_DEPTH>), dim3(ntiles), dim3(256), 0, s, cam, ntiles, order, ranges,
+                         plist, rec, final_T, n_contrib, out_color, out_color2, out_depth);
+    return 0;
+  }
   static int dbg_lds = diag_env("FSGS_DBG_LDS_FWD") ? atoi(diag_env("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
-  static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
-      diag_env("FSGS_DBG_TILE_TIMES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES_FWD"), nullptr, 0) : nullptr;
+  static const DiagPtrs<kDiagBuild> dbg = diag_ptrs<kDiagBuild>("FSGS_DBG_TILE_TIMES_FWD", "FSGS_DBG_LANES_FWD");
   // scheduling experiments only (scripts/dev/order_experiment.py): a dispatch order made on the host, holes (0xFFFFFFFF) allowed
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_FWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_FWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_FWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_FWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
-  // lane-utilisation counters (scripts/lane_utilisation.py): 32 u64 on the device, summed over every launch
-  static unsigned long long *dbg_lanes =
-      diag_env("FSGS_DBG_LANES_FWD") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_LANES_FWD"), nullptr, 0) : nullptr;
-  if (done)  // the launch's own completion signals the event: no marker packet behind the kernel (fsgs_forward_done_event)
-    hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam, ntiles,
-                          dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
-                          dbg_times, dbg_lanes);
+  if (done)
+    hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam,
+                          ntiles, dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2,
+                          out_depth, dbg);
   else
-    hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
-                       final_T, n_contrib, out_color, out_color2, out_depth, dbg_times, dbg_lanes);
+    hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles,
+                       dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
+                       dbg);
   return 0;
 }
 template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0>
@@ -1577,17 +1898,20 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                      const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
                      float *clear16 = nullptr) {
-  if (ROW != 0 && dcolors != grad_acc + 8) return FSGS_ERR_INVALID;  // the one-row layout the kernel's addressing assumes
+  if (ROW != 0 && dcolors != grad_acc + 8) return FSGS_ERR_INVALID;  // the one-row layout the kernels' addressing assumes
+  if (use_quad_waves(cam, ntiles, true)) {
+    hipLaunchKernelGGL((blend_bwd_quad_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(256), 0, s, cam, ntiles,
+                       order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
+    return 0;
+  }
   static int dbg_lds = diag_env("FSGS_DBG_LDS") ? atoi(diag_env("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
-  static unsigned long long *dbg_times =  // load-balance experiments only: a device buffer of 4 * ntiles uint64
-      diag_env("FSGS_DBG_TILE_TIMES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_TILE_TIMES"), nullptr, 0) : nullptr;
+  static const DiagPtrs<kDiagBuild> dbg = diag_ptrs<kDiagBuild>("FSGS_DBG_TILE_TIMES", "FSGS_DBG_LANES");
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_BWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_BWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_BWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_BWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
-  static unsigned long long *dbg_lanes =  // lane-utilisation counters, see launch_blend_fwd
-      diag_env("FSGS_DBG_LANES") ? (unsigned long long *)strtoull(diag_env("FSGS_DBG_LANES"), nullptr, 0) : nullptr;
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles, dbg_order ? dbg_order : order, ranges, plist, rec,
-                     final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16, dbg_times, dbg_lanes);
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, cam,
+                     ntiles, dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors,
+                     clear16, dbg);
   return 0;
 }
 

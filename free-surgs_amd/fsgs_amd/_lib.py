@@ -16,6 +16,7 @@ FSGS_ERR_INVALID = -1
 FSGS_ERR_CAPACITY = -2
 FSGS_FLAG_XCD_BANDED_ORDER, FSGS_FLAG_DEPTH_GRAD_ONLY, FSGS_FLAG_SCRATCH_ZEROED, FSGS_FLAG_RGB_DEPTH_ONLY = 1, 2, 4, 8
 FSGS_FLAG_SCRATCH_SELF_CLEAN = 16
+FSGS_FLAG_BLEND_ONE_WAVE, FSGS_FLAG_BLEND_QUAD_WAVES = 32, 64
 FSGS_ERR_HIP = -3
 FSGS_ERR_STATE = -4
 MAX_CHANNELS = 8

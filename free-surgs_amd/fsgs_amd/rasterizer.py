@@ -7,6 +7,8 @@ scene/pose_optimizer.py:619-632 (settings tuple), train.py:337 (`._replace`).
 from typing import NamedTuple
 
 import ctypes as C
+import os
+
 import torch
 import torch.nn as nn
 
@@ -50,12 +52,38 @@ def _host_floats(t, n):
     return hit[2]
 
 
+# ---- flavour of the blend kernels (include/fsgs.h FSGS_FLAG_BLEND_*) ---------------------------------------------------
+# "auto" (the default): the library picks by the size of the tile grid.  "one" / "quad" force one wave / four waves per
+# tile for every configuration struct made from here on -- the parity tests run over both, bench.py --blend measures the
+# crossover.  FSGS_BLEND_VARIANT in the environment sets the initial value.
+_BLEND_FLAGS = {"auto": 0, "one": _lib.FSGS_FLAG_BLEND_ONE_WAVE, "quad": _lib.FSGS_FLAG_BLEND_QUAD_WAVES}
+_blend_variant = os.environ.get("FSGS_BLEND_VARIANT", "auto")
+if _blend_variant not in _BLEND_FLAGS:
+    raise ValueError("FSGS_BLEND_VARIANT must be one of %s, not %r" % (sorted(_BLEND_FLAGS), _blend_variant))
+
+
+def set_blend_variant(name):
+    """force ("one" / "quad") or release ("auto") the flavour of the blend kernels; returns the previous setting.
+    Cached configuration structs are dropped, so the next render of every settings object sees the new value (a
+    FastStepper keeps its own struct: make a new stepper, or reset its cfg_key)."""
+    global _blend_variant
+    if name not in _BLEND_FLAGS:
+        raise ValueError("blend variant must be one of %s, not %r" % (sorted(_BLEND_FLAGS), name))
+    prev, _blend_variant = _blend_variant, name
+    _cfg_cache.clear()
+    return prev
+
+
+def blend_variant():
+    return _blend_variant
+
+
 def make_cfg(settings, channels):
     cfg = _lib.FsgsRasterCfg()
     cfg.image_height = int(settings.image_height)
     cfg.image_width = int(settings.image_width)
     cfg.channels = int(channels)
-    cfg.flags = 0
+    cfg.flags = _BLEND_FLAGS[_blend_variant]
     cfg.tanfovx = float(settings.tanfovx)
     cfg.tanfovy = float(settings.tanfovy)
     cfg.scale_modifier = float(settings.scale_modifier)
@@ -74,7 +102,9 @@ def make_cfg(settings, channels):
 # ---- the configuration struct of a settings object, cached (the drop-in makes two rasteriser calls per
 # render() with the SAME settings tuple; rebuilding the 50-field ctypes struct for each was ~40 us of host time) ----------
 # Keyed like _host_cache: the settings object itself is kept in the entry (an id() alone can be recycled) together with
-# the version counters of its three tensors; the struct is handed out READ-ONLY (callers that set flags copy it).
+# the version counters of its three tensors; callers get a copy of the cached struct.  The camera tensors must be
+# updated through versioned in-place ops (or optim.mark_updated after a raw-pointer kernel): a write through `.data` does
+# not bump the counter and leaves a stale camera here.
 _cfg_cache = {}
 
 
@@ -86,7 +116,11 @@ def cached_cfg(settings, channels):
         if len(_cfg_cache) >= 256:
             _cfg_cache.pop(next(iter(_cfg_cache)))
         hit = _cfg_cache[key] = (settings, vers, make_cfg(settings, channels))
-    return hit[2]
+    # a COPY (one 176-byte memmove against rebuilding 50 ctypes fields): a caller that sets flags on what it gets can
+    # never change what the next render with the same settings object sees
+    out = _lib.FsgsRasterCfg()
+    C.memmove(C.byref(out), C.byref(hit[2]), C.sizeof(out))
+    return out
 
 
 _sizes = {}  # (P, W, H, max_pairs) -> (state bytes, scratch bytes): pure functions of the shape, queried once
