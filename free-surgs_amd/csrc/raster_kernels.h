@@ -1028,6 +1028,9 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
   const int x0 = (tile % cam.gx) * FSGS_TILE + (lane & 7), y0 = (tile / cam.gx) * FSGS_TILE + (lane >> 3);
   const int x = x0 + FSGS_QUAD * (q & 1), y = y0 + FSGS_QUAD * (q >> 1);
   const float px0 = (float)x0, py0 = (float)y0;  // the lane's pixel in quadrant 0, as in the one-wave kernel
+  // quad_offset() with the wave's quadrant in scalar registers: d - 8 or d - 0 (exact, -0 included) -- one v_sub with a scalar
+  // operand per coordinate instead of add + select
+  const float offx = (q & 1) ? (float)FSGS_QUAD : 0.0f, offy = (q >> 1) ? (float)FSGS_QUAD : 0.0f;
   const bool inside = x < W && y < H;
   float T = inside ? 1.0f : -1.0f, D = 0.0f;
   float2v acc[CP];
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
           const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
           const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
           const float dx0 = __fsub_rn(r0.x, px0), dy0 = __fsub_rn(r0.y, py0);
-          blend_fwd_pixel<CP, WITH_DEPTH>(T, D, acc, last, quad_offset(dx0, q & 1), quad_offset(dy0, q >> 1), r0.z, r0.w,
+          blend_fwd_pixel<CP, WITH_DEPTH>(T, D, acc, last, __fsub_rn(dx0, offx), __fsub_rn(dy0, offy), r0.z, r0.w,
                                           r1.x, r1.y, r1.z, bcol2, (uint32_t)(base + j - rg.x + 1));
         }
         if (__ballot(T > 0.f) == 0ull) break;  // the quadrant finished inside this batch
@@ -1448,6 +1451,7 @@ __global__ __launch_bounds__(256) void blend_bwd_quad_kernel(
   const int x0 = (tile % cam.gx) * FSGS_TILE + (lane & 7), y0 = (tile / cam.gx) * FSGS_TILE + (lane >> 3);
   const int x = x0 + FSGS_QUAD * (q & 1), y = y0 + FSGS_QUAD * (q >> 1);
   const float px0 = (float)x0, py0 = (float)y0;
+  const float offx = (q & 1) ? (float)FSGS_QUAD : 0.0f, offy = (q >> 1) ? (float)FSGS_QUAD : 0.0f;  // see blend_fwd_quad_kernel
   const bool inside = x < W && y < H;
   const size_t pix = inside ? (size_t)y * W + x : 0;
   float T = inside ? final_T[pix] : 0.0f;
@@ -1519,8 +1523,8 @@ __global__ __launch_bounds__(256) void blend_bwd_quad_kernel(
             const float4 r0 = rec[j * 3 + 0], r1 = rec[j * 3 + 1], r2 = rec[j * 3 + 2];
             const float bcol[6] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
             const float dx0 = __fsub_rn(r0.x, px0), dy0 = __fsub_rn(r0.y, py0);
-            any |= blend_bwd_pixel<CG, SPLIT, POSE_ONLY>(&v[SL * u], T, gB, gBr, g, quad_offset(dx0, q & 1),
-                                                         quad_offset(dy0, q >> 1), r0.z, r0.w, r1.x, r1.y, bcol, lo + j < last);
+            any |= blend_bwd_pixel<CG, SPLIT, POSE_ONLY>(&v[SL * u], T, gB, gBr, g, __fsub_rn(dx0, offx), __fsub_rn(dy0, offy),
+                                                         r0.z, r0.w, r1.x, r1.y, bcol, lo + j < last);
           }
           if (__ballot(any) == 0ull) continue;  // wave-uniform: neither Gaussian touched a pixel of the quadrant
           const float tot = Slots::reduce(v, lane);
