@@ -369,10 +369,68 @@ def drop_in_extra(cfg_name, device, steps=30, warmup=5):
             out[name]["breakdown_ms"] = drop_in_breakdown(pc, poses, frames)
         del pc, poses, frames
         torch.cuda.empty_cache()
+    out["autobind"] = drop_in_autobind(cfg_name, device, steps, warmup)
+    out["autobind"]["over_three_edits"] = out["autobind"]["ms_per_step_without_driver_statistics"] / out["three_edits"]["ms_per_step"]
+    out["autobind"]["over_three_edits_incl_driver_statistics"] = out["autobind"]["ms_per_step"] / out["three_edits"]["ms_per_step"]
     out["what"] = ("trainer.mapping_step under torch.autograd at %s: `unchanged` = two drop-in GaussianRasterizer calls + torch glue "
                    "+ torch losses + torch.optim.Adam (INTEGRATION s2); `losses_edit_only` = the same with the HIP loss kernels; "
                    "`three_edits` = fused render + HIP losses + FusedAdam (INTEGRATION s3)" % cfg_name)
     return out
+
+
+
+def drop_in_autobind(cfg_name, device, steps=30, warmup=5):
+    """INTEGRATION.md s2's "no edit, one environment variable" row: a stand-in checkout (scripts/standin_checkout.py: the
+    reference's module / function names; its own bodies are the `unchanged` route) imported with fsgs_amd.autobind
+    installed, so its driver's `render`, the three losses and `torch.optim.Adam` are the fused op, the HIP loss kernels and
+    FusedAdam BY NAME -- the same kernels as `three_edits`, reached with no source edit."""
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import standin_checkout
+    from fsgs_amd import autobind
+
+    tree = standin_checkout.write_tree(tempfile.mkdtemp(prefix="fsgs_standin_"))
+    standin_checkout.forget()
+    autobind.install()
+    sys.path.insert(0, tree)
+    try:
+        import standin_train
+        from scene import GaussianModel
+
+        pc0, poses, frames, cam, sc = build_problem(cfg_name, device, 0, 1)
+        pc = GaussianModel(dict(sc), sh_degree=3, device=device, scene_radius=float(sc["depth_map"].max()) / 2.0)
+        pc.cam, pc.active_sh_degree, pc.spatial_lr_scale = pc0.cam, pc0.active_sh_degree, pc0.spatial_lr_scale
+        del pc0
+        pc.training_setup(eps=1e-8)
+        n = len(frames.colors)
+
+        def timed(statistics):
+            for it in range(warmup):
+                standin_train.mapping_iteration(poses, pc, frames.colors, frames.monodeps, it % n, statistics=statistics)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(steps):
+                standin_train.mapping_iteration(poses, pc, frames.colors, frames.monodeps, it % n, statistics=statistics)
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, t_issue
+
+        dt_core, _ = timed(False)
+        dt, t_issue = timed(True)
+        return {"ms_per_step": dt / steps * 1e3, "iters_per_sec": steps / dt, "host_issue_ms_per_step": t_issue / steps * 1e3,
+                # render + losses + backward + Adam alone: what `three_edits` times, which takes the statistics through ONE
+                # fused call (optim.densify_stats) instead of the driver's own boolean-mask statements (train.py:297-303)
+                "ms_per_step_without_driver_statistics": dt_core / steps * 1e3,
+                "steps": steps, "bound": autobind.bound(), "optimizer": type(pc.optimizer).__name__,
+                "render": standin_train.render.__module__, "losses": standin_train.rgb_loss_func.__module__,
+                "what": "stand-in checkout (reference names, unchanged-route bodies) + FSGS_AUTOBIND: fused render + HIP losses "
+                        "+ FusedAdam bound by name; densification statistics as the reference's torch statements"}
+    finally:
+        sys.path.remove(tree)
+        standin_checkout.forget()
+        autobind.uninstall()
+        torch.cuda.empty_cache()
 
 
 

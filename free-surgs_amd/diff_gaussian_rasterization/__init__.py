@@ -7,3 +7,8 @@ from fsgs_amd.rasterizer import (  # noqa: F401
     GaussianRasterizer,
     rasterize_gaussians,
 )
+
+# FSGS_AUTOBIND=1: also rebind render / the three losses / Adam of an unchanged checkout to the fused path (fsgs_amd/autobind.py)
+from fsgs_amd import autobind as _autobind  # noqa: E402
+
+_autobind.install_from_env()
