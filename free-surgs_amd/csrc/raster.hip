@@ -23,6 +23,11 @@
 // ================================================================================================
 extern "C" {
 
+size_t fsgs_deterministic_scratch_bytes(int P, int64_t max_pairs) {
+  if (P < 0 || max_pairs < 0) return 0;
+  return det_layout(P, max_pairs).total;
+}
+
 int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs, size_t *state_bytes, size_t *scratch_bytes) {
   if (P < 0 || width <= 0 || height <= 0 || max_pairs < 0 || !state_bytes || !scratch_bytes) return FSGS_ERR_INVALID;
   *state_bytes = state_layout(P, width, height, max_pairs).total;
@@ -106,6 +111,9 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   StateLayout SL = state_layout(P, W, H, max_pairs);
   if (state_bytes < SL.total) return FSGS_ERR_STATE;
   if (scratch_bytes < (size_t)P * kAccStride * sizeof(float)) return FSGS_ERR_CAPACITY;
+  const bool deterministic = (cfg->flags & FSGS_FLAG_DETERMINISTIC) != 0;
+  const DetLayout DL = det_layout(P, max_pairs);
+  if (deterministic && (scratch_bytes < DL.total || (((uintptr_t)scratch) & 15))) return FSGS_ERR_CAPACITY;
   CamParams cam = make_cam(cfg);
   const int ntiles = cam.gx * cam.gy;
   const char *sb = (const char *)state;
@@ -121,11 +129,16 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   FSGS_HIP(hipMemsetAsync(dcolors, 0, (size_t)P * C * sizeof(float), stream));
   if (num_rendered > 0) {
     ProfScope ps(PROF_BLEND_BWD, stream);
+    const DetGather dg{(float *)((char *)scratch + DL.pair_rows), max_pairs, P, radii, (const float2 *)(sb + SL.xy),
+                       (const float *)(sb + SL.depth)};
+    const DetGather *det = deterministic ? &dg : nullptr;
+    int rc = 0;
     switch (C) {
-      case 1: launch_blend_bwd<1>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 3: launch_blend_bwd<3>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
-      case 6: launch_blend_bwd<6>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream); break;
+      case 1: rc = launch_blend_bwd<1>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream, nullptr, det); break;
+      case 3: rc = launch_blend_bwd<3>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream, nullptr, det); break;
+      case 6: rc = launch_blend_bwd<6>(cam, ntiles, order, ranges, plist, rec, final_T, n_contrib, dL_dcolor, dL_dcolor + 3 * (size_t)W * H, grad_acc, dcolors, stream, nullptr, det); break;
     }
+    if (rc != 0) return rc;
     FSGS_HIP(hipGetLastError());
   }
   {

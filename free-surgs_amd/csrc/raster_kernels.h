@@ -52,6 +52,15 @@ struct Projected {
   float4 conic_op;
   float tz;
 };
+// the tiles a Gaussian's 3-sigma square touches: [minx, maxx) x [miny, maxy) (UPSTREAM getRect); also how
+// det_gather_kernel finds a Gaussian's pairs again from its stored mean2D and radius
+__device__ __forceinline__ void tile_rect(int gx, int gy, float px, float py, int r_, int &minx, int &miny, int &maxx,
+                                          int &maxy) {
+  minx = min(gx, max(0, (int)((px - r_) / FSGS_TILE)));
+  miny = min(gy, max(0, (int)((py - r_) / FSGS_TILE)));
+  maxx = min(gx, max(0, (int)((px + r_ + FSGS_TILE - 1) / FSGS_TILE)));
+  maxy = min(gy, max(0, (int)((py + r_ + FSGS_TILE - 1) / FSGS_TILE)));
+}
 // mean: Gaussian centre in the raster camera's world frame; s: activated scale * modifier;
 // q: quaternion as handed over (no re-normalisation); opacity: activated.
 __device__ __forceinline__ Projected project_gaussian(const CamParams &cam, float mx, float my, float mz, float3 s,
@@ -89,10 +98,8 @@ __device__ __forceinline__ Projected project_gaussian(const CamParams &cam, floa
   int r_ = (int)ceilf(3.0f * sqrtf(lam));
   float px = ((ndcx + 1.0f) * cam.W - 1.0f) * 0.5f;
   float py = ((ndcy + 1.0f) * cam.H - 1.0f) * 0.5f;
-  int minx = min(cam.gx, max(0, (int)((px - r_) / FSGS_TILE)));
-  int miny = min(cam.gy, max(0, (int)((py - r_) / FSGS_TILE)));
-  int maxx = min(cam.gx, max(0, (int)((px + r_ + FSGS_TILE - 1) / FSGS_TILE)));
-  int maxy = min(cam.gy, max(0, (int)((py + r_ + FSGS_TILE - 1) / FSGS_TILE)));
+  int minx, miny, maxx, maxy;
+  tile_rect(cam.gx, cam.gy, px, py, r_, minx, miny, maxx, maxy);
   int area = (maxx - minx) * (maxy - miny);
   if (area <= 0) return o;
   const float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
@@ -1107,6 +1114,8 @@ constexpr int kAccStride = 8;
 // The fused render keeps moments AND colour sums of a Gaussian in ONE 64-byte row, [0..7] moments | [8..13] colours:
 // the up to 12 atomics a (tile, Gaussian) pair issues land in one cache line instead of two or three.
 constexpr int kFusedRow = 16;
+// FSGS_FLAG_DETERMINISTIC: one row of this many floats per (tile, Gaussian) pair, [0..7] moments | [8..8+C) colour sums
+constexpr int kDetRow = 16;
 
 // Moments -> the gradients of SURVEY.md A.4.  The moments arrive multiplied by the opacity (w o = a dL/dalpha, see
 // SplatEval): dL/dmean2D (pixel units) = -(A m0 + B m1, C m1 + B m0), dL/dconic (A,B,C) = -(m2/2, m3, m4/2),
@@ -1213,7 +1222,10 @@ struct BwdSlots {
   }
 };
 
-template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, bool DIAG = false>
+// DET (FSGS_FLAG_DETERMINISTIC, tests): no atomics -- the wave's total of slot c of the pair at list position p goes to
+// pair_rows[p][c] (a plain store into the pair's own 16-float row, passed in `grad_acc`); det_gather_kernel then sums a
+// Gaussian's rows in a fixed order.
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, bool DIAG = false, bool DET = false>
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
 #endif
@@ -1387,7 +1399,9 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         const uint32_t gu = readlane(gid, max(jj - u, 0));
         gsel = my_u == u ? gu : gsel;
       }
-      if (j_mine >= 0 && c_used && tot != 0.f) {
+      if constexpr (DET) {
+        if (j_mine >= 0 && c_used && tot != 0.f) grad_acc[((size_t)rg.x + (size_t)(lo + j_mine)) * kDetRow + (uint32_t)my_c] = tot;
+      } else if (j_mine >= 0 && c_used && tot != 0.f) {
         if constexpr (ROW != 0) {
           // one row per Gaussian holds moments AND colour sums (dcolors = grad_acc + 8, stride ROW: launch_blend_bwd checks
           // it), so slot c of either kind is float c of the row: uniform base + a 32-bit offset, no 64-bit address pair
@@ -1837,6 +1851,85 @@ inline int finish_binning(const CamParams &cam, FwdBuffers &B, int64_t max_pairs
   return FSGS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FSGS_FLAG_DETERMINISTIC: the per-Gaussian sums of the backward blend in a FIXED order (tests only)
+// ------------------------------------------------------------------------------------------------
+// The product backward adds a pair's totals to its Gaussian's row with float atomics, in the order the workgroups happen
+// to get there: two runs differ in the last bits.  Here blend_bwd_kernel<.., DET> has stored every pair's totals in the
+// pair's own row (indexed by the pair's position in `plist`), and one thread per Gaussian walks the tiles of the Gaussian's
+// rect row by row, finds its entry in each tile's list -- the lists are sorted by (depth bits, index), both stored -- and adds
+// that row: same order, same bits, every run, whatever the dispatch order.  Costs a [max_pairs,16] float buffer, its
+// clearing and ~8 dependent probes per pair; nothing of it is compiled into the product path's kernels.
+template <int C, int ROW>
+__global__ __launch_bounds__(256) void det_gather_kernel(int P, int gx, int gy, const int32_t *__restrict__ radii,
+                                                         const float2 *__restrict__ xy, const float *__restrict__ depth,
+                                                         const int2 *__restrict__ ranges, const uint32_t *__restrict__ plist,
+                                                         const float *__restrict__ pair_rows, float *__restrict__ grad_acc,
+                                                         float *__restrict__ dcolors) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int r_ = radii[i];
+  if (r_ <= 0) return;
+  const float2 p = xy[i];
+  int minx, miny, maxx, maxy;
+  tile_rect(gx, gy, p.x, p.y, r_, minx, miny, maxx, maxy);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+  float acc[kDetRow];
+#pragma unroll
+  for (int c = 0; c < kDetRow; c++) acc[c] = 0.f;
+  for (int ty = miny; ty < maxy; ty++)
+    for (int tx = minx; tx < maxx; tx++) {
+      const int2 rg = ranges[ty * gx + tx];
+      int lo = rg.x, hi = rg.y;
+      while (lo < hi) {  // first entry whose key is not below this Gaussian's
+        const int mid = (lo + hi) >> 1;
+        const uint32_t g = plist[mid];
+        const unsigned long long k = ((unsigned long long)__float_as_uint(depth[g]) << 32) | g;
+        if (k < key) lo = mid + 1; else hi = mid;
+      }
+      if (lo < rg.y && plist[lo] == (uint32_t)i) {
+        const float4 *row = reinterpret_cast<const float4 *>(pair_rows + (size_t)lo * kDetRow);
+#pragma unroll
+        for (int q = 0; q < kDetRow / 4; q++) {
+          const float4 v = row[q];
+          acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+        }
+      }
+    }
+  if constexpr (ROW != 0) {
+#pragma unroll
+    for (int c = 0; c < ROW; c++) grad_acc[(size_t)i * ROW + c] = acc[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < kAccStride; c++) grad_acc[(size_t)i * kAccStride + c] = acc[c];
+#pragma unroll
+    for (int c = 0; c < C; c++) dcolors[(size_t)i * C + c] = acc[8 + c];
+  }
+}
+// what the deterministic route of launch_blend_bwd needs beyond the blend's own arguments
+struct DetGather {
+  float *pair_rows;  // [max_pairs * kDetRow] floats, 16-byte aligned
+  int64_t max_pairs;
+  int P;
+  const int32_t *radii;
+  const float2 *xy;
+  const float *depth;
+};
+inline size_t det_pair_rows_bytes(int64_t max_pairs) { return (size_t)(max_pairs > 0 ? max_pairs : 1) * kDetRow * sizeof(float); }
+// `scratch` of a deterministic backward: [per-Gaussian rows (P x 64 B) | pair rows | per-workgroup dL/dw2c partials]
+constexpr int kDetW2cBlock = 256;  // Gaussians per workgroup of the per-Gaussian backward kernels (render.hip RB)
+struct DetLayout {
+  size_t pair_rows, w2c_partials, total;
+};
+inline DetLayout det_layout(int P, int64_t max_pairs) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  DetLayout L;
+  L.pair_rows = up((size_t)(P > 0 ? P : 1) * kFusedRow * sizeof(float));
+  L.w2c_partials = L.pair_rows + up(det_pair_rows_bytes(max_pairs));
+  L.total = L.w2c_partials + up((size_t)((P > 0 ? P : 1) + kDetW2cBlock - 1) / kDetW2cBlock * 16 * sizeof(float));
+  return L;
+}
+
 // Which flavour of the blend kernels a launch takes: one wave per tile or four waves per tile (blend_*_quad_kernel).
 // FsgsRasterCfg.flags can force either for both directions; otherwise, measured on MI355X (profiles/r05_blend_flavours.txt,
 // blend kernel us, one wave -> four waves, mapping step of bench.py):
@@ -1901,8 +1994,18 @@ template <int C, bool SPLIT = false, bool POSE_ONLY = false, int CGRAD = C, int 
 int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, const int2 *ranges, const uint32_t *plist,
                      const float4 *rec, const float *final_T, const uint32_t *n_contrib,
                      const float *dL, const float *dL2, float *grad_acc, float *dcolors, hipStream_t s,
-                     float *clear16 = nullptr) {
+                     float *clear16 = nullptr, const DetGather *det = nullptr) {
   if (ROW != 0 && dcolors != grad_acc + 8) return FSGS_ERR_INVALID;  // the one-row layout the kernels' addressing assumes
+  if (det && det->pair_rows) {
+    // FSGS_FLAG_DETERMINISTIC: pair rows (one-wave kernel, plain stores) + the fixed-order gather; see det_gather_kernel
+    if (hipMemsetAsync(det->pair_rows, 0, det_pair_rows_bytes(det->max_pairs), s) != hipSuccess) return FSGS_ERR_HIP;
+    hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, false, true>), dim3(ntiles), dim3(64), 0, s, cam,
+                       ntiles, order, ranges, plist, rec, final_T, n_contrib, dL, dL2, det->pair_rows, det->pair_rows + 8,
+                       clear16, DiagPtrs<false>{});
+    hipLaunchKernelGGL((det_gather_kernel<C, ROW>), dim3((det->P + 255) / 256), dim3(256), 0, s, det->P, cam.gx, cam.gy,
+                       det->radii, det->xy, det->depth, ranges, plist, (const float *)det->pair_rows, grad_acc, dcolors);
+    return 0;
+  }
   if (use_quad_waves(cam, ntiles, true)) {
     hipLaunchKernelGGL((blend_bwd_quad_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(256), 0, s, cam, ntiles,
                        order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);

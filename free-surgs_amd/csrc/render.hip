@@ -123,6 +123,7 @@ constexpr int SH_REST_MAX = 45;  // (16 - 1) * 3
 // coefficients (46 KB at 256).  Measured at C2: 64 / 128 / 256 are within 3 % of each other for the mapping
 // backward (LDS bytes per resident wave are the same), and 256 has the fewest dL/dw2c atomics in tracking.
 constexpr int RB = 256;
+static_assert(RB == kDetW2cBlock, "det_layout sizes the dL/dw2c partials for workgroups of RB Gaussians");
 
 __device__ __forceinline__ void stage_in(float *lds, const float *src, size_t first, size_t count) {
   // count floats starting at src[first]; first*4 is 16-byte aligned for 256-Gaussian blocks when the row
@@ -238,6 +239,7 @@ struct RenderGradsDev {
 };
 
 // mode bits
+constexpr int MODE_DET_W2C = 64;    // dL/dw2c as per-workgroup partials (FSGS_FLAG_DETERMINISTIC), see w2c_finish_kernel
 constexpr int MODE_GS_GRAD = 1;     // means3D gradient flows to _xyz (gs_grad=True)
 constexpr int MODE_CAM_GRAD = 2;    // reduce dL/dw2c (cam_grad=True)
 constexpr int MODE_PARAM_GRAD = 4;  // gradients of features / opacity / scaling / rotation (+ _xyz through the SH direction)
@@ -581,7 +583,10 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_kernel(int P, CamParams cam
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < RB / 64; w++) t += red[threadIdx.x][w];
-      if (t != 0.f) atomicAdd(out.w2c + threadIdx.x, t);
+      // MODE_DET_W2C (FSGS_FLAG_DETERMINISTIC): out.w2c is the per-workgroup partials buffer, summed in workgroup order by
+      // w2c_finish_kernel instead of by atomics in arrival order
+      if (mode & MODE_DET_W2C) out.w2c[(size_t)blockIdx.x * 16 + threadIdx.x] = t;
+      else if (t != 0.f) atomicAdd(out.w2c + threadIdx.x, t);
     }
   }
 }
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParam
     float4 *ap = (float4 *)(grad_acc + (size_t)i * kFusedRow);  // moments | colour sums (dc[3], dc[5]: depth)
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
     const float2 a3 = *(const float2 *)(ap + 3);
-    if (clean) {  // FSGS_FLAG_SCRATCH_SELF_CLEAN (see render_pre_bwd_kernel)
+    if (clean & 1) {  // FSGS_FLAG_SCRATCH_SELF_CLEAN (see render_pre_bwd_kernel); bit 1: deterministic partials
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       ap[0] = z; ap[1] = z; ap[2] = z; ap[3] = z;
     }
@@ -638,8 +643,19 @@ __global__ __launch_bounds__(RB) void render_pre_bwd_pose_kernel(int P, CamParam
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < RB / 64; w++) t += red[threadIdx.x][w];
-    if (t != 0.f) atomicAdd(dw2c + threadIdx.x, t);
+    if (clean & 2) dw2c[(size_t)blockIdx.x * 16 + threadIdx.x] = t;  // deterministic: partials (see MODE_DET_W2C)
+    else if (t != 0.f) atomicAdd(dw2c + threadIdx.x, t);
   }
+}
+
+// FSGS_FLAG_DETERMINISTIC: dL/dw2c = the per-workgroup partials added in workgroup order (rows 0..2; row 3 = 0)
+__global__ void w2c_finish_kernel(const float *__restrict__ partials, int nblocks, float *__restrict__ w2c) {
+  const int k = threadIdx.x;
+  if (k >= 16) return;
+  float t = 0.f;
+  if (k < 12)
+    for (int b = 0; b < nblocks; b++) t += partials[(size_t)b * 16 + k];
+  w2c[k] = t;
 }
 
 // Adam step of all six groups from the compact per-Gaussian gradient (see OUT_COMPACT): the SH gradients
@@ -899,6 +915,9 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   const size_t need = (size_t)P * kFusedRow * sizeof(float);
   if (scratch_bytes < need) return FSGS_ERR_CAPACITY;
   if (((uintptr_t)scratch) & 15) return FSGS_ERR_INVALID;  // the accumulator rows are read as float4
+  const bool deterministic = (cfg->flags & FSGS_FLAG_DETERMINISTIC) != 0;
+  const DetLayout DL = det_layout(P, max_pairs);
+  if (deterministic && scratch_bytes < DL.total) return FSGS_ERR_CAPACITY;
   // EVERY argument is validated before the first launch: the blend backward accumulates into `scratch`, and a caller that
   // runs with FSGS_FLAG_SCRATCH_ZEROED relies on the per-Gaussian kernel behind it to leave the rows zero again -- a
   // rejected call must not have touched them
@@ -929,6 +948,10 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   // dL/dw2c is accumulated with atomics by the preprocess backward: cleared by the blend kernel in front of it
   // (tracking), by a fill otherwise
   if (cam_grad && !pose_only_path) FSGS_HIP(hipMemsetAsync(grads->w2c, 0, 16 * sizeof(float), stream));
+  const DetGather dg{(float *)((char *)scratch + DL.pair_rows), max_pairs, P, radii, (const float2 *)(sb + SL.xy),
+                     (const float *)(sb + SL.depth)};
+  const DetGather *det = deterministic ? &dg : nullptr;
+  float *w2c_partials = (float *)((char *)scratch + DL.w2c_partials);
   if (blend) {
     ProfScope ps(PROF_BLEND_BWD, stream);
     const uint32_t *order = ntiles <= ORDER_MAX_TILES ? (const uint32_t *)(sb + SL.order) : nullptr;
@@ -938,30 +961,32 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
       launch_blend_bwd<6, false, true, 6, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                        (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                        (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c);
+                                       dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, grads->w2c, det);
     else if ((cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY) && !grads->means2D)
       // nobody wants the densification statistic (means2D_grad == NULL): the RGB-only mean2D moments are dropped too
       launch_blend_bwd<6, false, false, 4, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                            (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                            (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+                                           dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, det);
     else if (cfg->flags & FSGS_FLAG_DEPTH_GRAD_ONLY)  // dL_ddepth_sil is [1,H,W]: planes 1, 2 carry no gradient
       launch_blend_bwd<6, true, false, 4, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges),
                                           (const uint32_t *)(sb + SL.plist), (const float4 *)(sb + SL.rec),
                                           (const float *)(sb + SL.final_T), (const uint32_t *)(sb + SL.n_contrib),
-                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream);
+                                          dL_dimage, dL_ddepth_sil, grad_acc, dcolors6, stream, nullptr, det);
     else
       launch_blend_bwd<6, true, false, 6, kFusedRow>(cam, ntiles, order, (const int2 *)(sb + SL.ranges), (const uint32_t *)(sb + SL.plist),
                                 (const float4 *)(sb + SL.rec), (const float *)(sb + SL.final_T),
                                 (const uint32_t *)(sb + SL.n_contrib), dL_dimage, dL_ddepth_sil, grad_acc, dcolors6,
-                                stream);
+                                stream, nullptr, det);
   }
   FSGS_HIP(hipGetLastError());
   const bool clean = (cfg->flags & FSGS_FLAG_SCRATCH_SELF_CLEAN) != 0;
+  const bool det_w2c = deterministic && cam_grad;
   int mode = (gs_grad ? MODE_GS_GRAD : 0) | (cam_grad ? MODE_CAM_GRAD : 0) | (param_grads ? MODE_PARAM_GRAD : 0) |
              (clean ? MODE_CLEAN_ACC : 0);
   RenderGradsDev out{grads->xyz, grads->features_dc, grads->features_rest, grads->opacity, grads->scaling,
-                     grads->rotation, grads->means2D, grads->w2c, compact};
+                     grads->rotation, grads->means2D, det_w2c ? w2c_partials : grads->w2c, compact};
+  int w2c_blocks = 0;  // deterministic: workgroups whose partials w2c_finish_kernel adds up
   if (row_hi > row_lo) {
     ProfScope ps(PROF_RENDER_PRE_BWD, stream);
     // (diagnostics flavour only: unused dynamic LDS = fewer resident workgroups, the occupancy experiment of DESIGN s3 round 4)
@@ -975,14 +1000,20 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
                          (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
     else if ((mode & ~MODE_CLEAN_ACC) == MODE_CAM_GRAD && !out.means2D && !td.accum && !td.total && row_lo == 0 && row_hi == P &&
-             out.w2c)
+             out.w2c) {
       // the tracking step: dL/dw2c and nothing else
-      hipLaunchKernelGGL(render_pre_bwd_pose_kernel, dim3(std::min((P + RB - 1) / RB, 512)), dim3(RB), 0, stream, P, cam,
-                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, clean ? 1 : 0, out.w2c);
-    else
-      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3((row_hi - row_lo + RB - 1) / RB), dim3(RB), 0, stream, row_hi,
+      w2c_blocks = std::min((P + RB - 1) / RB, 512);
+      hipLaunchKernelGGL(render_pre_bwd_pose_kernel, dim3(w2c_blocks), dim3(RB), 0, stream, P, cam,
+                         to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, (clean ? 1 : 0) | (det_w2c ? 2 : 0),
+                         out.w2c);
+    } else {
+      w2c_blocks = (row_hi - row_lo + RB - 1) / RB;
+      hipLaunchKernelGGL(render_pre_bwd_kernel<OUT_GRADS>, dim3(w2c_blocks), dim3(RB), 0, stream, row_hi,
                          cam, to_dev(args), radii, (const float4 *)(sb + SL.conic_op), grad_acc, dcolors6,
-                         (const uint32_t *)(sb + SL.flags), mode, out, ad, td, row_lo);
+                         (const uint32_t *)(sb + SL.flags), mode | (det_w2c ? MODE_DET_W2C : 0), out, ad, td, row_lo);
+    }
+    if (det_w2c && !adam && !compact)
+      hipLaunchKernelGGL(w2c_finish_kernel, dim3(1), dim3(64), 0, stream, (const float *)w2c_partials, w2c_blocks, grads->w2c);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

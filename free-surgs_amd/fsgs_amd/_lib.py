@@ -17,6 +17,7 @@ FSGS_ERR_CAPACITY = -2
 FSGS_FLAG_XCD_BANDED_ORDER, FSGS_FLAG_DEPTH_GRAD_ONLY, FSGS_FLAG_SCRATCH_ZEROED, FSGS_FLAG_RGB_DEPTH_ONLY = 1, 2, 4, 8
 FSGS_FLAG_SCRATCH_SELF_CLEAN = 16
 FSGS_FLAG_BLEND_ONE_WAVE, FSGS_FLAG_BLEND_QUAD_WAVES = 32, 64
+FSGS_FLAG_DETERMINISTIC = 128
 FSGS_ERR_HIP = -3
 FSGS_ERR_STATE = -4
 MAX_CHANNELS = 8
@@ -104,6 +105,7 @@ _PROTOTYPES = {
     "fsgs_profile_count": (_i, []),
     "fsgs_profile_name": (C.c_char_p, [_i]),
     "fsgs_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "fsgs_deterministic_scratch_bytes": (_sz, [_i, _i64]),
     "fsgs_raster_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
     "fsgs_raster_state_layout": (_i, [_i, _i, _i, _i64, C.POINTER(_sz)]),
     "fsgs_raster_forward": (

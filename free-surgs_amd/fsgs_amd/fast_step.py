@@ -160,10 +160,16 @@ class FastStepper:
             self._cfgz, self._cfgz_of = z, base
         return self._cfgz
 
-    def _cfg_backward(self, b, trust=True):
+    def _cfg_backward(self, b, trust=True, cap=None):
         """configuration of a backward on buffer set `b`: the accumulator rows are known to be zero (SCRATCH_ZEROED) unless
         the previous backward on them did not run to its end (or trust=False: the call clears them itself); marks the set
-        dirty until _backward_done(b)"""
+        dirty until _backward_done(b).  cap: the forward's pair capacity -- the deterministic backward (tests) keeps a row
+        per pair slot behind the accumulator rows, so the scratch grows with it"""
+        if cap is not None and (self._cfg().flags & _lib.FSGS_FLAG_DETERMINISTIC):
+            need = rasterizer.backward_scratch_bytes(self._cfg(), self.pc.num_points, cap, b.bwd_scratch.numel())
+            if b.bwd_scratch.numel() < need:
+                b.bwd_scratch = torch.zeros((need,), dtype=torch.uint8, device=b.bwd_scratch.device)
+                b.scratch_dirty = False
         cfg = self._cfg() if (b.scratch_dirty or not trust) else self._cfg_zeroed()
         b.scratch_dirty = True
         return cfg
@@ -376,7 +382,7 @@ class FastStepper:
 
     def _render_backward(self, args, state, sbytes, cap, nr, b, d_image, d_depth_sil, grads, gs_grad, cam_grad,
                          param_grads, zeroed=False):
-        cfg = self._cfg_backward(b, trust=zeroed)
+        cfg = self._cfg_backward(b, trust=zeroed, cap=cap)
         rc = self.lib.fsgs_render_backward(C.byref(cfg), self.pc.num_points, C.byref(args), _lib.ptr(b.radii),
                                            _lib.ptr(state), sbytes, cap, nr, _lib.ptr(d_image), _lib.ptr(d_depth_sil),
                                            int(gs_grad), int(cam_grad), int(param_grads), C.byref(grads),
@@ -513,7 +519,7 @@ class FastStepper:
                 ts = timesteps[0]
                 args, state, sbytes, cap, nr, _ = self._view_forward_and_losses(b, ts, corners, dev, H, W, n_patches, 0)
                 adam = self._fused_adam_struct()
-                cfg = self._cfg_backward(b)
+                cfg = self._cfg_backward(b, cap=cap)
                 # statistics and the scalar loss ride in the same launch (no densify_stats / dot kernels)
                 tail, total, _keep = self._step_tail(b, b.term_w, collect_stats)
                 _lib.check(lib.fsgs_render_backward_adam(C.byref(cfg), pc.num_points, C.byref(args), _lib.ptr(b.radii),
@@ -615,7 +621,7 @@ class FastStepper:
                 # the densification statistic comes from view 0 only (train.py:260-263); the other views of the step raise
                 # max_radii2D, as every render() does (gaussian_renderer/__init__.py:79) -- both inside the backward launch
                 m2 = b.means2D_grad if (first and collect_stats) else None
-                cfg = self._cfg_backward(b)
+                cfg = self._cfg_backward(b, cap=cap)
                 tail, loss_k, _keep = self._step_tail(b, b.term_w, (True if first else "radii") if collect_stats else False)
                 # one view per step and a producer-side reducer (N > 1): the per-Gaussian backward goes out in row
                 # chunks, the all-reduce of each chunk starts while the next one is produced (dist.py)

@@ -78,12 +78,37 @@ def blend_variant():
     return _blend_variant
 
 
+# ---- bit-reproducible backward (include/fsgs.h FSGS_FLAG_DETERMINISTIC; tests) -----------------------------------------
+_deterministic = os.environ.get("FSGS_DETERMINISTIC", "") not in ("", "0")
+
+
+def set_deterministic(on):
+    """every configuration struct made from here on asks for the deterministic backward (fixed-order sums instead of float
+    atomics; needs backward_scratch_bytes() of scratch); returns the previous setting"""
+    global _deterministic
+    prev, _deterministic = _deterministic, bool(on)
+    _cfg_cache.clear()
+    return prev
+
+
+def deterministic():
+    return _deterministic
+
+
+def backward_scratch_bytes(cfg, P, max_pairs, rows_bytes):
+    """bytes of `scratch` a backward call with this configuration needs: the per-Gaussian accumulator rows alone, or --
+    FSGS_FLAG_DETERMINISTIC -- rows + one 64-byte row per pair slot + the dL/dw2c partials"""
+    if cfg.flags & _lib.FSGS_FLAG_DETERMINISTIC:
+        return max(int(_lib.load().fsgs_deterministic_scratch_bytes(int(P), int(max_pairs))), rows_bytes)
+    return rows_bytes
+
+
 def make_cfg(settings, channels):
     cfg = _lib.FsgsRasterCfg()
     cfg.image_height = int(settings.image_height)
     cfg.image_width = int(settings.image_width)
     cfg.channels = int(channels)
-    cfg.flags = _BLEND_FLAGS[_blend_variant]
+    cfg.flags = _BLEND_FLAGS[_blend_variant] | (_lib.FSGS_FLAG_DETERMINISTIC if _deterministic else 0)
     cfg.tanfovx = float(settings.tanfovx)
     cfg.tanfovy = float(settings.tanfovy)
     cfg.scale_modifier = float(settings.scale_modifier)
@@ -233,7 +258,7 @@ def raster_backward(st, means3D, colors, scales, rotations, radii, grad_color):
     dmeans3D, dscales, drots = z(P, 3), z(P, 3), z(P, 4)
     if P == 0:
         return dmeans2D, dcolors, dopac, dmeans3D, dscales, drots
-    scratch = torch.empty((P * 32 + 256,), dtype=torch.uint8, device=dev)
+    scratch = torch.empty((backward_scratch_bytes(st.cfg, P, st.max_pairs, P * 32 + 256),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.fsgs_raster_backward(
             C.byref(st.cfg), P, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(scales), _lib.ptr(rotations),

@@ -101,7 +101,7 @@ class _FusedRender(torch.autograd.Function):
         grads.w2c = None if d_w2c is None else d_w2c.data_ptr()
         if P > 0:
             args = _args_struct(*t, active_deg, max_deg)
-            scratch = torch.empty((P * 64 + 512,), dtype=torch.uint8, device=dev)
+            scratch = torch.empty((rasterizer.backward_scratch_bytes(cfg, P, cap, P * 64 + 512),), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.fsgs_render_backward(C.byref(cfg), P, C.byref(args), _lib.ptr(radii), _lib.ptr(state), sbytes,
                                               cap, nr, _lib.ptr(gi), _lib.ptr(gd), int(gs_grad), int(cam_grad),

@@ -81,6 +81,13 @@ enum {
  * A/B measurements); both set = ONE_WAVE. */
 #define FSGS_FLAG_BLEND_ONE_WAVE 32
 #define FSGS_FLAG_BLEND_QUAD_WAVES 64
+/* fsgs_raster_backward / fsgs_render_backward*: bit-reproducible gradients (tests; SURVEY.md s7 "deterministic mode").  The
+ * product backward sums a Gaussian's per-tile totals, and dL/dw2c over the workgroups, with float atomics in arrival
+ * order; with this flag every (tile, Gaussian) pair's totals are stored in a row of their own and summed per Gaussian in a
+ * fixed order (tiles row by row), and dL/dw2c is summed over per-workgroup partials in workgroup order.  `scratch` must
+ * then hold fsgs_deterministic_scratch_bytes(P, max_pairs) bytes (FSGS_ERR_CAPACITY otherwise).  Same results as the
+ * product path up to the order of float additions; slower (a [max_pairs,16] float buffer is cleared and re-read). */
+#define FSGS_FLAG_DETERMINISTIC 128
 
 /* Mirror of GaussianRasterizationSettings (scene/pose_optimizer.py:619-632).
  * viewmatrix / projmatrix are in the reference's TRANSPOSED storage:
@@ -150,6 +157,10 @@ int fsgs_profile_read(int id, double *total_ms, int64_t *launches);
  * `max_pairs` (tile, Gaussian) pairs.  `state` must stay alive and untouched from
  * forward to its backward (it plays the role of UPSTREAM's geomBuffer /
  * binningBuffer / imgBuffer); `scratch` is only used during forward. */
+/* bytes of `scratch` a backward call with FSGS_FLAG_DETERMINISTIC needs (covers both fsgs_raster_backward and
+ * fsgs_render_backward*): the per-Gaussian rows + one 64-byte row per pair slot + the per-workgroup dL/dw2c partials */
+size_t fsgs_deterministic_scratch_bytes(int P, int64_t max_pairs);
+
 int fsgs_raster_sizes(int P, int width, int height, int64_t max_pairs,
                       size_t *state_bytes, size_t *scratch_bytes);
 
