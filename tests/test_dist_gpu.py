@@ -52,9 +52,9 @@ def _corners(H, W, dev):
     return (torch.randint(0, H - 128, (n,), generator=g).to(dev), torch.randint(0, W - 128, (n,), generator=g).to(dev))
 
 
-def _worker(rank, world, port, out_dir, mode):
+def _worker(rank, world, port, out_dir, mode, deterministic=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK="0", FSGS_DETERMINISTIC="1" if deterministic else "0")
     from fsgs_amd import dist as fdist
     from fsgs_amd.fast_step import FastStepper
     from fsgs_amd.model import PARAM_NAMES
@@ -111,6 +111,35 @@ def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
         # Adam divides by sqrt(v): elements whose gradient is rounding noise can move by lr either way
         frac_off = ((a[k] - ref).abs() > 1e-4 * (ref.abs() + 1e-3)).float().mean().item()
         assert frac_off < 2e-3, (k, frac_off)
+
+
+@pytest.mark.parametrize("mode", ["compact", "direct", "producer"])
+def test_two_deterministic_ranks_equal_the_two_view_step_bit_for_bit(tmp_path, mode):
+    """FSGS_FLAG_DETERMINISTIC (VERDICT r4 #4b): with the backward's float atomics gone, the frame-sharded step IS the
+    single-process two-view step -- the same two compact gradients, summed once (a + b by the all-reduce, a + b by
+    fsgs_adam_step_compact_sum), the same Adam -- so after two steps every parameter has the same bits on both ranks and in
+    the single process.  (Eight ranks: a ring's order of additions differs from the single process's; that case keeps the
+    tolerance of the test below.)"""
+    from fsgs_amd import rasterizer
+    from fsgs_amd.fast_step import FastStepper
+    from fsgs_amd.model import PARAM_NAMES
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode, True), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    prev = rasterizer.set_deterministic(True)
+    try:
+        pc, poses, frames, (H, W) = _world("cuda:0")
+        cr = _corners(H, W, "cuda:0")
+        fs = FastStepper(pc, poses, frames)
+        for step in range(2):
+            fs.mapping_step([0, 1], corners=cr)
+        torch.cuda.synchronize()
+    finally:
+        rasterizer.set_deterministic(prev)
+    for k in PARAM_NAMES:
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], pc.params[k].detach().cpu()), k
 
 
 @pytest.mark.parametrize("mode", ["compact", "direct", "producer"])
