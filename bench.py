@@ -149,10 +149,75 @@ def cpu_baseline(sc, cam, pc_sh_degree, seconds_budget=30.0):
         if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
             break
     dt = (time.time() - t0) / n
-    return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
-            "raster_fwd_ms_per_pass": 1e3 * t_fwd / (2 * n), "raster_bwd_ms_per_pass": 1e3 * t_bwd / (2 * n),
-            "sample": "%d full step(s) of the rasteriser part only (2 passes fwd+bwd, %dx%d, P=%d, R=%d), "
-                      "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
+    out = {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+           "raster_fwd_ms_per_pass": 1e3 * t_fwd / (2 * n), "raster_bwd_ms_per_pass": 1e3 * t_bwd / (2 * n),
+           "sample": "%d full step(s) of the rasteriser part only (2 passes fwd+bwd, %dx%d, P=%d, R=%d), "
+                     "oracle/raster_oracle.c with OpenMP" % (n, W, H, len(sc["_xyz"]), R)}
+
+    # ---- the rest of SURVEY.md s8(d)'s CPU set: one thread, C1, and the torch-CPU losses -------------
+    def one_pass(scene, camera, colours, threads):
+        o.set_threads(threads)
+        s_, r_, op_ = synth.activate(scene)
+        h, w = camera["image_height"], camera["image_width"]
+        g = (np.random.default_rng(0).uniform(-1, 1, (3, h, w)) / (3 * h * w)).astype(np.float32)
+        ta = time.time()
+        st_ = o.raster_forward(camera, scene["_xyz"], colours, op_.reshape(-1), s_, r_)[3]
+        tb = time.time()
+        o.raster_backward(st_, g)
+        return {"raster_fwd_ms_per_pass": 1e3 * (tb - ta), "raster_bwd_ms_per_pass": 1e3 * (time.time() - tb),
+                "threads": threads, "num_rendered_rect_rule": int(st_.num_rendered)}
+
+    try:
+        if len(sc["_xyz"]) <= 400_000:  # (C4 on one thread is ~40 s: not inside a bench run)
+            out["one_thread"] = one_pass(sc, cam, col, 1)
+            out["one_thread"]["sample"] = ("ONE RGB pass fwd + bwd on one thread at this configuration; a step's rasteriser part is two "
+                                           "such passes, i.e. ~%.0f ms extrapolated" % (2 * (out["one_thread"]["raster_fwd_ms_per_pass"] +
+                                                                                             out["one_thread"]["raster_bwd_ms_per_pass"])))
+        w1, h1, p1, _ = CONFIGS["C1"]
+        if (W, H, len(sc["_xyz"])) != (w1, h1, p1):
+            sc1 = synth.init_scene(w1, h1, p1, seed=0)  # (scales from the oracle's own KNN: this leg must not touch the GPU)
+            cam1 = synth.make_camera(w1, h1)
+            col1 = np.clip(sc1["_features_dc"][:, 0, :] * synth.SH_C0 + 0.5, 0, None).astype(np.float32)
+            out["c1"] = {"all_cores": one_pass(sc1, cam1, col1, cores), "one_thread": one_pass(sc1, cam1, col1, 1),
+                         "sample": "ONE RGB pass fwd + bwd at C1 (640x512, 20 000 init Gaussians)"}
+        out["losses_torch_cpu_ms"] = losses_torch_cpu(H, W, cores)
+    except Exception as e:  # a reported baseline, never a reason to lose the line
+        out["extras_error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        o.set_threads(cores)
+    return out
+
+
+def losses_torch_cpu(H, W, threads):
+    """the build's own plain-torch restatement of the three mapping losses (fsgs_amd/losses.py *_torch: utils/loss_utils.py:41-127)
+    forward + backward on the host cores -- the CPU counterpart of the fused loss kernels"""
+    from fsgs_amd import losses
+
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, int(threads)))
+    try:
+        g = torch.Generator().manual_seed(0)
+        img = torch.rand(3, H, W, generator=g, requires_grad=True)
+        gt = torch.rand(3, H, W, generator=g)
+        dep = (torch.rand(H, W, generator=g) + 0.5).requires_grad_(True)
+        mono = torch.rand(H, W, generator=g) + 0.5
+        corners = losses.draw_patch_corners(H, W, 128, 0.5, "cpu")
+        res = {}
+        for name, fn in (("rgb_l1_ssim", lambda: losses.rgb_loss_torch(img, gt)),
+                         ("pearson_global_and_local", lambda: losses.pearson_torch(mono, dep) * 0.05 +
+                          losses.local_pearson_torch(mono, dep, 128, 0.5, corners) * 0.15)):
+            fn().backward()  # warm-up
+            t0 = time.time()
+            n = 0
+            while n < 3:
+                fn().backward()
+                n += 1
+            res[name] = 1e3 * (time.time() - t0) / n
+        res["threads"] = int(threads)
+        res["what"] = "forward + backward, %dx%d, torch CPU" % (W, H)
+        return res
+    finally:
+        torch.set_num_threads(old)
 
 
 def harness_extra(cfg_name, device, scene="default"):
@@ -265,7 +330,7 @@ def harness_extra(cfg_name, device, scene="default"):
 
 
 
-def comm_model(nbytes, world, step_ms_one_gpu=0.651):
+def comm_model(nbytes, world, step_ms_one_gpu):
     """What DESIGN.md s6 predicts for the step's one exchange on a fully connected xGMI node, stated in the line so that a
     scaling record can be judged against it (VERDICT r3 #2c).  t = launches * a_launch + steps * a_step + wire_bytes / b:
     every GPU has a link to every other (7 links at N = 8), both routes can keep all N - 1 links of a GPU busy, so the
@@ -281,9 +346,9 @@ def comm_model(nbytes, world, step_ms_one_gpu=0.651):
             "params": {"link_GBps_per_direction": link_GBps, "links_used": world - 1, "launch_ms": a_launch,
                        "hop_ms": a_step, "bytes": nbytes},
             "step_ms": {"one_collective": step_ms_one_gpu + best, "per_rank_path_without_exchange": step_ms_one_gpu},
-            "weak_scaling_efficiency": 0.638 / (step_ms_one_gpu + best),
-            "note": "a model (DESIGN.md s6), not a measurement: no multi-GPU node has run this code; 0.638 / 0.651 ms are the "
-                    "round-3 single-GPU step and its compact-gradient variant at C2"}
+            "weak_scaling_efficiency": step_ms_one_gpu / (step_ms_one_gpu + best),
+            "note": "a model (DESIGN.md s6) of the exchange on top of THIS run's own one-rank step (comm.one_rank: the same "
+                    "configuration and scene, timed on every rank without an exchange before the N-rank loop), not a measurement"}
 
 
 
@@ -527,8 +592,12 @@ def main():
                          "all-reduce while the next is produced, Adam per chunk behind it (dist.ProducerPipelinedReducer); "
                          "default one collective in the first timed loop; every N > 1 run then times the x4 pipelined route over "
                          "the same K steps as well and reports it beside the configured route (exchange_routes_ms_per_step); `value` is always the configured route")
-    ap.add_argument("--ar-algo", default="rccl", choices=["rccl", "direct"],
-                    help="N > 1: the step's exchange -- `rccl`: one torch.distributed all_reduce (RCCL picks algorithm and "
+    ap.add_argument("--smoke", action="store_true",
+                    help="allow FSGS_DIST_ONE_GPU=1 (every rank on device 0 over gloo): a smoke test of the N > 1 code path on a "
+                         "one-GPU box.  Without this flag a run with that variable set is refused -- its line must never be "
+                         "mistaken for a scaling point")
+    ap.add_argument("--ar-algo", default="all_reduce", choices=["all_reduce", "rccl", "direct"],
+                    help="N > 1: the step's exchange -- `all_reduce` (`rccl` = the same, the name of rounds 2-4): one torch.distributed all_reduce (the backend picks algorithm and "
                          "protocol); `direct`: dist.DirectAllReduce, an explicit all-to-all of shards + local sum + all-gather "
                          "over the point-to-point xGMI links (SURVEY s5).  The extras of every N > 1 run time both alone")
     ap.add_argument("--dp-path", action="store_true", help="N = 1 only: run the per-rank code path of N > 1 (compact gradient + Adam from it) with a no-op all-reduce")
@@ -546,6 +615,12 @@ def main():
                     help="HIP-event time every n-th launch of the dominant kernels inside the timed region (each timed "
                          "launch costs two event packets of dispatch gap); 1 = every launch.  Keep it coprime with the 8-frame cycle")
     args = ap.parse_args()
+    if args.ar_algo == "rccl":
+        args.ar_algo = "all_reduce"  # the ALGORITHM is what the route fields name; the transport is comm.backend
+    if os.environ.get("FSGS_DIST_ONE_GPU") == "1" and args.gpus > 1 and not args.smoke:
+        sys.stderr.write("bench.py: FSGS_DIST_ONE_GPU=1 puts every rank on one GPU over gloo -- a smoke test, not a scaling "
+                         "point; pass --smoke to run it\n")
+        sys.exit(2)
 
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         sys.exit(self_launch(args.gpus))  # no launcher around us: start the N ranks ourselves
@@ -635,6 +710,28 @@ def main():
             else:
                 torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: the one-rank step of THIS box, configuration and scene, timed on every rank at once (no exchange: the N = 1
+    # code path with Adam fused into the backward, on a cloud of its own so that the replicas stay identical) before the
+    # N-rank loop -- efficiency_measured = value / (N x this), and the exchange model is laid on top of it
+    one_rank = None
+    if world > 1 and use_fast:
+        pc1, poses1, frames1, _c1, _s1 = build_problem(args.config, device, rank, world, scene=args.scene, texture=texture)
+        st1 = FastStepper(pc1, poses1, frames1)
+        k1 = max(10, min(args.steps, 100))
+        for it in range(min(args.warmup, 10)):
+            st1.mapping_step([(rank + it) % n_frames], collect_stats=not args.no_stats)
+        barrier()
+        t1 = time.perf_counter()
+        for it in range(k1):
+            st1.mapping_step([(rank + it) % n_frames], collect_stats=not args.no_stats)
+        barrier()
+        d1 = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(d1, op=torch.distributed.ReduceOp.MAX)
+        one_rank = {"ms_per_step": float(d1.item()) / k1 * 1e3, "iters_per_sec": k1 / float(d1.item()), "steps": k1,
+                    "what": "the N = 1 step (no exchange, Adam fused into the backward) on every rank at once, max over ranks"}
+        del st1, pc1, poses1, frames1
+        torch.cuda.empty_cache()
 
     for it in range(args.warmup):
         one_step(it)
@@ -974,10 +1071,17 @@ def main():
         probe("chunks4_ms", lambda: [torch.distributed.all_reduce(c) for c in chunks])
         direct = fdist.DirectAllReduce()
         probe("direct_ms", lambda: direct(buf))  # all-to-all of shards + local sum + all-gather (--ar-algo direct)
-        comm["timed_route"] = "pipelined x%d" % args.ar_chunks if args.ar_chunks > 1 else args.ar_algo
+        comm["timed_route"] = "pipelined x%d" % args.ar_chunks if args.ar_chunks > 1 else args.ar_algo  # (the algorithm; the transport is comm.backend)
         tiny = torch.zeros((1024,), dtype=torch.float32, device=device)
         probe("latency_4KB_ms", lambda: torch.distributed.all_reduce(tiny), reps=50)
-        comm["expected"] = comm_model(nfloat * 4, world)
+        comm["one_rank"] = one_rank
+        step1 = one_rank["ms_per_step"] if one_rank else None
+        comm["expected"] = comm_model(nfloat * 4, world, step1) if step1 else None
+        comm["efficiency_expected"] = comm["expected"]["weak_scaling_efficiency"] if step1 else None
+        # measured weak-scaling efficiency of THIS run: whole-job rate over N times the one-rank rate of the same box
+        comm["efficiency_measured"] = (args.steps * world / dt) / (world * one_rank["iters_per_sec"]) if one_rank else None
+        if os.environ.get("FSGS_DIST_ONE_GPU") == "1":
+            comm["efficiency_note"] = "one-GPU smoke (--smoke): every rank shares one device; not a scaling point"
         comm["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "OMP_NUM"))}
         try:
             comm["rccl_info"] = rccl_info_lines()
