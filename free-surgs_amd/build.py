@@ -33,13 +33,13 @@ DIAG = os.environ.get("FSGS_DIAG") == "1"
 # lib/diag/libfsgs_hip.foo.so from objects of its own; FSGS_LIB_PATH=<that file> makes fsgs_amd._lib load it.
 EXTRA = os.environ.get("FSGS_CFLAGS", "").split()
 TAG = os.environ.get("FSGS_LIB_TAG", "")
-if EXTRA and not (TAG and DIAG):
-    raise SystemExit("FSGS_CFLAGS needs FSGS_DIAG=1 and FSGS_LIB_TAG (the product library is only ever built with the default flags)")
-if TAG and not DIAG:
-    raise SystemExit("FSGS_LIB_TAG needs FSGS_DIAG=1 (tagged libraries are diagnostics builds)")
+if EXTRA and not TAG:
+    raise SystemExit("FSGS_CFLAGS needs FSGS_LIB_TAG (the product library is only ever built with the default flags)")
 DIAG_DIR = os.path.join(OUT_DIR, "diag")
-if DIAG:
-    FLAGS.append("-DFSGS_DIAG_HOOKS")
+if DIAG or TAG:
+    # FSGS_LIB_TAG alone (no FSGS_DIAG): the PRODUCT kernels + FSGS_CFLAGS, for a clean A/B of a code variant
+    if DIAG:
+        FLAGS.append("-DFSGS_DIAG_HOOKS")
     FLAGS += EXTRA
     OBJ_DIR = DIAG_DIR
     LIB = os.path.join(DIAG_DIR, "libfsgs_hip.%s.so" % (TAG or "diag"))
