@@ -30,6 +30,12 @@ from tests import ref_cpu
 # leave the fixture by 0.47e-4 .. 3.32e-4 after the densification (median 1.8e-4, 99th percentile 3.25e-4; tracking losses
 # <= 2.8e-4) and by <= 1.3e-5 before it.  The bound is 1.5 x the worst of those 200.  (Rounds 2-3 carried 5e-4, then 2e-3.)
 POST_DENSIFY_RTOL = 5e-4
+# Round 5: the backward of a small tile grid now runs four waves per tile (csrc/raster_kernels.h), i.e. ~2x as many,
+# smaller float atomics per Gaussian: 180 further runs (profiles/r05_pin_deviation.txt) leave the fixture by 0.33e-4 .. 5.84e-4
+# (median 1.6e-4 .. 2.8e-4 depending on the batch; forced back to one wave per tile: <= 3.1e-4 as before) -- the same size as
+# the reference's own 0.9e-4 .. 5.4e-4.  The product path is therefore held to 1e-3 (1.7 x the worst of those), and the bound
+# above is kept for FSGS_FLAG_DETERMINISTIC, whose ONE reproducible trajectory sits 2.73e-4 (mapping) / 2.88e-4 (tracking) away.
+POST_DENSIFY_RTOL_PRODUCT = 1e-3
 # ... and how far the REFERENCE moves against itself there (this CPU harness with 8 OpenMP threads in the oracle's backward
 # against its own 1-thread fixture: 0.9e-4 .. 5.4e-4 over the thread counts tried, 6e-7 before the densification;
 # tests/test_harness_pin_cpu.py): the yardstick that says the number above is not a property of the HIP path
@@ -38,6 +44,11 @@ REFERENCE_SELF_RTOL = 1e-3
 # Gaussian, not only for the children of a densification): 100 runs leave the fixture by up to 7.0e-4 in a per-iteration loss
 # (median of the per-run maximum 3.0e-4, 90th percentile 4.8e-4; profiles/r04_pin_global_deviation_100runs.txt).  1.5 x the worst.
 GLOBAL_PHASE_RTOL = 1.1e-3
+# Round 5 (four-waves-per-tile backward on this small grid): 100 further runs leave it by up to 8.9e-4 (median of the per-run
+# maximum 4.0e-4, 90th percentile 5.8e-4; profiles/r05_pin_global_deviation_100runs.txt) -> 1.5 x the worst for the product
+# path; FSGS_FLAG_DETERMINISTIC's one trajectory sits 1.9e-4 away and is held to 5e-4.
+GLOBAL_PHASE_RTOL_PRODUCT = 1.4e-3
+GLOBAL_PHASE_RTOL_DETERMINISTIC = 5e-4
 
 
 @contextlib.contextmanager
