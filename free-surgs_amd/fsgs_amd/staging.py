@@ -50,7 +50,14 @@ class StagedLane:
         # frames whose copy was started by prefetch(protect=True) and that nobody has looked up yet: not evicted (ADVICE r3:
         # progressive_run asks for frame t+1 a whole frame cycle ahead, and the ~30 random keyframes of the mapping
         # iterations in between would otherwise push it out of a 4-buffer lane before it is read)
-        self.protected = set()
+        # A protection is released by the frame's first lookup, by clear_protected() (Runner calls it when a phase ends), or
+        # by AGE: a prefetch that is never read (an early exit, an exception, a caller asking the wrong lane) would otherwise
+        # pin one buffer for the life of the lane, and in a small lane the frame in use becomes the only eviction victim
+        # (ADVICE r4).  protected: frame -> value of the lane's load counter when it was protected; older than
+        # PROTECT_LOADS loads = expired.  A lane needs >= 4 buffers for Runner's access pattern (frame t, keyframe, the two
+        # look-aheads): StagedFrames clamps to that, a bare StagedLane with less simply protects less (see prefetch).
+        self.protected = {}
+        self.loads = 0
         self.free = []
         self.hits = self.misses = self.prefetched = 0
         first = next((h for h in self.host if h is not None), None)
@@ -76,12 +83,20 @@ class StagedLane:
     def _victim(self):
         """least recently used resident frame that is not protected (the oldest protected one when all are: capacity
         smaller than the number of outstanding prefetches)"""
+        for k in [k for k, born in self.protected.items() if self.loads - born > self.PROTECT_LOADS]:
+            del self.protected[k]
         for k in self.cache:
             if k not in self.protected:
                 return k
         k = next(iter(self.cache))
-        self.protected.discard(k)
+        self.protected.pop(k, None)
         return k
+
+    PROTECT_LOADS = 64  # loads a never-read prefetch stays protected for (a frame cycle is ~30 keyframe loads)
+
+    def clear_protected(self):
+        """release every prefetch protection (the frames stay resident and age out in least-recently-used order)"""
+        self.protected.clear()
 
     def _load(self, i, asynchronous, fence=None):
         evicted = not self.free
@@ -109,6 +124,7 @@ class StagedLane:
         else:
             buf.copy_(self.host[i])
         self.cache[i] = (buf, done)
+        self.loads += 1
 
     def prefetch(self, i, fence=None, protect=True):
         """start copying frame i (no-op when it is resident, out of range or absent).  A prefetched frame stays resident
@@ -117,7 +133,7 @@ class StagedLane:
         if i is None or i < 0 or i >= len(self.host) or self.host[i] is None:
             return
         if protect and len(self.protected) < self.capacity - 1:  # (at least one buffer stays evictable)
-            self.protected.add(int(i))
+            self.protected[int(i)] = self.loads
         if i in self.cache:
             self.cache.move_to_end(i)
             return
@@ -136,7 +152,7 @@ class StagedLane:
             i += len(self.host)
         if self.host[i] is None:
             return None
-        self.protected.discard(i)
+        self.protected.pop(i, None)
         if i in self.cache:
             self.hits += 1
             self.cache.move_to_end(i)
@@ -212,6 +228,12 @@ class StagedFrames(FrameData):
         if flows and self.flows_fw is not None:
             self.flows_fw.prefetch(t - 1, fence, protect)
             self.flows_fw.prefetch(t - 2, fence, protect)
+
+    def clear_protected(self):
+        """release the prefetch protections of every lane (end of a phase: whatever was fetched ahead and not read may go)"""
+        for lane in (self.colors, self.monodeps, self.flows_fw):
+            if lane is not None:
+                lane.clear_protected()
 
     def stats(self):
         lanes = {"colors": self.colors, "monodeps": self.monodeps, "flows_fw": self.flows_fw}

@@ -399,8 +399,17 @@ class Runner:
 
     def mapping(self, cur_t, mapping_iter, progressive, want_pkg=True):
         """want_pkg=False (global_run, train.py:386-393: the reference copies the render to the host there and nothing reads
-        it): no render is handed back.  Otherwise the returned `render` / `render_dep` are VIEWS of the step driver's
-        buffers, valid until the next step is enqueued (progressive_run copies what it keeps, _stored_depth)."""
+        it): no render is handed back.  Otherwise `render` / `render_dep` of the last iteration, as tensors of the caller's
+        own (the zero-copy hand-out of the step driver's buffers is _mapping(borrow=True), for callers inside this class
+        that copy what they keep before the next step: ADVICE r4)."""
+        pkg = self._mapping(cur_t, mapping_iter, progressive, want_pkg)
+        if pkg is not None and pkg.pop("views_of_step_buffers", False):
+            pkg = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in pkg.items()}
+        return pkg
+
+    def _mapping(self, cur_t, mapping_iter, progressive, want_pkg=True, borrow=False):
+        """borrow=True: the returned `render` / `render_dep` may be VIEWS of the step driver's buffers (marked
+        "views_of_step_buffers"), valid until the next step is enqueued."""
         views = 2 if (progressive and cur_t != 0) else 1
         self.pc.optimizer.zero_grad(set_to_none=True)
         pkg = None
@@ -448,6 +457,8 @@ class Runner:
             # iteration's optimizer step (train.py:236-265, 291): exactly what the step driver still holds -- handed out
             # as views (round 3 cloned 21 MB here after every call, global_run's single iterations included)
             pkg = {"render": self.fast.last["image"], "render_dep": self.fast.last["depth_sil"][0], "views_of_step_buffers": True}
+            if not borrow:
+                pkg = {"render": pkg["render"].clone(), "render_dep": pkg["render_dep"].clone()}
         if pkg is None:
             with torch.no_grad():
                 pkg = (render if self.fused else render_two_pass)(self.poses, cur_t, self.pc, gs_grad=False, cam_grad=False)
@@ -542,8 +553,8 @@ class Runner:
                     self.pc.oneupSHdegree()
                 it = self.first_mapping_iter if t == 0 else self.mapping_iter
                 with self._phase("frame.mapping", t):
-                    pkg = self.mapping(t, it, progressive=True)
-                    self.frames.pred_depths[t] = self._stored_depth(pkg)
+                    pkg = self._mapping(t, it, progressive=True, borrow=True)
+                    self.frames.pred_depths[t] = self._stored_depth(pkg)  # (copies: pkg may alias the step driver's buffers)
                 self.keyframes.append(t)
             elif self.frames.pred_depths[t] is None:
                 if self.test_frame_quirks:  # never rendered upstream: the next frame's flow loss sees no valid depth
@@ -553,6 +564,14 @@ class Runner:
                     with torch.no_grad():
                         pkg = (render if self.fused else render_two_pass)(self.poses, t, self.pc, False, False)
                     self.frames.pred_depths[t] = self._stored_depth(pkg)
+        self._release_prefetches()
+
+    def _release_prefetches(self):
+        """end of a phase: look-aheads that were fetched and never read (the frame behind the last one, a keyframe drawn for
+        an iteration that did not run) must not keep their buffers pinned (staging.StagedLane.protected)"""
+        rel = getattr(self.frames, "clear_protected", None)
+        if rel is not None:
+            rel()
 
     def _prefetch(self, t, flows=True, **lanes):
         pf = getattr(self.frames, "prefetch", None)
@@ -599,6 +618,7 @@ class Runner:
                 from . import checkpoint
 
                 checkpoint.save(model_path, it, self.pc, self.poses, np.asarray(self.frames.K, np.float32))
+        self._release_prefetches()
 
     def validation(self):
         from . import metrics

@@ -581,12 +581,13 @@ def test_comm_model_of_the_bench_line():
     nbytes = 300_000 * 14 * 4
     prev = None
     for n in (2, 4, 8):
-        m = bench.comm_model(nbytes, n)
+        m = bench.comm_model(nbytes, n, 0.62)  # on top of a measured one-rank step (here: round 5's C2 step, ms)
         wire = 2.0 * (n - 1) / n * nbytes / ((n - 1) * 64e9) * 1e3
         assert abs(m["wire_ms"] - wire) < 1e-12 and m["rccl_ms"] > wire and m["direct_ms"] > wire
         assert abs((m["rccl_ms"] - m["wire_ms"]) - (0.020 + 2 * (n - 1) * 0.005)) < 1e-12
         assert 0.5 < m["weak_scaling_efficiency"] < 1.0
+        assert abs(m["weak_scaling_efficiency"] - 0.62 / (0.62 + min(m["rccl_ms"], m["direct_ms"]))) < 1e-12
         if prev is not None:
             assert m["wire_ms"] < prev["wire_ms"] and m["weak_scaling_efficiency"] > prev["weak_scaling_efficiency"]
         prev = m
-    assert bench.comm_model(nbytes, 8)["direct_ms"] < bench.comm_model(nbytes, 8)["rccl_ms"]  # 14 hops against 2
+    assert bench.comm_model(nbytes, 8, 0.62)["direct_ms"] < bench.comm_model(nbytes, 8, 0.62)["rccl_ms"]  # 14 hops against 2

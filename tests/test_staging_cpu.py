@@ -70,7 +70,7 @@ def test_a_protected_prefetch_survives_the_keyframes_pulled_through_the_lane_unt
     small = StagedLane(_items(6), "cpu", capacity=2)
     small.prefetch(0)
     small.prefetch(1)
-    assert small.protected == {0}
+    assert set(small.protected) == {0}
     small.prefetch(2, protect=False)
     assert set(small.cache) == {0, 2} and float(small[0].mean()) == 0.0
 
@@ -238,3 +238,33 @@ def test_progressive_mapping_draws_its_keyframes_in_the_reference_order_too():
     assert run.rng.random() == want_rng.random()
     run.mapping(0, 4, progressive=True)  # frame 0 is mapped alone: no draw at all
     assert run.fast.seen[-4:] == [[0]] * 4 and run.rng.random() == want_rng.random()
+
+
+def test_a_prefetch_that_is_never_read_does_not_pin_its_buffer_forever():
+    """protections end with the first lookup, with clear_protected() (Runner: end of a phase), or by age --
+    PROTECT_LOADS loads after they were made -- so an abandoned look-ahead cannot make the frame in use the only
+    eviction victim of a small lane"""
+    import torch
+
+    from fsgs_amd.staging import StagedLane
+
+    host = [torch.full((2, 2), float(i)) for i in range(40)]
+    lane = StagedLane(host, "cpu", 3)
+    lane.prefetch(30)
+    lane.prefetch(31)  # capacity - 1 protections at most
+    assert set(lane.protected) == {30, 31}
+    for rep in range(4):  # the frame in use keeps missing: it is the only victim
+        assert float(lane[1][0, 0]) == 1.0 and float(lane[2][0, 0]) == 2.0
+    assert lane.misses == 8 and 30 in lane.cache and 31 in lane.cache
+    lane.clear_protected()
+    assert not lane.protected
+    m = lane.misses
+    for rep in range(4):
+        lane[1], lane[2]
+    assert lane.misses - m <= 2  # both fit beside each other now
+    # ageing: a fresh protection expires after PROTECT_LOADS further loads
+    lane.prefetch(33)
+    assert 33 in lane.protected
+    for i in range(lane.PROTECT_LOADS + 4):
+        lane[i % 20]
+    assert 33 not in lane.protected and 33 not in lane.cache
