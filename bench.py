@@ -878,7 +878,8 @@ def main():
                 # the second issue-bound kernel, same definitions: blend_fwd (HIP events of this run; counters offline)
                 fms, fl = prof.get("blend_fwd", (0.0, 0))
                 Cf = 4 if (use_fast and C == 6 and getattr(stepper, "mapping_planes4", False)) else C  # planes the step's forward blends
-                fhits = [k for k in pmc["kernels"] if k.startswith("blend_fwd_kernel<%d" % Cf)]
+                # (round 5: the forward blends with four waves per tile at every size -- blend_fwd_quad_kernel)
+                fhits = [k for k in pmc["kernels"] if k.startswith(("blend_fwd_quad_kernel<%d" % Cf, "blend_fwd_kernel<%d" % Cf))]
                 if fl and len(fhits) == 1:
                     fent = pmc["kernels"][fhits[0]]
                     f_alg = R * (4 + 24 + 4 * Cf) + H * W * (4 * Cf + 4 + 8)

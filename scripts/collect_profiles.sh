@@ -6,6 +6,9 @@ cd "$(dirname "$0")/.."
 tag=${1:-r02}
 for n in bench bench_C1 bench_C4 bench_C4_densify bench_dp_path bench_profile_all; do cp gpurun_out/$n.json profiles/${tag}_$n.json; done
 cp gpurun_out/bench_kernel_stats.csv profiles/${tag}_bench_kernel_stats.csv
+for n in C1 dense; do [ -f gpurun_out/bench_kernel_stats_$n.csv ] && cp gpurun_out/bench_kernel_stats_$n.csv profiles/${tag}_bench_kernel_stats_$n.csv; done
+[ -f gpurun_out/bench_dense_profile_all.json ] && cp gpurun_out/bench_dense_profile_all.json profiles/${tag}_bench_dense_profile_all.json
+[ -f gpurun_out/trace_step_C1.txt ] && cp gpurun_out/trace_step_C1.txt profiles/${tag}_step_timeline_C1.txt
 cp gpurun_out/pmc_FETCH_SIZE_summary.csv profiles/${tag}_pmc_FETCH_SIZE_summary.csv
 cp gpurun_out/pmc_WRITE_SIZE_summary.csv profiles/${tag}_pmc_WRITE_SIZE_summary.csv
 cp gpurun_out/sq_summary.txt profiles/${tag}_sq_counters.txt

@@ -55,7 +55,7 @@ queues = {}
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"([A-Za-z_0-9:]+(<[0-9a-z, ]+>)?)", name); name = (m.group(1) if m else name)[-48:]
+    m = re.match(r"([A-Za-z_0-9:]+(<[0-9a-z, ]+>)?)", name); name = (m.group(1) if m else name)[-64:]
     q = queues.setdefault(r[qcol], len(queues)) if qcol else 0
     P("%8.1f .. %8.1f  dur %7.1f  q%d %s%s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, "    " * q, name))
 PY

@@ -5,7 +5,7 @@ sys.path.insert(0, "free-surgs_amd"); sys.path.insert(0, ".")
 import bench
 from fsgs_amd.fast_step import FastStepper
 
-pc, poses, frames, cam, sc = bench.build_problem("C2", "cuda", 0, 1)
+pc, poses, frames, cam, sc = bench.build_problem(sys.argv[1] if len(sys.argv) > 1 else "C2", "cuda", 0, 1)
 fs = FastStepper(pc, poses, frames)
 orig = fs._render_forward
 acc = {"fwd": 0.0, "n": 0}

@@ -36,7 +36,8 @@ try:
     for line in open("gpurun_out/sq_summary.txt"):
         m = re.match(r"(\S.*?)\s+launches \d+ (.*)", line)
         if m:
-            sq[m.group(1).strip()] = {k: float(v) for k, v in (kv.split("=") for kv in m.group(2).split())}
+            # (one line per kernel and --pmc pass: merge the passes)
+            sq.setdefault(m.group(1).strip(), {}).update({k: float(v) for k, v in (kv.split("=") for kv in m.group(2).split())})
 except FileNotFoundError:
     pass
 HW = W * H
