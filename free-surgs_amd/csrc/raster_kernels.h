@@ -1940,13 +1940,21 @@ inline DetLayout det_layout(int P, int64_t max_pairs) {
 //   * backward: four waves while one wave per tile cannot fill the chip (5 waves x 1024 SIMDs = 5120 one-wave workgroups);
 //     from there on the one-wave kernel's single transposing reduction per pair (instead of one per quadrant reached)
 //     is worth more than the parallelism.
+// The per-kernel event timings above place the backward's crossover between 3808 and 5120 tiles; whole-step A/Bs on one box
+// without events (scripts/dev/ab_tracking.sh, threshold 4096 against 2560; profiles/r05_blend_flavours.txt) narrow it down:
+//     mapping step     2880 tiles: 0.350 (four waves) vs 0.366 ms    3808 tiles: 0.476 vs 0.468   -> crossover ~3300
+//     tracking step    2880 tiles: 0.279 vs 0.316                    3808 tiles: 0.358 vs 0.373; 5120 (C2): 0.485 vs 0.471 -> ~4400
+// (the pose-only backward's reduction is the cheap 5-of-8 one, so a reduction per quadrant costs it less)
 #ifndef FSGS_QUAD_BWD_MAX_TILES
-#define FSGS_QUAD_BWD_MAX_TILES 4096
+#define FSGS_QUAD_BWD_MAX_TILES 3328
 #endif
-inline bool use_quad_waves(const CamParams &cam, int ntiles, bool backward) {
+#ifndef FSGS_QUAD_BWD_POSE_MAX_TILES
+#define FSGS_QUAD_BWD_POSE_MAX_TILES 4352
+#endif
+inline bool use_quad_waves(const CamParams &cam, int ntiles, bool backward, bool pose_only = false) {
   if (cam.flags & FSGS_FLAG_BLEND_ONE_WAVE) return false;
   if (cam.flags & FSGS_FLAG_BLEND_QUAD_WAVES) return true;
-  return backward ? ntiles <= FSGS_QUAD_BWD_MAX_TILES : true;
+  return backward ? ntiles <= (pose_only ? FSGS_QUAD_BWD_POSE_MAX_TILES : FSGS_QUAD_BWD_MAX_TILES) : true;
 }
 
 template <bool DIAG>
@@ -2006,7 +2014,7 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
                        det->radii, det->xy, det->depth, ranges, plist, (const float *)det->pair_rows, grad_acc, dcolors);
     return 0;
   }
-  if (use_quad_waves(cam, ntiles, true)) {
+  if (use_quad_waves(cam, ntiles, true, POSE_ONLY)) {
     hipLaunchKernelGGL((blend_bwd_quad_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW>), dim3(ntiles), dim3(256), 0, s, cam, ntiles,
                        order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors, clear16);
     return 0;

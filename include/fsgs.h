@@ -76,8 +76,8 @@ enum {
 #define FSGS_FLAG_RGB_DEPTH_ONLY 8
 /* Flavour of the blend kernels (forward and backward of fsgs_raster_* and fsgs_render_*; results agree: the forward's are
  * bit-identical, the backward's differ by the order of float additions).  Default (neither bit): the forward blends with
- * four waves per 16x16 tile (one 8x8 quadrant per wave), the backward does while one wave per tile could not fill the chip
- * (<= 4096 tiles, e.g. 640x512) and uses one wave per tile above.  The bits force one flavour for both directions (tests,
+ * four waves per 16x16 tile (one 8x8 quadrant per wave), the backward does on small tile grids, which one wave per tile
+ * cannot fill the chip with (<= 3328 tiles, pose-only backward <= 4352; e.g. 640x512), and uses one wave per tile above.  The bits force one flavour for both directions (tests,
  * A/B measurements); both set = ONE_WAVE. */
 #define FSGS_FLAG_BLEND_ONE_WAVE 32
 #define FSGS_FLAG_BLEND_QUAD_WAVES 64
