@@ -20,7 +20,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"([A-Za-z_0-9:]+(<[0-9a-z, ]+>)?)", name); name = (m.group(1) if m else name)[:50]
-    if not any(k in name for k in ("blend", "render_pre", "photometric", "adam")): continue
+    if not any(k in name for k in ("blend", "render_pre", "photometric", "adam", "bin_scatter", "sort_tiles", "pearson")): continue
     agg[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[name][r["Counter_Name"]] += 1
 out = open(sys.argv[2], "a")
 for k, d in agg.items():

@@ -163,6 +163,13 @@ def dump_attribution_log(name, extra=None):
     if not os.path.isdir(d):
         return None
     path = os.path.join(d, name + ".jsonl")
+    if isinstance(extra, dict):  # which flavour of the blend kernels the record belongs to (tests/conftest.py forces both)
+        try:
+            from fsgs_amd import rasterizer
+
+            extra = dict(extra, blend_variant=rasterizer.blend_variant(), deterministic=rasterizer.deterministic())
+        except Exception:  # noqa: BLE001
+            pass
     with open(path, "a") as f:
         if extra is not None:
             f.write(json.dumps(extra) + "\n")
