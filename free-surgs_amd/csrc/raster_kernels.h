@@ -810,22 +810,25 @@ __device__ __forceinline__ bool blend_fwd_pixel(float &T, float &D, float2v (&ac
 
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
-// DIAG (diagnostics flavour of the library only, `FSGS_DIAG=1 python free-surgs_amd/build.py`): the SAME instruction stream
-// plus wave-uniform counters / time stamps behind `if constexpr (DIAG)`; the product library instantiates DIAG = false only.
-template <bool DIAG>
-struct DiagPtrs {};
-template <>
-struct DiagPtrs<true> {
+// DIAG (diagnostics flavour of the library only, `FSGS_DIAG=1 python free-surgs_amd/build.py`): the SAME instruction stream plus
+// instrumentation behind `if constexpr`; the product library instantiates DIAG = 0 only.  Levels:
+//   1  per-workgroup start / end stamps and the scalar pair / body counts (FSGS_DBG_TILE_TIMES*) -- within noise of the product;
+//   2  + the lane-utilisation counters (FSGS_DBG_LANES*): one ballot + popcount per quadrant body and a 16-block footprint mask
+//      per staged record -- picked by the launcher only when the counter buffer is set (scripts/lane_utilisation.py).
+template <int DIAG>
+struct DiagPtrs {
   unsigned long long *times;  // FSGS_DBG_TILE_TIMES*: 4 u64 per workgroup (start, end, pairs << 32 | bodies, list << 32 | walked)
   unsigned long long *lanes;  // FSGS_DBG_LANES*: 32 u64 lane-utilisation counters (diag_flush)
 };
+template <>
+struct DiagPtrs<0> {};
 #ifdef FSGS_DIAG_HOOKS
 constexpr bool kDiagBuild = true;
 #else
 constexpr bool kDiagBuild = false;
 #endif
 
-template <int C, bool WITH_DEPTH, bool DIAG = false>
+template <int C, bool WITH_DEPTH, int DIAG = 0>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, float *__restrict__ final_T,
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
   __shared__ uint32_t dbg_hist[9];
   if constexpr (DIAG) {
     if (dbg.times) dbg_t0 = wall_clock64();
-    if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+    if (DIAG >= 2 && threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
   }
 #else
   static_assert(!DIAG, "the diagnostics flavour needs FSGS_DIAG_HOOKS");
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     uint32_t gmask16 = 0;
 #ifdef FSGS_DIAG_HOOKS
-    if constexpr (DIAG) gmask16 = dbg.lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+    if constexpr (DIAG >= 2) gmask16 = diag_block_mask16(tile, cam.gx, gxy, gco);
 #endif
     // park the 64 records in LDS: v_readlane costs ~8 cycles each on gfx950 (SGPR write -> VALU read), 13 of them
     // per pair were as expensive as half the blending arithmetic; a same-address ds_read_b128 is a broadcast
@@ -933,8 +936,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         const bool contributed = blend_fwd_pixel<CP, WITH_DEPTH>(T[k], D[k], acc[k], last[k], quad_offset(dx0, k & 1),
                                                                  quad_offset(dy0, k >> 1), bA, bB, bC, bo, bz, bcol2, pos);
 #ifdef FSGS_DIAG_HOOKS
-        if constexpr (DIAG) {
-          if (dbg.lanes) {
+        if constexpr (DIAG >= 2) {
+          {
             const unsigned long long bal = __ballot(contributed);
             const int cnt = __popcll(bal);
             dl.lanes += (uint32_t)cnt;
@@ -947,8 +950,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 #endif
       }
 #ifdef FSGS_DIAG_HOOKS
-      if constexpr (DIAG) {
-        if (dbg.lanes) {
+      if constexpr (DIAG >= 2) {
+        {
           uint32_t qsel = 0;  // the 4-bit groups of the quadrants this pair executed
           for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
           const uint32_t r16 = readlane(gmask16, j) & qsel;
@@ -964,7 +967,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     }
   }
 #ifdef FSGS_DIAG_HOOKS
-  if constexpr (DIAG) {
+  if constexpr (DIAG >= 2) {
     __syncthreads();
     diag_flush(dbg.lanes, dl, dbg_hist, lane);
   }
@@ -1225,7 +1228,7 @@ struct BwdSlots {
 // DET (FSGS_FLAG_DETERMINISTIC, tests): no atomics -- the wave's total of slot c of the pair at list position p goes to
 // pair_rows[p][c] (a plain store into the pair's own 16-float row, passed in `grad_acc`); det_gather_kernel then sums a
 // Gaussian's rows in a fixed order.
-template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, bool DIAG = false, bool DET = false>
+template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, int DIAG = 0, bool DET = false>
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
 #endif
@@ -1241,7 +1244,7 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   __shared__ uint32_t dbg_hist[9];
   if constexpr (DIAG) {
     if (dbg.times) dbg_t0 = wall_clock64();
-    if (threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
+    if (DIAG >= 2 && threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
   }
 #else
   static_assert(!DIAG, "the diagnostics flavour needs FSGS_DIAG_HOOKS");
@@ -1314,7 +1317,7 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     const uint32_t gmask = quadrant_mask(tile, cam.gx, gxy, gco);
     uint32_t gmask16 = 0;
 #ifdef FSGS_DIAG_HOOKS
-    if constexpr (DIAG) gmask16 = dbg.lanes ? diag_block_mask16(tile, cam.gx, gxy, gco) : 0u;
+    if constexpr (DIAG >= 2) gmask16 = diag_block_mask16(tile, cam.gx, gxy, gco);
 #endif
     __syncthreads();  // records of the previous batch fully consumed
     const SplatCoef kf = splat_coef(gco.x, gco.y, gco.z);
@@ -1362,8 +1365,8 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
                                                                          pos < last[k]);
           any |= contributed;
 #ifdef FSGS_DIAG_HOOKS
-          if constexpr (DIAG) {
-            if (dbg.lanes) {
+          if constexpr (DIAG >= 2) {
+            {
               const unsigned long long bal = __ballot(contributed);
               const int cnt = __popcll(bal);
               dl.lanes += (uint32_t)cnt;
@@ -1375,8 +1378,8 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
         }
         any_group = any_group || (__ballot(any) != 0ull);
 #ifdef FSGS_DIAG_HOOKS
-        if constexpr (DIAG) {
-          if (dbg.lanes) {
+        if constexpr (DIAG >= 2) {
+          {
             uint32_t qsel = 0;
             for (int k = 0; k < 4; k++) qsel |= ((bm >> k) & 1u) ? (0xFu << (4 * k)) : 0u;
             const uint32_t r16 = readlane(gmask16, j) & qsel;
@@ -1417,9 +1420,11 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     hi = lo;
   }
 #ifdef FSGS_DIAG_HOOKS
-  if constexpr (DIAG) {
+  if constexpr (DIAG >= 2) {
     __syncthreads();
     diag_flush(dbg.lanes, dl, dbg_hist, lane);
+  }
+  if constexpr (DIAG) {
     if (dbg.times && lane == 0) {
       dbg.times[4 * blockIdx.x + 0] = dbg_t0;
       dbg.times[4 * blockIdx.x + 1] = wall_clock64();
@@ -1957,10 +1962,10 @@ inline bool use_quad_waves(const CamParams &cam, int ntiles, bool backward, bool
   return backward ? ntiles <= (pose_only ? FSGS_QUAD_BWD_POSE_MAX_TILES : FSGS_QUAD_BWD_MAX_TILES) : true;
 }
 
-template <bool DIAG>
+template <int DIAG>
 inline DiagPtrs<DIAG> diag_ptrs(const char *times_var, const char *lanes_var) {
   DiagPtrs<DIAG> d{};
-  if constexpr (DIAG) {
+  if constexpr (DIAG != 0) {
     // load-balance experiments only: a device buffer of 4 * ntiles uint64 whose ADDRESS comes from the environment;
     // lane-utilisation counters (scripts/lane_utilisation.py): 32 u64 on the device, summed over every launch
     d.times = diag_env(times_var) ? (unsigned long long *)strtoull(diag_env(times_var), nullptr, 0) : nullptr;
@@ -1983,17 +1988,34 @@ int launch_blend_fwd(const CamParams &cam, int ntiles, const uint32_t *order, co
     return 0;
   }
   static int dbg_lds = diag_env("FSGS_DBG_LDS_FWD") ? atoi(diag_env("FSGS_DBG_LDS_FWD")) : 0;  // occupancy experiments only
-  static const DiagPtrs<kDiagBuild> dbg = diag_ptrs<kDiagBuild>("FSGS_DBG_TILE_TIMES_FWD", "FSGS_DBG_LANES_FWD");
+  constexpr int kLvl = kDiagBuild ? 1 : 0;
+#ifdef FSGS_DIAG_HOOKS
+  constexpr int kLvlLanes = 2;
+#endif
+  static const DiagPtrs<kLvl> dbg = diag_ptrs<kLvl>("FSGS_DBG_TILE_TIMES_FWD", "FSGS_DBG_LANES_FWD");
   // scheduling experiments only (scripts/dev/order_experiment.py): a dispatch order made on the host, holes (0xFFFFFFFF) allowed
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_FWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_FWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_FWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_FWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
+#ifdef FSGS_DIAG_HOOKS
+  {
+    if (dbg.lanes) {  // the lane-utilisation counters were asked for: the level-2 instantiation
+      DiagPtrs<kLvlLanes> d2;
+      d2.times = dbg.times; d2.lanes = dbg.lanes;
+      hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kLvlLanes>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles,
+                         dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
+                         d2);
+      if (done) return hipEventRecord(done, s) == hipSuccess ? 0 : FSGS_ERR_HIP;
+      return 0;
+    }
+  }
+#endif
   if (done)
-    hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam,
+    hipExtLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kLvl>), dim3(grid), dim3(64), dbg_lds, s, nullptr, done, 0, cam,
                           ntiles, dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2,
                           out_depth, dbg);
   else
-    hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles,
+    hipLaunchKernelGGL((blend_fwd_kernel<C, WITH_DEPTH, kLvl>), dim3(grid), dim3(64), dbg_lds, s, cam, ntiles,
                        dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, out_color, out_color2, out_depth,
                        dbg);
   return 0;
@@ -2007,9 +2029,9 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
   if (det && det->pair_rows) {
     // FSGS_FLAG_DETERMINISTIC: pair rows (one-wave kernel, plain stores) + the fixed-order gather; see det_gather_kernel
     if (hipMemsetAsync(det->pair_rows, 0, det_pair_rows_bytes(det->max_pairs), s) != hipSuccess) return FSGS_ERR_HIP;
-    hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, false, true>), dim3(ntiles), dim3(64), 0, s, cam,
+    hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, 0, true>), dim3(ntiles), dim3(64), 0, s, cam,
                        ntiles, order, ranges, plist, rec, final_T, n_contrib, dL, dL2, det->pair_rows, det->pair_rows + 8,
-                       clear16, DiagPtrs<false>{});
+                       clear16, DiagPtrs<0>{});
     hipLaunchKernelGGL((det_gather_kernel<C, ROW>), dim3((det->P + 255) / 256), dim3(256), 0, s, det->P, cam.gx, cam.gy,
                        det->radii, det->xy, det->depth, ranges, plist, (const float *)det->pair_rows, grad_acc, dcolors);
     return 0;
@@ -2020,11 +2042,27 @@ int launch_blend_bwd(const CamParams &cam, int ntiles, const uint32_t *order, co
     return 0;
   }
   static int dbg_lds = diag_env("FSGS_DBG_LDS") ? atoi(diag_env("FSGS_DBG_LDS")) : 0;  // occupancy experiments only
-  static const DiagPtrs<kDiagBuild> dbg = diag_ptrs<kDiagBuild>("FSGS_DBG_TILE_TIMES", "FSGS_DBG_LANES");
+  constexpr int kLvl = kDiagBuild ? 1 : 0;
+#ifdef FSGS_DIAG_HOOKS
+  constexpr int kLvlLanes = 2;
+#endif
+  static const DiagPtrs<kLvl> dbg = diag_ptrs<kLvl>("FSGS_DBG_TILE_TIMES", "FSGS_DBG_LANES");
   static const uint32_t *dbg_order = diag_env("FSGS_DBG_ORDER_BWD") ? (const uint32_t *)strtoull(diag_env("FSGS_DBG_ORDER_BWD"), nullptr, 0) : nullptr;
   static int dbg_order_n = diag_env("FSGS_DBG_ORDER_BWD_N") ? atoi(diag_env("FSGS_DBG_ORDER_BWD_N")) : 0;
   const int grid = (dbg_order && dbg_order_n > 0) ? dbg_order_n : ntiles;
-  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, kDiagBuild>), dim3(grid), dim3(64), dbg_lds, s, cam,
+#ifdef FSGS_DIAG_HOOKS
+  {
+    if (dbg.lanes) {
+      DiagPtrs<kLvlLanes> d2;
+      d2.times = dbg.times; d2.lanes = dbg.lanes;
+      hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, kLvlLanes>), dim3(grid), dim3(64), dbg_lds, s, cam,
+                         ntiles, dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors,
+                         clear16, d2);
+      return 0;
+    }
+  }
+#endif
+  hipLaunchKernelGGL((blend_bwd_kernel<C, SPLIT, POSE_ONLY, CGRAD, ROW, kLvl>), dim3(grid), dim3(64), dbg_lds, s, cam,
                      ntiles, dbg_order ? dbg_order : order, ranges, plist, rec, final_T, n_contrib, dL, dL2, grad_acc, dcolors,
                      clear16, dbg);
   return 0;

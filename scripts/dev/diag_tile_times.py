@@ -4,6 +4,7 @@ the LPT key (list length) predicts a tile's duration compared with the depth act
     gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/dev/diag_tile_times.py [--fwd]'
 (the stamps are a diagnostics hook: only a library built with FSGS_DIAG=1 looks at the environment variable)"""
 import os
+os.environ.setdefault("FSGS_BLEND_VARIANT", "one")  # the hooks live in the one-wave flavour of the blend kernels (round 5: the forward defaults to four waves per tile)
 import sys
 
 import numpy as np

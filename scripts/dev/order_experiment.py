@@ -3,6 +3,7 @@ here on the host.)  One frame of C2, the cloud frozen (lr 0): the list lengths a
 are formed from them and each is timed over 30 forward + backward passes with the library's own HIP events.
     gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/dev/order_experiment.py'"""
 import os
+os.environ.setdefault("FSGS_BLEND_VARIANT", "one")  # the hooks live in the one-wave flavour of the blend kernels (round 5: the forward defaults to four waves per tile)
 import sys
 
 import numpy as np

@@ -5,10 +5,19 @@ Needs the diagnostics flavour of the library (the counters are compiled out of t
     gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && \
                FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/lane_utilisation.py'
 
-Prints one JSON object per workload (C2 default scene, C2 dense scene, C4) -> profiles/r04_lane_utilisation.jsonl."""
+Prints one JSON object per workload (C2 default scene, C2 dense scene, C4) -> profiles/r05_lane_utilisation.jsonl.
+
+Round 5: the counters live in the ONE-WAVE flavour of the blend kernels (the diagnostics library instantiates
+blend_*_kernel<..., DIAG = true>: the product's instruction stream plus counters behind `if constexpr`), so the script forces
+FSGS_BLEND_VARIANT=one; and before it counts anything it times that flavour against the product library on the same workload
+(bench.py, both forced to one wave per tile, counters off): the diagnostics kernels must be within 10 % of the product's
+(VERDICT r4 #5), and every record states the flavour and both step times."""
 import json
 import os
+import subprocess
 import sys
+
+os.environ["FSGS_BLEND_VARIANT"] = "one"
 
 import numpy as np
 import torch
@@ -34,7 +43,31 @@ def report(name, c):
     return out
 
 
+def flavour_times():
+    """blend kernel times and step time of the product library and of the diagnostics library (counters off), one wave per
+    tile forced on both, via bench.py in subprocesses"""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = {}
+    for name, lib in (("product", os.path.join(root, "free-surgs_amd", "fsgs_amd", "lib", "libfsgs_hip.so")),
+                      ("diag", os.environ.get("FSGS_LIB_PATH", ""))):
+        env = dict(os.environ, FSGS_LIB_PATH=lib, FSGS_BLEND_VARIANT="one")
+        for k in ("FSGS_DBG_LANES_FWD", "FSGS_DBG_LANES"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline",
+                            "--no-extras", "--no-tracking"], env=env, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out[name] = {"step_ms": d["ms_per_step"], "blend_fwd_us": 1e3 * d["kernels_ms"]["blend_fwd"]["avg_ms"],
+                     "blend_bwd_us": 1e3 * d["kernels_ms"]["blend_bwd"]["avg_ms"]}
+    for k in ("blend_fwd_us", "blend_bwd_us"):
+        ratio = out["diag"][k] / out["product"][k]
+        out[k + "_diag_over_product"] = ratio
+        assert ratio < 1.10, "the diagnostics flavour's %s is %.0f %% above the product's" % (k, 100 * (ratio - 1))
+    return out
+
+
 def main():
+    flavour = flavour_times()
+    print(json.dumps({"flavour_check": flavour}), flush=True)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     bufs = {"fwd": torch.zeros((32,), dtype=torch.int64, device=dev), "bwd": torch.zeros((32,), dtype=torch.int64, device=dev)}
@@ -68,7 +101,10 @@ def main():
             rep = report("blend_" + k, bufs[k].cpu().numpy())
             if rep["bodies"] == 0:
                 sys.exit("no counts: the loaded library has no diagnostics hooks")
-            rep.update({"config": cfg, "scene": scene, "steps": n, "num_rendered": R,
+            rep.update({"config": cfg, "scene": scene, "steps": n, "num_rendered": R, "kernel_flavour": "one wave per tile, DIAG = true",
+                        "flavour_step_ms": flavour["diag"]["step_ms"], "product_one_wave_step_ms": flavour["product"]["step_ms"],
+                        "flavour_blend_us_over_product": {"fwd": flavour["blend_fwd_us_diag_over_product"],
+                                                          "bwd": flavour["blend_bwd_us_diag_over_product"]},
                         "pairs_walked_over_num_rendered": rep["pairs"] / n / R})
             lines.append(rep)
             print(json.dumps(rep), flush=True)
