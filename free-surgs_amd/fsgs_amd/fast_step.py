@@ -137,7 +137,9 @@ class FastStepper:
     def _cfg(self):
         cam = self.pc.cam
         # the settings object itself is part of the key and kept alive by it (an id() alone can be recycled)
-        key = (cam, cam.viewmatrix._version, cam.projmatrix._version, cam.bg._version)
+        # (+ the process-wide switches make_cfg folds into the flags: toggling them re-makes the struct here too)
+        key = (cam, cam.viewmatrix._version, cam.projmatrix._version, cam.bg._version, rasterizer.blend_variant(),
+               rasterizer.deterministic())
         if (self.cfg_key is None or self.cfg_key[0] is not cam or self.cfg_key[1:] != key[1:]):
             self.cfg = rasterizer.make_cfg(cam, 6)
             # this driver only ever hands the backward a gradient of the depth plane (Pearson losses): the silhouette and

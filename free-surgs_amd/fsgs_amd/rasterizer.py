@@ -65,7 +65,7 @@ if _blend_variant not in _BLEND_FLAGS:
 def set_blend_variant(name):
     """force ("one" / "quad") or release ("auto") the flavour of the blend kernels; returns the previous setting.
     Cached configuration structs are dropped, so the next render of every settings object sees the new value (a
-    FastStepper keeps its own struct: make a new stepper, or reset its cfg_key)."""
+    FastStepper re-makes its own struct when the switch has changed)."""
     global _blend_variant
     if name not in _BLEND_FLAGS:
         raise ValueError("blend variant must be one of %s, not %r" % (sorted(_BLEND_FLAGS), name))
