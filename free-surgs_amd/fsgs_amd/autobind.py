@@ -101,7 +101,7 @@ def _add_densification_stats(self, viewspace_point_tensor, update_filter):
 
     g = viewspace_point_tensor.grad
     f = update_filter.reshape(-1, 1)
-    norm = torch.norm(g[:, :2], dim=-1, keepdim=True)
+    norm = torch.norm(g, dim=-1, keepdim=True)  # (all three components, as the reference; the third is zero)
     self.variables["xyz_gradient_accum"] += torch.where(f, norm, torch.zeros_like(norm))
     self.variables["denom"] += f.to(self.variables["denom"].dtype)
 

@@ -72,7 +72,7 @@ FILES = {
             def add_densification_stats(self, viewspace_point_tensor, update_filter):
                 # (:678-681: boolean-mask indexing, i.e. a host synchronisation per statement)
                 self.variables["xyz_gradient_accum"][update_filter] += torch.norm(
-                    viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+                    viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
                 self.variables["denom"][update_filter] += 1
     ''',
     "standin_train.py": '''
