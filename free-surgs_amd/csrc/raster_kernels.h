@@ -207,8 +207,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(int P, CamParams ca
 // alone, and every step waits for a returning atomic), so the candidates of the 64 Gaussians of a wave are
 // flattened instead: an inclusive scan of the rect areas, then lane l of step s takes candidate 64*s + l, finds
 // its Gaussian by binary search in LDS and tests that one tile.  BIN_UNROLL candidates per lane keep several
-// atomics in flight.
-constexpr int BIN_UNROLL = 4;
+// atomics in flight (two: more of them per lane only lengthen the wave's critical path -- every step waits for its slowest
+// returning atomic).
+#ifndef FSGS_BIN_UNROLL
+#define FSGS_BIN_UNROLL 2  // (round 5 A/B, profiles/r05_ab_bin_unroll.txt: 2 -> 30.1 us, 4 -> 32.4, 8 -> 34.6 at C2; rounds 1-4 ran 4)
+#endif
+constexpr int BIN_UNROLL = FSGS_BIN_UNROLL;
 __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const uint32_t *__restrict__ tiles,
                                                           const ushort4 *__restrict__ rect,
                                                           const float2 *__restrict__ xy,
