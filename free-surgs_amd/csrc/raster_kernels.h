@@ -248,12 +248,15 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
   const uint32_t total = (uint32_t)readlane((int)incl, 63);
   __syncthreads();
   for (uint32_t base = 0; base < total; base += 64 * BIN_UNROLL) {
+    // slot = 0xFFFFFFFF: no pair (a value no capacity reaches: the store below needs no separate "hit" flag -- as a bool
+    // array the flag lived in a scalar mask register that one build variant's control flow left stale on a wave-uniform
+    // early-out path, profiles/r05_ab_bin_unroll.txt)
     uint32_t slot[BIN_UNROLL], seg[BIN_UNROLL], klo[BIN_UNROLL], khi[BIN_UNROLL];
-    bool hit[BIN_UNROLL];
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++) {
       const uint32_t item = base + (uint32_t)(u * 64 + lane);
-      hit[u] = false;
+      slot[u] = 0xFFFFFFFFu;
+      seg[u] = klo[u] = khi[u] = 0u;
       if (item < total) {
         int own = 0;  // number of lanes whose inclusive prefix is <= item  ==  the owning lane
 #pragma unroll
@@ -267,7 +270,6 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
         const int tx = (int)(c.x + rx), ty = (int)(c.y + ry);
         if (rect_touched(a.x, a.y, a.z, a.w, b.x, b.y, (float)(tx * FSGS_TILE), (float)(ty * FSGS_TILE),
                          (float)FSGS_TILE, (float)FSGS_TILE)) {
-          hit[u] = true;
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
           seg[u] = (uint32_t)bin_slot(ty * gx + tx, (int)klo[u]);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
     }
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++)
-      if (hit[u] && slot[u] < cap_sub)  // an overflowing segment keeps counting (the sort kernel reports it)
+      if (slot[u] < cap_sub)  // an overflowing segment keeps counting (the sort kernel reports it)
         keys[(size_t)seg[u] * cap_sub + slot[u]] = ((unsigned long long)khi[u] << 32) | klo[u];
   }
 }
