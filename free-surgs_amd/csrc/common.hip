@@ -207,6 +207,11 @@ int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event) {
   FSGS_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
   return FSGS_OK;
 }
+int fsgs_event_record(fsgs_event_t event, fsgs_stream_t stream) {
+  if (!event) return FSGS_ERR_INVALID;
+  FSGS_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return FSGS_OK;
+}
 int fsgs_forward_done_event(fsgs_event_t event) {
   fsgs::g_forward_done = (hipEvent_t)event;
   return FSGS_OK;

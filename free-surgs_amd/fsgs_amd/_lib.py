@@ -190,6 +190,7 @@ _PROTOTYPES = {
     "fsgs_event_create": (_i, [C.POINTER(C.c_void_p)]),
     "fsgs_event_destroy": (_i, [_vp]),
     "fsgs_stream_wait_event": (_i, [_vp, _vp]),
+    "fsgs_event_record": (_i, [_vp, _vp]),
     "fsgs_forward_done_event": (_i, [_vp]),
     "fsgs_pose_step_done_event": (_i, [_vp]),
 }

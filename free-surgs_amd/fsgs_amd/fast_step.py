@@ -465,24 +465,30 @@ class FastStepper:
             3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
             _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), stream),
             "fsgs_photometric_loss_forward_backward")
-        _lib.check(lib.fsgs_stream_wait_event(C.c_void_p(side.cuda_stream), ctx["fwd_done"]), "fsgs_stream_wait_event")
+        sstream = C.c_void_p(side.cuda_stream)
+        _lib.check(lib.fsgs_stream_wait_event(sstream, ctx["fwd_done"]), "fsgs_stream_wait_event")
         ready = getattr(self.frames.monodeps, "ready", None)  # a staged lane: the side stream reads the mono-depth too
         if ready is not None and ready(ts) is not None:
             side.wait_event(ready(ts))
-        with torch.cuda.stream(side):
-            sstream = _lib.current_stream()
-            dep = b.depth_sil[0]
-            _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
-                                                _lib.ptr(b.pe_out), sstream), "fsgs_pearson_forward")
-            _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
-                                                 _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
-                                                 0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
-            side_done = torch.cuda.Event()
-            side_done.record()
-            for t_ in cr:  # drawn on the side stream, last used there
-                t_.record_stream(side)
-        torch.cuda.current_stream().wait_event(side_done)
+        # the two Pearson launches go to the side stream by its raw handle and the join back is an event this buffer set keeps
+        # (round 5: a `with torch.cuda.stream(...)` block, a fresh torch.cuda.Event and torch.cuda.current_stream() per step
+        # were ~25 us of host time, scripts/dev/host_microbench.py -- at 640x512 the step is as much host- as GPU-bound)
+        dep = b.depth_sil[0]
+        _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                            _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.stats), _lib.ptr(b.coef),
+                                            _lib.ptr(b.pe_out), sstream), "fsgs_pearson_forward")
+        _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                                             _lib.ptr(mono), _lib.ptr(dep), _lib.ptr(b.coef), _lib.ptr(b.pe_w),
+                                             0, _lib.ptr(b.d_depth_sil[0]), sstream), "fsgs_pearson_backward")
+        if getattr(b, "side_event", None) is None:
+            ev = C.c_void_p()
+            _lib.check(lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
+            b.side_event = ev
+            weakref.finalize(b, _lib.load().fsgs_event_destroy, ev).atexit = False
+        _lib.check(lib.fsgs_event_record(b.side_event, sstream), "fsgs_event_record")
+        for t_ in cr:  # last used on the side stream (drawn there, or handed in by the caller from another stream)
+            t_.record_stream(side)
+        _lib.check(lib.fsgs_stream_wait_event(stream, b.side_event), "fsgs_stream_wait_event")
 
     def _view_forward_and_losses(self, b, ts, corners, dev, H, W, n_patches, view):
         """Front half of one view's pipeline on the CURRENT stream (+ the view's side stream): render forward, L1+SSIM
@@ -728,16 +734,21 @@ class FastStepper:
                 if b.flow_scratch is None or b.flow_scratch.numel() < need:
                     b.flow_scratch = torch.empty((need,), dtype=torch.uint8, device=dev)
                 args, state, sbytes, cap, nr = self._render_forward(wd, b, tracking=True)
-                with torch.cuda.stream(side):
-                    _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
-                                                             targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
-                                                             float(LOSS_W_TRACKING["flow"]), 0.0,
-                                                             _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
-                                                             _lib.ptr(b.d_flow), _lib.current_stream()),
-                               "fsgs_flow_pose_loss_fused")
-                    flow_done = torch.cuda.Event()
-                    flow_done.record()
-                    wd.record_stream(side)
+                # (side stream by its raw handle, join through an event this buffer set keeps: see _view_losses)
+                sstream = C.c_void_p(side.cuda_stream)
+                _lib.check(lib.fsgs_flow_pose_loss_fused(M, _lib.ptr(targets.pts), _lib.ptr(targets.vu), _lib.ptr(wd),
+                                                         targets.K9, _lib.ptr(targets.flow), W, H, 20.0,
+                                                         float(LOSS_W_TRACKING["flow"]), 0.0,
+                                                         _lib.ptr(b.flow_scratch), _lib.ptr(b.flow_out),
+                                                         _lib.ptr(b.d_flow), sstream),
+                           "fsgs_flow_pose_loss_fused")
+                if getattr(b, "flow_event", None) is None:
+                    ev = C.c_void_p()
+                    _lib.check(lib.fsgs_event_create(C.byref(ev)), "fsgs_event_create")
+                    b.flow_event = ev
+                    weakref.finalize(b, _lib.load().fsgs_event_destroy, ev).atexit = False
+                _lib.check(lib.fsgs_event_record(b.flow_event, sstream), "fsgs_event_record")
+                wd.record_stream(side)
                 # mask = [rendered depth > 0] * rigid mask (train.py:176-178): the presence test is evaluated inside the
                 # loss kernels from the depth plane; the rigid mask (None = every pixel rigid) is handed over as floats,
                 # converted once per mask object -- a frame's 50 iterations share it
@@ -757,7 +768,7 @@ class FastStepper:
                 d_total = torch.empty((4, 4), dtype=torch.float32, device=dev)
                 # (no dL/dmeans2D: with gs_grad = False the reference's viewspace_points carries no gradient either)
                 grads = self._grad_struct([None] * 6, None, d_total)
-                torch.cuda.current_stream().wait_event(flow_done)
+                _lib.check(lib.fsgs_stream_wait_event(stream, b.flow_event), "fsgs_stream_wait_event")
                 self._render_backward(args, state, sbytes, cap, nr, b, b.d_image, None, grads, False, True, False,
                                       zeroed=True)
                 total = rgb = flow = None

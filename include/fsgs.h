@@ -118,6 +118,9 @@ typedef void *fsgs_event_t; /* hipEvent_t */
 int fsgs_event_create(fsgs_event_t *event);
 int fsgs_event_destroy(fsgs_event_t event);
 int fsgs_stream_wait_event(fsgs_stream_t stream, fsgs_event_t event);
+/* hipEventRecord: for a step driver that joins a side stream back into its main stream with an event it keeps (a host
+ * language's own event objects cost a creation per step) */
+int fsgs_event_record(fsgs_event_t event, fsgs_stream_t stream);
 int fsgs_forward_done_event(fsgs_event_t event);
 /* the same for the next fsgs_pose_adam_step of this thread: the event is signalled when the updated pose (w2c_next) exists */
 int fsgs_pose_step_done_event(fsgs_event_t event);

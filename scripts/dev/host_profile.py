@@ -17,5 +17,5 @@ for it in range(300): fs.mapping_step([it % 8])
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(32)
 print(s.getvalue()[:9000])
