@@ -448,10 +448,11 @@ def test_trainer_thread_and_viewer_thread_share_the_library(own_streams):
     with torch.no_grad():
         want = render(view[1], 1, view[0], gs_grad=False, cam_grad=False)["render"].clone()
     fs_solo = FastStepper(solo[0], solo[1], solo[2])
-    for it in range(12):
+    STEPS = 12
+    for it in range(STEPS):
         fs_solo.mapping_step([it % 3], corners=corners)
     torch.cuda.synchronize()
-    stop, bad, count = threading.Event(), [], [0]
+    stop, bad, count, started = threading.Event(), [], [0], threading.Event()
 
     def viewer():
         s = torch.cuda.Stream() if own_streams else torch.cuda.current_stream()
@@ -461,13 +462,15 @@ def test_trainer_thread_and_viewer_thread_share_the_library(own_streams):
                 if not torch.equal(img, want):
                     bad.append(count[0])
                 count[0] += 1
+                started.set()
         s.synchronize()
 
     def trainer():
         s = torch.cuda.Stream() if own_streams else torch.cuda.current_stream()
+        started.wait(60)  # the viewer's loop is running (the step driver got fast enough to finish before its first render)
         with torch.cuda.stream(s):
             fs = FastStepper(busy[0], busy[1], busy[2])
-            for it in range(12):
+            for it in range(STEPS):
                 fs.mapping_step([it % 3], corners=corners)
         s.synchronize()
 
@@ -478,7 +481,7 @@ def test_trainer_thread_and_viewer_thread_share_the_library(own_streams):
     stop.set()
     tv.join()
     torch.cuda.synchronize()
-    assert count[0] >= 3 and not bad, (count[0], bad[:5])
+    assert count[0] >= 2 and not bad, (count[0], bad[:5])  # (one render before the trainer starts + those beside its 12 steps)
     for k in PARAM_NAMES:
         a, b = solo[0].params[k].detach(), busy[0].params[k].detach()
         assert ((a - b).abs() > 1e-5 * a.abs().max()).float().mean().item() < 2e-3, k
