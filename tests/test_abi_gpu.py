@@ -107,3 +107,30 @@ def test_current_stream_handle_follows_torch_stream_contexts():
             assert (_lib.current_stream().value or 0) == inner.cuda_stream
         assert (_lib.current_stream().value or 0) == side.cuda_stream
     assert (_lib.current_stream().value or 0) == torch.cuda.current_stream().cuda_stream
+
+
+def test_a_kept_event_orders_a_side_stream_behind_and_back_into_the_main_stream():
+    """fsgs_event_create / fsgs_event_record / fsgs_stream_wait_event (include/fsgs.h): the join the step driver makes every
+    step with ONE event it keeps -- work enqueued on the main stream behind the wait sees what the side stream wrote before
+    the record, over many re-records of the same event; a NULL event is FSGS_ERR_INVALID, not a crash."""
+    lib = _lib.load()
+    ev = C.c_void_p()
+    assert lib.fsgs_event_create(C.byref(ev)) == _lib.FSGS_OK and ev.value
+    assert lib.fsgs_event_record(None, None) == _lib.FSGS_ERR_INVALID
+    assert lib.fsgs_stream_wait_event(None, None) == _lib.FSGS_ERR_INVALID
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    a = torch.zeros(1 << 22, device=DEV)
+    out = []
+    for k in range(1, 21):
+        side.wait_stream(main)  # (the side stream's writer must not overtake the previous round's reader)
+        with torch.cuda.stream(side):
+            for _ in range(8):  # enough queued work that an unordered reader would run too early
+                a.add_(1.0)
+        assert lib.fsgs_event_record(ev, C.c_void_p(side.cuda_stream)) == _lib.FSGS_OK
+        assert lib.fsgs_stream_wait_event(_lib.current_stream(), ev) == _lib.FSGS_OK
+        out.append(a[::65536].clone())
+    torch.cuda.synchronize()
+    for k, o in enumerate(out, 1):
+        assert torch.equal(o, torch.full_like(o, 8.0 * k)), k
+    assert lib.fsgs_event_destroy(ev) == _lib.FSGS_OK
