@@ -133,6 +133,16 @@ def test_trained_like_scene_with_view_matrix(oracle32):
     _compare(oracle32, cam, sc["_xyz"], col, o.reshape(-1), s, r, seed=9)
 
 
+def test_one_channel(oracle32):
+    """channels = 1 (include/fsgs.h: 1, 3 or 6): the narrowest instantiation of every blend kernel, both flavours (conftest)"""
+    W, H, P = 200, 136, 3000
+    cam = synth.make_camera(W, H)
+    sc = synth.trained_like_scene(W, H, P, seed=4, base_ratio=0.02)
+    s, r, o = synth.activate(sc)
+    col = np.random.default_rng(6).uniform(0, 1, (P, 1)).astype(np.float32)
+    _compare(oracle32, cam, to_camera_frame(sc["_xyz"], synth.pose_matrix(**synth.PERTURBED_POSE)), col, o.reshape(-1), s, r, seed=3)
+
+
 def test_six_channel_fused_layout(oracle32):
     W, H, P = 160, 128, 1500
     cam = synth.make_camera(W, H)
