@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c && mkdir -p /tmp/pmc_$c
-  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-extras > gpurun_out/pmc_$c.log 2>&1
+  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py ${PMC_ARGS:-} --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-extras > gpurun_out/pmc_$c.log 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   python - "$f" "$c" <<'PY'
 import csv, sys, collections
