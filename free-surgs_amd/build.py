@@ -67,13 +67,24 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", (".%s.o" % TAG) if TAG else ".o"))
-    if _stale(obj, [src] + headers()):
+    # the flag list an object was built with sits beside it: the same TAG rebuilt with other FSGS_CFLAGS (or with
+    # FSGS_DIAG toggled) must not reuse the old objects -- an A/B of two identical libraries proves nothing
+    stamp = obj + ".flags"
+    want = " ".join(FLAGS)
+    try:
+        with open(stamp) as f:
+            same_flags = f.read() == want
+    except OSError:
+        same_flags = False
+    if not same_flags or _stale(obj, [src] + headers()):
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
+        with open(stamp, "w") as f:
+            f.write(want)
     return obj
 
 
@@ -81,7 +92,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJ_DIR):
-            if f.endswith((".o", ".so")):
+            if f.endswith((".o", ".so", ".flags")):
                 os.remove(os.path.join(OBJ_DIR, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(_compile, sources()))

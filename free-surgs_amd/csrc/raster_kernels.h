@@ -141,11 +141,25 @@ __device__ __forceinline__ void clear_binning_cursors(const GeomOut &g) {
     g.tile_count[w] = 0u;
 }
 // Same-address atomics serialise at ~46 ns each on MI355X (profiles/r01_atomic_scope_ubench.txt): the longest tile
-// list alone would cost > 100 us per binning pass.  Every tile therefore owns BIN_SUBS counters / cursors, picked by
-// the Gaussian index, and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
+// list alone would cost > 100 us per binning pass.  Every tile therefore owns BIN_SUBS counters / cursors (bin_slot below
+// says which one a key takes), and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
 // (depth, index) order anyway).
 constexpr int BIN_SUBS = 8;
-__device__ __forceinline__ int bin_slot(int tile, int gaussian) { return tile * BIN_SUBS + (gaussian & (BIN_SUBS - 1)); }
+// Which of a tile's BIN_SUBS sub-lists a key goes to.  Rounds 1-5: the Gaussian index (gaussian & 7).  Round 6: the XCD the
+// writing workgroup runs on (HW_REG_XCC_ID).  Every 64-byte line of a segment then collects its eight keys in ONE L2 -- with
+// the index rule the eight keys of a line arrived from up to eight XCDs, each of which wrote its own partial line back
+// (WRITE_SIZE 51.7 MB for 8.4 MB of keys, profiles/r05_pmc_traffic.json).  The per-tile sort orders by (depth, index), so
+// the sub-list a key sat in never shows in a result; the sub-lists stay balanced because consecutive workgroups (256
+// Gaussians each) land on consecutive XCDs.
+#ifndef FSGS_BIN_SUB_XCC
+#define FSGS_BIN_SUB_XCC 1
+#endif
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  return x;
+}
+__device__ __forceinline__ int bin_slot(int tile, int sub) { return tile * BIN_SUBS + (sub & (BIN_SUBS - 1)); }
 
 __device__ __forceinline__ void store_projected(const GeomOut &g, int i, const Projected &o) {
   g.radii[i] = o.radius;
@@ -226,6 +240,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
   __shared__ uint32_t pre[256];  // inclusive scan of the rect areas, per wave
   const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int xcc = FSGS_BIN_SUB_XCC ? (int)xcc_id() : 0;  // wave-uniform
   uint32_t area = 0;
   if (i < P && tiles[i] != 0) {
     const ushort4 rc = rect[i];
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
                          (float)FSGS_TILE, (float)FSGS_TILE)) {
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
-          seg[u] = (uint32_t)bin_slot(ty * gx + tx, (int)klo[u]);
+          seg[u] = (uint32_t)bin_slot(ty * gx + tx, FSGS_BIN_SUB_XCC ? xcc : (int)klo[u]);
           slot[u] = atomicAdd(&cursors[seg[u]], 1u);
         }
       }
@@ -757,7 +772,21 @@ __device__ __forceinline__ uint32_t quadrant_mask(int tile, int gx, float2 gxy, 
 //   15 alive blocks (footprint test)  16 pairs whose packed count (footprint test) is below their body count
 struct DiagLanes {
   uint32_t pairs, bodies, lanes, packed_true, blocks_true, packed_rect, blocks_rect, pairs_gain;
+  // round 6 (VERDICT r5 #1 b, "four independent 4x4-block streams per wave"): if each 16-lane row of a quadrant's wave walked
+  // the list of ITS 4x4 block (alive by the footprint test, behind nobody's deepest contributor), a batch of 256 records would
+  // take max_b n_b wave steps for sum_b n_b row bodies: row_steps / row_alive summed over (quadrant, 256-record batch)
+  uint32_t row_steps, row_alive;
+  uint32_t cnt[16];  // alive records of the current 256-record batch per (quadrant, block)
 };
+__device__ __forceinline__ void diag_rows_flush(DiagLanes &d) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    d.row_steps += max(max(d.cnt[4 * k], d.cnt[4 * k + 1]), max(d.cnt[4 * k + 2], d.cnt[4 * k + 3]));
+    d.row_alive += d.cnt[4 * k] + d.cnt[4 * k + 1] + d.cnt[4 * k + 2] + d.cnt[4 * k + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) d.cnt[i] = 0;
+}
 __device__ __forceinline__ uint32_t diag_block_bits(unsigned long long ballot) {  // 4 bits: 4x4 blocks with a set lane
   const unsigned long long B0 = 0x0F0F0F0Full, B1 = 0xF0F0F0F0ull;
   return ((ballot & B0) ? 1u : 0u) | ((ballot & B1) ? 2u : 0u) | ((ballot & (B0 << 32)) ? 4u : 0u) |
@@ -793,6 +822,8 @@ __device__ __forceinline__ void diag_flush(unsigned long long *out, const DiagLa
   atomicAdd(out + 14, (unsigned long long)d.packed_rect);
   atomicAdd(out + 15, (unsigned long long)d.blocks_rect);
   atomicAdd(out + 16, (unsigned long long)d.pairs_gain);
+  atomicAdd(out + 17, (unsigned long long)d.row_steps);
+  atomicAdd(out + 18, (unsigned long long)d.row_alive);
 }
 #endif
 
@@ -827,9 +858,13 @@ __device__ __forceinline__ bool blend_fwd_pixel(float &T, float &D, float2v (&ac
 //   1  per-workgroup start / end stamps and the scalar pair / body counts (FSGS_DBG_TILE_TIMES*) -- within noise of the product;
 //   2  + the lane-utilisation counters (FSGS_DBG_LANES*): one ballot + popcount per quadrant body and a 16-block footprint mask
 //      per staged record -- picked by the launcher only when the counter buffer is set (scripts/lane_utilisation.py).
+constexpr int kDiagStampWords = 6;
 template <int DIAG>
 struct DiagPtrs {
-  unsigned long long *times;  // FSGS_DBG_TILE_TIMES*: 4 u64 per workgroup (start, end, pairs << 32 | bodies, list << 32 | walked)
+  // FSGS_DBG_TILE_TIMES*: kDiagStampWords u64 per workgroup -- start, end (s_memrealtime, 100 MHz), pairs << 32 | bodies,
+  // list << 32 | walked, and (round 6) start, end in s_memtime ticks = shader cycles: delta cycles / delta 100 MHz ticks is the
+  // shader clock the tile's wave ran at (VERDICT r5 #4 a: valu_frac had assumed 2.4 GHz)
+  unsigned long long *times;
   unsigned long long *lanes;  // FSGS_DBG_LANES*: 32 u64 lane-utilisation counters (diag_flush)
 };
 template <>
@@ -848,13 +883,16 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     float *__restrict__ out_depth, DiagPtrs<DIAG> dbg) {
   // dbg.times (FSGS_DBG_TILE_TIMES_FWD / FSGS_DBG_TILE_TIMES, scripts/dev/diag_tile_times.py only):
   // 100 MHz wall-clock stamps of this wave's start and end, to measure load balance and the kernel's tail
-  unsigned long long dbg_t0 = 0ull;
+  unsigned long long dbg_t0 = 0ull, dbg_c0 = 0ull;
   uint32_t dbg_bodies = 0, dbg_pairs = 0;  // quadrant bodies executed / pairs not skipped altogether (scalar counters)
 #ifdef FSGS_DIAG_HOOKS
   DiagLanes dl{};
   __shared__ uint32_t dbg_hist[9];
   if constexpr (DIAG) {
-    if (dbg.times) dbg_t0 = wall_clock64();
+    if (dbg.times) {
+      dbg_t0 = wall_clock64();
+      dbg_c0 = __builtin_readcyclecounter();
+    }
     if (DIAG >= 2 && threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
   }
 #else
@@ -1004,15 +1042,17 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 #ifdef FSGS_DIAG_HOOKS
   if constexpr (DIAG) {
     if (dbg.times && lane == 0) {
-      dbg.times[4 * blockIdx.x + 0] = dbg_t0;
-      dbg.times[4 * blockIdx.x + 1] = wall_clock64();
-      dbg.times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
-      dbg.times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
+      dbg.times[kDiagStampWords * blockIdx.x + 0] = dbg_t0;
+      dbg.times[kDiagStampWords * blockIdx.x + 1] = wall_clock64();
+      dbg.times[kDiagStampWords * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+      dbg.times[kDiagStampWords * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) |
                                       max(max(last[0], last[1]), max(last[2], last[3]));
+      dbg.times[kDiagStampWords * blockIdx.x + 4] = dbg_c0;
+      dbg.times[kDiagStampWords * blockIdx.x + 5] = __builtin_readcyclecounter();
     }
   }
 #endif
-  (void)dbg_t0; (void)dbg_bodies; (void)dbg_pairs;
+  (void)dbg_t0; (void)dbg_c0; (void)dbg_bodies; (void)dbg_pairs;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1249,13 +1289,16 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     const uint32_t *__restrict__ plist, const float4 *__restrict__ grec, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dcolor2,
     float *__restrict__ grad_acc, float *__restrict__ dcolors, float *__restrict__ clear16, DiagPtrs<DIAG> dbg) {
-  unsigned long long dbg_t0 = 0ull;  // see blend_fwd_kernel
+  unsigned long long dbg_t0 = 0ull, dbg_c0 = 0ull;  // see blend_fwd_kernel
   uint32_t dbg_bodies = 0, dbg_pairs = 0;
 #ifdef FSGS_DIAG_HOOKS
   DiagLanes dl{};
   __shared__ uint32_t dbg_hist[9];
   if constexpr (DIAG) {
-    if (dbg.times) dbg_t0 = wall_clock64();
+    if (dbg.times) {
+      dbg_t0 = wall_clock64();
+      dbg_c0 = __builtin_readcyclecounter();
+    }
     if (DIAG >= 2 && threadIdx.x < 9) dbg_hist[threadIdx.x] = 0;
   }
 #else
@@ -1400,6 +1443,8 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
             dl.packed_true += diag_packed(dbg_m16); dl.blocks_true += (uint32_t)__popc(dbg_m16);
             dl.packed_rect += pr; dl.blocks_rect += (uint32_t)__popc(r16);
             dl.pairs_gain += pr < nb ? 1u : 0u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) dl.cnt[i] += (r16 >> i) & 1u;
           }
         }
 #endif
@@ -1430,6 +1475,11 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
       }
     }
     hi = lo;
+#ifdef FSGS_DIAG_HOOKS
+    if constexpr (DIAG >= 2) {
+      if (((dbg_walked - hi) & 255) == 0 || hi == 0) diag_rows_flush(dl);  // a 256-record batch of a four-waves workgroup ends
+    }
+#endif
   }
 #ifdef FSGS_DIAG_HOOKS
   if constexpr (DIAG >= 2) {
@@ -1438,14 +1488,16 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   }
   if constexpr (DIAG) {
     if (dbg.times && lane == 0) {
-      dbg.times[4 * blockIdx.x + 0] = dbg_t0;
-      dbg.times[4 * blockIdx.x + 1] = wall_clock64();
-      dbg.times[4 * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
-      dbg.times[4 * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
+      dbg.times[kDiagStampWords * blockIdx.x + 0] = dbg_t0;
+      dbg.times[kDiagStampWords * blockIdx.x + 1] = wall_clock64();
+      dbg.times[kDiagStampWords * blockIdx.x + 2] = ((unsigned long long)dbg_pairs << 32) | dbg_bodies;
+      dbg.times[kDiagStampWords * blockIdx.x + 3] = ((unsigned long long)(uint32_t)(rg.y - rg.x) << 32) | (uint32_t)dbg_walked;
+      dbg.times[kDiagStampWords * blockIdx.x + 4] = dbg_c0;
+      dbg.times[kDiagStampWords * blockIdx.x + 5] = __builtin_readcyclecounter();
     }
   }
 #endif
-  (void)dbg_t0; (void)dbg_bodies; (void)dbg_pairs; (void)dbg_walked;
+  (void)dbg_t0; (void)dbg_c0; (void)dbg_bodies; (void)dbg_pairs; (void)dbg_walked;
 }
 
 // ------------------------------------------------------------------------------------------------

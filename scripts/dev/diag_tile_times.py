@@ -3,6 +3,7 @@ through FSGS_DBG_TILE_TIMES.  Prints the makespan, the mean number of resident w
 the LPT key (list length) predicts a tile's duration compared with the depth actually walked (max n_contrib).
     gpurun -- 'FSGS_DIAG=1 python free-surgs_amd/build.py && FSGS_LIB_PATH=free-surgs_amd/fsgs_amd/lib/diag/libfsgs_hip.diag.so python scripts/dev/diag_tile_times.py [--fwd]'
 (the stamps are a diagnostics hook: only a library built with FSGS_DIAG=1 looks at the environment variable)"""
+import json
 import os
 os.environ.setdefault("FSGS_BLEND_VARIANT", "one")  # the hooks live in the one-wave flavour of the blend kernels (round 5: the forward defaults to four waves per tile)
 import sys
@@ -22,7 +23,7 @@ def main():
     np.random.seed(0)
     ntiles = 80 * 64
     nwaves = ntiles
-    buf = torch.zeros((nwaves * 4,), dtype=torch.int64, device=dev)
+    buf = torch.zeros((nwaves * 6,), dtype=torch.int64, device=dev)  # kDiagStampWords
     os.environ["FSGS_DBG_TILE_TIMES_FWD" if "--fwd" in sys.argv else "FSGS_DBG_TILE_TIMES"] = str(buf.data_ptr())
     slots = 6144 if "--fwd" in sys.argv else 5120
     from fsgs_amd import _lib
@@ -38,7 +39,7 @@ def main():
         buf.zero_()
         st.mapping_step([it % len(frames.colors)])
         torch.cuda.synchronize()
-        d = buf.cpu().numpy().reshape(nwaves, 4)
+        d = buf.cpu().numpy().reshape(nwaves, 6)
         t0, t1 = d[:, 0].astype(np.float64) * 0.01, d[:, 1].astype(np.float64) * 0.01  # us
         ok = d[:, 1] > 0
         if not ok.any():
@@ -49,6 +50,13 @@ def main():
         dur = (t1 - t0)[ok]
         print("step %d: %d waves, makespan %.1f us, busy %.0f wave-us -> mean resident waves %.0f of %d (%.1f %%)" % (
             it, ok.sum(), end - start, dur.sum(), dur.sum() / (end - start), slots, 100 * dur.sum() / (end - start) / slots))
+        # round 6: the shader clock the tiles' waves ran at = delta s_memtime (shader cycles) / delta s_memrealtime (100 MHz)
+        cyc = (d[:, 5] - d[:, 4]).astype(np.float64)[ok]
+        mhz = cyc / np.maximum(dur, 1e-9)
+        print("  shader clock while the kernel ran: %.0f MHz (sum of cycles / sum of wall time over the waves; per wave p10 %.0f "
+              "p50 %.0f p90 %.0f MHz)" % (cyc.sum() / dur.sum(), np.percentile(mhz, 10), np.percentile(mhz, 50), np.percentile(mhz, 90)))
+        print(json.dumps({"kernel": "blend_fwd" if "--fwd" in sys.argv else "blend_bwd", "step": it, "shader_clock_mhz": cyc.sum() / dur.sum(),
+                          "makespan_us": end - start, "waves": int(ok.sum())}))
         print("  tile duration us: mean %.1f  median %.1f  p90 %.1f  max %.1f;  list length mean %.0f max %.0f;  walked mean %.0f max %.0f" % (
             dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max(), lst[ok].mean(), lst[ok].max(), walked[ok].mean(), walked[ok].max()))
         print("  corr(duration, list length) %.3f   corr(duration, walked depth) %.3f" % (

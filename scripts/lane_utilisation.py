@@ -40,6 +40,13 @@ def report(name, c):
                                          "blocks_by_footprint_test (decidable up front)": c[14] / max(bodies, 1)},
            "alive_4x4_blocks_per_body": {"contributed": c[13] / max(bodies, 1), "footprint_test": c[15] / max(bodies, 1)},
            "pairs_with_a_gain_footprint_test": c[16] / max(pairs, 1)}
+    if len(c) > 18 and c[17]:
+        # round 6: four 16-lane row streams per quadrant wave (one 4x4 block each, its own list): wave steps a 256-record
+        # batch would take (max over the four rows) against the 8x8 bodies executed today, and how full the rows would be
+        out["row_streams"] = {"wave_steps": c[17], "wave_steps_over_bodies": c[17] / max(bodies, 1),
+                              "wave_steps_per_pair": c[17] / max(pairs, 1), "row_bodies": c[18],
+                              "row_balance": c[18] / max(4 * c[17], 1),
+                              "lane_utilisation_of_a_row_step": lanes / max(64 * c[17], 1)}
     return out
 
 

@@ -1,0 +1,102 @@
+// issue_clock.hip -- (1) what shader clock does an MI355X hold while every SIMD issues VALU work back to back, and (2) how
+// many wave64 VALU instructions per shader cycle does a SIMD retire at W = 1..8 resident waves?  (VERDICT r5 #4 a, b: the
+// bench line's `valu_frac` used an ASSUMED 2.4 GHz.)
+// Every wave stamps s_memtime (shader clock, the guide: "tick = shader cycle") and s_memrealtime (constant 100 MHz) around its
+// loop; the ratio of the two deltas is the clock the wave ran at, with no assumption.  The loop bodies:
+//   fma   : 8 independent v_fma_f32 chains per lane (the issue-rate ceiling)
+//   blend : the instruction MIX of the backward blend body per 40 instructions -- 1 v_exp_f32, 1 v_rcp_f32, 3 v_cmp/v_cndmask
+//           pairs, 3 broadcast ds_read_b128 per two bodies, the rest FMA / mul / add -- what `valu_frac_of_achievable` is
+//           quoted against
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/issue_clock.bin scripts/ubench/issue_clock.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Stamp {
+  unsigned long long cyc, rt;
+};
+__device__ __forceinline__ Stamp stamp() {
+  Stamp s;
+  s.cyc = __builtin_readcyclecounter();  // s_memtime
+  s.rt = wall_clock64();                 // s_memrealtime, 100 MHz
+  return s;
+}
+
+template <int MIX>
+__global__ __launch_bounds__(256) void k(float *out, unsigned long long *st, int iters, float b, float c) {
+  __shared__ float4 lds[64];
+  float a[8];
+  for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 0.001f + i;
+  if (threadIdx.x < 64) lds[threadIdx.x] = make_float4(a[0], a[1], b, c);
+  __syncthreads();
+  const Stamp s0 = stamp();
+  for (int it = 0; it < iters; it++) {
+    if (MIX == 0) {
+#pragma unroll
+      for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+    } else {
+      // 40 VALU: 1 exp, 1 rcp, 3 x (cmp + cndmask), 32 FMA-class; + 1.5 broadcast LDS reads
+      const float4 r0 = lds[it & 63];
+      float4 r1 = r0;
+      if (it & 1) r1 = lds[(it + 7) & 63];
+      asm volatile("v_exp_f32 %0, %0" : "+v"(a[0]));
+      asm volatile("v_rcp_f32 %0, %0" : "+v"(a[1]));
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[2 + i]) : "v"(b), "v"(c) : "vcc");
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(r0.z), "v"(r1.w));
+    }
+  }
+  const Stamp s1 = stamp();
+  float acc = 0.f;
+  for (int i = 0; i < 8; i++) acc += a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  if ((threadIdx.x & 63) == 0) {
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    st[2 * w + 0] = s1.cyc - s0.cyc;
+    st[2 * w + 1] = s1.rt - s0.rt;
+  }
+}
+
+template <int MIX>
+static void run(int W, float *d_out, unsigned long long *d_st) {
+  const int blocks = 256 * W, iters = 20000, per_iter = 40;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipEventRecord(e0));
+    k<MIX><<<blocks, 256>>>(d_out, d_st, iters, 0.999f, 0.001f);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = fminf(best, ms);
+  }
+  std::vector<unsigned long long> st(2 * (size_t)blocks * 4);
+  CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+  double cyc = 0, rt = 0;
+  for (size_t w = 0; w < (size_t)blocks * 4; w++) { cyc += (double)st[2 * w]; rt += (double)st[2 * w + 1]; }
+  const double mhz = cyc / rt * 100.0;                       // shader cycles per 100 MHz tick
+  const double n_inst = (double)iters * per_iter * W;        // wave-instructions per SIMD
+  const double cyc_per_wave = cyc / ((double)blocks * 4);    // a wave's loop, in shader cycles
+  printf("%-5s W=%d waves/SIMD: %7.3f ms  %6.3f ns/inst/SIMD  shader clock %6.0f MHz  %5.2f cycles/inst/SIMD  (%4.2f inst/cycle/SIMD; wave loop %.0f cycles)\n",
+         MIX ? "blend" : "fma", W, best, best * 1e6 / n_inst, mhz, cyc_per_wave / n_inst, n_inst / cyc_per_wave, cyc_per_wave);
+}
+
+int main() {
+  float *d_out; unsigned long long *d_st;
+  CK(hipMalloc(&d_out, 4 * 256 * 256 * 8)); CK(hipMalloc(&d_st, 16 * 256 * 8 * 4));
+  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<0>(W, d_out, d_st);
+  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<1>(W, d_out, d_st);
+  return 0;
+}
