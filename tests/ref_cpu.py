@@ -1,15 +1,22 @@
 """CPU reference of the whole `render(...)` for the parity tests (TEST INFRASTRUCTURE, never the product).
 
-The reference's sequence (gaussian_renderer/__init__.py:49-92) is kept as it is written in fsgs_amd.render.render_two_pass
--- small torch ops whose statements are pinned to the reference's golden vectors on CPU (tests/test_golden_host.py) --
-and its two calls of `GaussianRasterizer` are served by the CPU oracle (oracle/raster_oracle.c) through
-`OracleRasterizer`, an nn.Module with UPSTREAM's call signature.  So a CPU `render` exists whose every stage is either
-reference-pinned torch or the oracle; the fused HIP op is compared against it end to end, and the CPU harness of
-tests/golden/make_harness_golden.py is built from it."""
+Round 6 (VERDICT r5 weak #1a): the glue around the rasteriser is tests/ref_glue.py -- an independent restatement of
+gaussian_renderer/__init__.py:49-92 that imports NOTHING from `fsgs_amd`, pinned on CPU against the reference's own `render()`
+(tests/golden/render_composition.npz, tests/test_ref_glue.py) -- and its two calls of `GaussianRasterizer` are served by the
+CPU oracle (oracle/raster_oracle.c) through `OracleRasterizer`, an nn.Module with UPSTREAM's call signature.  `render_reference`
+is what the fused HIP op is compared against end to end.  (`oracle_backend` still lets the CPU harness of
+tests/ref_harness.py -- the product's trainer logic on CPU -- rasterise with the oracle; that harness is a different check.)"""
 import contextlib
 
 import numpy as np
 import torch
+
+from tests import ref_glue
+
+
+def render_reference(poses, index, pc, gs_grad=True, cam_grad=True):
+    """render() on CPU: tests/ref_glue.py around the oracle rasteriser set by `oracle_backend`."""
+    return ref_glue.render_two_pass(poses, index, pc, gs_grad=gs_grad, cam_grad=cam_grad, rasterizer=OracleRasterizer)
 
 
 def cam_from_settings(s):
@@ -71,34 +78,19 @@ def oracle_backend(oracle):
 
 
 def cpu_cloud(pc):
-    """A CPU copy of a GaussianCloud (parameters, SH degree, raster camera)."""
-    from fsgs_amd.model import PARAM_NAMES, GaussianCloud
-    from fsgs_amd.rasterizer import GaussianRasterizationSettings
-
-    c = GaussianCloud({k: pc.params[k].detach().cpu() for k in PARAM_NAMES}, sh_degree=pc.max_sh_degree, device="cpu",
-                      spatial_lr_scale=pc.spatial_lr_scale, scene_radius=float(pc.variables["scene_radius"]))
-    c.active_sh_degree = pc.active_sh_degree
-    s = pc.cam
-    c.cam = GaussianRasterizationSettings(**{f: (getattr(s, f).detach().cpu() if torch.is_tensor(getattr(s, f)) else getattr(s, f))
-                                             for f in s._fields})
-    return c
+    """A CPU copy of what render() reads of a GaussianCloud (raw parameters, SH degrees, raster camera)."""
+    return ref_glue.Cloud(pc.params, ref_glue.Settings.of(pc.cam), pc.active_sh_degree, pc.max_sh_degree)
 
 
 def cpu_poses(poses):
-    from fsgs_amd.trainer import PoseTrack
-
-    p = PoseTrack(int(poses.r.shape[-1]), device="cpu")
-    with torch.no_grad():
-        p.r.copy_(poses.r.detach().cpu())
-        p.t.copy_(poses.t.detach().cpu())
-    return p
+    return ref_glue.Poses(poses.r, poses.t, poses.cam_center)
 
 
 def run_render(render_fn, pc, poses, index, gs_grad, cam_grad, wi, wd, ws, pixel_classes=None):
     """render -> the weighted-sum loss the GPU tests use -> backward; numpy outputs and gradients.
     pixel_classes (list of [H,W] bool masks): additionally the gradients of the loss restricted to each class (the
     backward is linear in the weights) -> (outputs, grads, [grads of class 0, ...])."""
-    from fsgs_amd.model import PARAM_NAMES
+    PARAM_NAMES = ref_glue.Cloud.NAMES
 
     n = lambda t: None if t is None else t.detach().cpu().numpy().copy()
 
@@ -140,16 +132,12 @@ _oracle64 = None
 
 def _to_double(c, p):
     """the same cloud / poses / camera with every tensor in float64 (the glue statements are dtype-agnostic)."""
-    from fsgs_amd.rasterizer import GaussianRasterizationSettings
-
     for k in c.params:
         c.params[k] = c.params[k].detach().double().requires_grad_(True)
     for k, v in c.variables.items():
         if torch.is_tensor(v) and v.is_floating_point():
             c.variables[k] = v.double()
-    s = c.cam
-    c.cam = GaussianRasterizationSettings(**{f: (getattr(s, f).double() if torch.is_tensor(getattr(s, f)) else getattr(s, f))
-                                             for f in s._fields})
+    c.cam = ref_glue.Settings.of(c.cam, conv=lambda t: t.detach().double())
     p.r = p.r.detach().double().requires_grad_(True)
     p.t = p.t.detach().double().requires_grad_(True)
     p.cam_center = p.cam_center.double()
@@ -163,7 +151,7 @@ def reference_render_with_amplitudes(oracle, pc, poses, index, gs_grad, cam_grad
     glue + the fp64 oracle build) -- the allowance of tests/util.py:assert_close_attributed, see
     Oracle.flip_amplitudes for the reasoning.  -> (outputs, grads, amp_outputs, amp_grads)."""
     global _oracle64
-    from fsgs_amd.render import render_two_pass
+    render_two_pass = render_reference
 
     c, p = cpu_cloud(pc), cpu_poses(poses)
     w = [t.detach().cpu() for t in (wi, wd, ws)]

@@ -23,12 +23,17 @@ def _free_port():
     return p
 
 
-def _world(dev, n=2):
+# "small": the quick shape of rounds 1-5; "C3": BASELINE.json configs[2] at ITS OWN size -- 1280x1024, 300 000 Gaussians, one
+# camera per rank (the 8-rank path had only ever run at 320x256 / 4 000)
+SIZES = {"small": (320, 256, 4000), "C3": (1280, 1024, 300_000)}
+
+
+def _world(dev, n=2, size="small"):
     from fsgs_amd import synth
     from fsgs_amd.model import GaussianCloud
     from fsgs_amd.trainer import FrameData, PoseTrack, settings_from_cam
 
-    W, H, P = 320, 256, 4000
+    W, H, P = SIZES[size]
     cam = synth.make_camera(W, H)
     sc = synth.trained_like_scene(W, H, P, seed=0)
     pc = GaussianCloud(sc, sh_degree=3, device=dev)
@@ -52,7 +57,7 @@ def _corners(H, W, dev):
     return (torch.randint(0, H - 128, (n,), generator=g).to(dev), torch.randint(0, W - 128, (n,), generator=g).to(dev))
 
 
-def _worker(rank, world, port, out_dir, mode, deterministic=False):
+def _worker(rank, world, port, out_dir, mode, deterministic=False, size="small"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", FSGS_DETERMINISTIC="1" if deterministic else "0")
     from fsgs_amd import dist as fdist
@@ -62,7 +67,7 @@ def _worker(rank, world, port, out_dir, mode, deterministic=False):
     dev = "cuda:0"
     torch.cuda.set_device(0)
     fdist.init_from_env(backend="gloo")
-    pc, poses, frames, (H, W) = _world(dev, n=max(2, world))
+    pc, poses, frames, (H, W) = _world(dev, n=max(2, world), size=size)
     cr = _corners(H, W, dev)
     fs = FastStepper(pc, poses, frames)
     if mode == "bucket":
@@ -113,8 +118,9 @@ def test_two_ranks_with_the_hip_stepper_match_the_two_view_step(tmp_path, mode):
         assert frac_off < 2e-3, (k, frac_off)
 
 
-@pytest.mark.parametrize("mode", ["compact", "direct", "producer"])
-def test_two_deterministic_ranks_equal_the_two_view_step_bit_for_bit(tmp_path, mode):
+@pytest.mark.parametrize("mode,size", [("compact", "small"), ("direct", "small"), ("producer", "small"),
+                                       ("compact", "C3"), ("direct", "C3")])
+def test_two_deterministic_ranks_equal_the_two_view_step_bit_for_bit(tmp_path, mode, size):
     """FSGS_FLAG_DETERMINISTIC (VERDICT r4 #4b): with the backward's float atomics gone, the frame-sharded step IS the
     single-process two-view step -- the same two compact gradients, summed once (a + b by the all-reduce, a + b by
     fsgs_adam_step_compact_sum), the same Adam -- so after two steps every parameter has the same bits on both ranks and in
@@ -124,12 +130,12 @@ def test_two_deterministic_ranks_equal_the_two_view_step_bit_for_bit(tmp_path, m
     from fsgs_amd.fast_step import FastStepper
     from fsgs_amd.model import PARAM_NAMES
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), mode, True, size), nprocs=2, join=True)
     a = torch.load(os.path.join(tmp_path, "rank0.pt"))
     b = torch.load(os.path.join(tmp_path, "rank1.pt"))
     prev = rasterizer.set_deterministic(True)
     try:
-        pc, poses, frames, (H, W) = _world("cuda:0")
+        pc, poses, frames, (H, W) = _world("cuda:0", size=size)
         cr = _corners(H, W, "cuda:0")
         fs = FastStepper(pc, poses, frames)
         for step in range(2):
@@ -142,8 +148,9 @@ def test_two_deterministic_ranks_equal_the_two_view_step_bit_for_bit(tmp_path, m
         assert torch.equal(a[k], pc.params[k].detach().cpu()), k
 
 
-@pytest.mark.parametrize("mode", ["compact", "direct", "producer"])
-def test_eight_ranks_on_the_one_gpu_match_the_eight_view_step(tmp_path, mode):
+@pytest.mark.parametrize("mode,size", [("compact", "small"), ("direct", "small"), ("producer", "small"),
+                                       ("compact", "C3"), ("direct", "C3")])
+def test_eight_ranks_on_the_one_gpu_match_the_eight_view_step(tmp_path, mode, size):
     """The world size of configuration C3 (8 ranks, one camera each) with the HIP step driver: eight processes on the one
     test GPU over gloo.  Replicas bit-identical after two steps for the one-collective, the direct (shards padded for 8) and
     the producer-pipelined exchange, and equal to ONE process taking the same eight views in a step (summed loss, one Adam
@@ -152,12 +159,12 @@ def test_eight_ranks_on_the_one_gpu_match_the_eight_view_step(tmp_path, mode):
     from fsgs_amd.model import PARAM_NAMES
 
     world = 8
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode, False, size), nprocs=world, join=True)
     ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
     for r in ranks[1:]:
         for k in PARAM_NAMES:
             assert torch.equal(ranks[0][k], r[k]), k
-    pc, poses, frames, (H, W) = _world("cuda:0", n=world)
+    pc, poses, frames, (H, W) = _world("cuda:0", n=world, size=size)
     cr = _corners(H, W, "cuda:0")
     fs = FastStepper(pc, poses, frames)
     for step in range(2):
@@ -169,7 +176,7 @@ def test_eight_ranks_on_the_one_gpu_match_the_eight_view_step(tmp_path, mode):
         assert frac_off < 2e-3, (k, frac_off)
 
 
-def _rccl_one_rank_worker(rank, world, port, out_dir):
+def _rccl_one_rank_worker(rank, world, port, out_dir, size="small"):
     """a ONE-rank "nccl" (= RCCL) group on the test GPU with the collectives forced on: the real backend of the
     multi-GPU run -- RCCL kernels on their own stream, event hand-offs, barrier(device_ids) -- under every exchange route
     of the step driver; the result must equal the step without any exchange (an all-reduce over one rank is the identity)."""
@@ -184,7 +191,7 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
     fdist.FORCE_COLLECTIVES = True
     results = {}
     for mode in ("none", "compact", "direct", "pipelined", "producer"):
-        pc, poses, frames, (H, W) = _world("cuda:0")
+        pc, poses, frames, (H, W) = _world("cuda:0", size=size)
         cr = _corners(H, W, "cuda:0")
         fs = FastStepper(pc, poses, frames)
         red = {"none": None, "compact": fdist.all_reduce_compact, "direct": fdist.DirectAllReduce(),
@@ -207,10 +214,11 @@ def _rccl_one_rank_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_every_exchange_route_runs_on_rccl_with_one_rank(tmp_path):
+@pytest.mark.parametrize("size", ["small", "C3"])
+def test_every_exchange_route_runs_on_rccl_with_one_rank(tmp_path, size):
     from fsgs_amd.model import PARAM_NAMES
 
-    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), str(tmp_path), size), nprocs=1, join=True)
     r = torch.load(os.path.join(tmp_path, "rccl.pt"))
     for mode in ("compact", "direct", "pipelined", "producer"):
         # identity exchange: the same trajectory as without one, up to the arrival order of the backward's atomics

@@ -1,12 +1,11 @@
-"""The CPU reference render of tests/ref_cpu.py (reference-pinned torch glue around the oracle rasteriser, the thing the
-fused HIP render is compared with on the GPU box) checked on its own: its autograd wiring against fp64 central
+"""The CPU reference render of tests/ref_cpu.py (tests/ref_glue.py -- an independent restatement of the reference's render()
+glue -- around the oracle rasteriser: the thing the fused HIP render is compared with on the GPU box) checked on its own: its autograd wiring against fp64 central
 differences along random directions of every parameter tensor and of the pose."""
 import numpy as np
 import torch
 
 from fsgs_amd import synth
 from fsgs_amd.model import PARAM_NAMES, GaussianCloud
-from fsgs_amd.render import render_two_pass
 from fsgs_amd.trainer import PoseTrack, settings_from_cam
 from tests import ref_cpu
 
@@ -23,7 +22,8 @@ def test_reference_render_gradients_match_fp64_central_differences(oracle64):
     pc.active_sh_degree = 2
     poses = PoseTrack(2, "cpu")
     poses.set_pose(1, (1.0, 0.01, -0.02, 0.015), (0.02, -0.01, 0.03))
-    pc, poses = ref_cpu._to_double(pc, poses)
+    pc, poses = ref_cpu._to_double(ref_cpu.cpu_cloud(pc), ref_cpu.cpu_poses(poses))
+    render_two_pass = ref_cpu.render_reference
     g = torch.Generator().manual_seed(1)
     wi = (torch.rand(3, H, W, generator=g, dtype=torch.float64) - 0.5)
     wd = (torch.rand(H, W, generator=g, dtype=torch.float64) - 0.5)
