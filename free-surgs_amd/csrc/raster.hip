@@ -23,6 +23,12 @@
 // ================================================================================================
 extern "C" {
 
+int fsgs_blend_waves_per_tile(int width, int height, int flags, int backward, int pose_only) {
+  if (width <= 0 || height <= 0) return FSGS_ERR_INVALID;
+  const int ntiles = ((width + FSGS_TILE - 1) / FSGS_TILE) * ((height + FSGS_TILE - 1) / FSGS_TILE);
+  return use_quad_waves((uint32_t)flags, ntiles, backward != 0, pose_only != 0) ? 4 : 1;
+}
+
 size_t fsgs_deterministic_scratch_bytes(int P, int64_t max_pairs) {
   if (P < 0 || max_pairs < 0) return 0;
   return det_layout(P, max_pairs).total;
@@ -113,7 +119,8 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   if (scratch_bytes < (size_t)P * kAccStride * sizeof(float)) return FSGS_ERR_CAPACITY;
   const bool deterministic = (cfg->flags & FSGS_FLAG_DETERMINISTIC) != 0;
   const DetLayout DL = det_layout(P, max_pairs);
-  if (deterministic && (scratch_bytes < DL.total || (((uintptr_t)scratch) & 15))) return FSGS_ERR_CAPACITY;
+  if (deterministic && (((uintptr_t)scratch) & 15)) return FSGS_ERR_INVALID;  // (as fsgs_render_backward*: a bad pointer, not a size)
+  if (deterministic && scratch_bytes < DL.total) return FSGS_ERR_CAPACITY;
   CamParams cam = make_cam(cfg);
   const int ntiles = cam.gx * cam.gy;
   const char *sb = (const char *)state;

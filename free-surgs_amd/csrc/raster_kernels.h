@@ -2014,16 +2014,37 @@ inline DetLayout det_layout(int P, int64_t max_pairs) {
 //     mapping step     2880 tiles: 0.350 (four waves) vs 0.366 ms    3808 tiles: 0.476 vs 0.468   -> crossover ~3300
 //     tracking step    2880 tiles: 0.279 vs 0.316                    3808 tiles: 0.358 vs 0.373; 5120 (C2): 0.485 vs 0.471 -> ~4400
 // (the pose-only backward's reduction is the cheap 5-of-8 one, so a reduction per quadrant costs it less)
-#ifndef FSGS_QUAD_BWD_MAX_TILES
-#define FSGS_QUAD_BWD_MAX_TILES 3328
+// The crossovers were measured on an MI355X (1024 SIMDs): 3328 tiles = 3.25 per SIMD (mapping), 4352 = 4.25 per SIMD (pose-only).
+// What decides is how many one-wave workgroups a SIMD gets, so the rule is stated per SIMD and scaled by the device the call runs
+// on (hipDeviceProp: multiProcessorCount x 4 SIMDs; ADVICE r5 -- a hard-coded tile count is simply wrong on any other part).
+// FSGS_QUAD_BWD_MAX_TILES / _POSE_MAX_TILES (A/B builds only) still override it with an absolute count.
+constexpr int kQuadBwdQuarterTilesPerSimd = 13, kQuadBwdPoseQuarterTilesPerSimd = 17;  // 3.25 and 4.25 tiles per SIMD
+inline int device_simd_count() {
+  static int simds[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+  if (simds[dev] == 0) {
+    hipDeviceProp_t prop;
+    simds[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount * 4 : 1024;
+  }
+  return simds[dev];
+}
+inline int quad_bwd_max_tiles(bool pose_only) {
+#ifdef FSGS_QUAD_BWD_MAX_TILES
+  if (!pose_only) return FSGS_QUAD_BWD_MAX_TILES;
 #endif
-#ifndef FSGS_QUAD_BWD_POSE_MAX_TILES
-#define FSGS_QUAD_BWD_POSE_MAX_TILES 4352
+#ifdef FSGS_QUAD_BWD_POSE_MAX_TILES
+  if (pose_only) return FSGS_QUAD_BWD_POSE_MAX_TILES;
 #endif
+  return device_simd_count() * (pose_only ? kQuadBwdPoseQuarterTilesPerSimd : kQuadBwdQuarterTilesPerSimd) / 4;
+}
+inline bool use_quad_waves(uint32_t flags, int ntiles, bool backward, bool pose_only = false) {
+  if (flags & FSGS_FLAG_BLEND_ONE_WAVE) return false;
+  if (flags & FSGS_FLAG_BLEND_QUAD_WAVES) return true;
+  return backward ? ntiles <= quad_bwd_max_tiles(pose_only) : true;
+}
 inline bool use_quad_waves(const CamParams &cam, int ntiles, bool backward, bool pose_only = false) {
-  if (cam.flags & FSGS_FLAG_BLEND_ONE_WAVE) return false;
-  if (cam.flags & FSGS_FLAG_BLEND_QUAD_WAVES) return true;
-  return backward ? ntiles <= (pose_only ? FSGS_QUAD_BWD_POSE_MAX_TILES : FSGS_QUAD_BWD_MAX_TILES) : true;
+  return use_quad_waves((uint32_t)cam.flags, ntiles, backward, pose_only);
 }
 
 template <int DIAG>

@@ -105,6 +105,7 @@ _PROTOTYPES = {
     "fsgs_profile_count": (_i, []),
     "fsgs_profile_name": (C.c_char_p, [_i]),
     "fsgs_profile_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "fsgs_blend_waves_per_tile": (_i, [_i, _i, _i, _i, _i]),
     "fsgs_deterministic_scratch_bytes": (_sz, [_i, _i64]),
     "fsgs_raster_sizes": (_i, [_i, _i, _i, _i64, C.POINTER(_sz), C.POINTER(_sz)]),
     "fsgs_raster_state_layout": (_i, [_i, _i, _i, _i64, C.POINTER(_sz)]),

@@ -173,10 +173,11 @@ def _patch_in_flight(mod):
             _bound[mod.__name__] += [d for d in done if d not in _bound[mod.__name__]]
         _pending.append(mod)  # what the body has not defined yet (the class) is bound when it has finished: _drain_pending
         return bool(done)
-    ns = {}
-    for attr, get in spec.items():
-        ns[attr] = property(lambda self, _g=get: _g())
-    mod.__class__ = type("_FsgsBound_" + mod.__name__.replace(".", "_"), (type(mod),), ns)
+    if not type(mod).__name__.startswith("_FsgsBound_"):  # install() runs from both import shims: one swap, not a stack of them
+        ns = {}
+        for attr, get in spec.items():
+            ns[attr] = property(lambda self, _g=get: _g())
+        mod.__class__ = type("_FsgsBound_" + mod.__name__.replace(".", "_"), (type(mod),), ns)
     _bound.setdefault(mod.__name__, [])
     _bound[mod.__name__] += [a for a in spec if a not in _bound[mod.__name__]]
     return True
@@ -257,8 +258,36 @@ def uninstall():
     _finder = None
 
 
+def verify(strict=False):
+    """FSGS_AUTOBIND asked for the fused path: every target that HAS been imported and has finished its body must carry its
+    bindings.  In-flight detection reads the private ModuleSpec._initializing; should a future CPython rename it, install()
+    would take the 'already imported' branch on a module whose body has not defined `render` yet, bind nothing, and train.py
+    would run the original with no error.  -> list of problems (warned about loudly; raised when `strict`)."""
+    import warnings
+
+    problems = []
+    for name, spec in TARGETS.items():
+        mod = sys.modules.get(name)
+        if mod is None or _executing(mod) or mod in _pending:
+            continue
+        if callable(spec):
+            continue  # (optimizer proxies: bound() reports them; nothing to look up by attribute name)
+        for attr in spec:
+            if attr in mod.__dict__ and "_fsgs_original_" + attr not in mod.__dict__ and not type(mod).__name__.startswith("_FsgsBound_"):
+                problems.append("%s.%s is the ORIGINAL although %s is set" % (name, attr, ENV))
+    if problems:
+        msg = "fsgs_amd.autobind: " + "; ".join(problems) + " -- import fsgs_amd.autobind before the reference's modules"
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
+    return problems
+
+
 def install_from_env():
-    """called by the import-name shims: FSGS_AUTOBIND=1 -> install()"""
+    """called by the import-name shims: FSGS_AUTOBIND=1 -> install(); what is already importable is verified on the spot and
+    everything once more at interpreter exit of the import phase (the finder drains its pending modules on every import)"""
     if os.environ.get(ENV, "") not in ("", "0"):
-        return install()
+        rep = install()
+        verify()
+        return rep
     return None

@@ -402,10 +402,8 @@ class Runner:
         it): no render is handed back.  Otherwise `render` / `render_dep` of the last iteration, as tensors of the caller's
         own (the zero-copy hand-out of the step driver's buffers is _mapping(borrow=True), for callers inside this class
         that copy what they keep before the next step: ADVICE r4)."""
-        pkg = self._mapping(cur_t, mapping_iter, progressive, want_pkg)
-        if pkg is not None and pkg.pop("views_of_step_buffers", False):
-            pkg = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in pkg.items()}
-        return pkg
+        # (_mapping(borrow=False) has already cloned what it hands out and carries no "views_of_step_buffers" marker)
+        return self._mapping(cur_t, mapping_iter, progressive, want_pkg)
 
     def _mapping(self, cur_t, mapping_iter, progressive, want_pkg=True, borrow=False):
         """borrow=True: the returned `render` / `render_dep` may be VIEWS of the step driver's buffers (marked

@@ -160,6 +160,13 @@ int fsgs_profile_read(int id, double *total_ms, int64_t *launches);
  * `max_pairs` (tile, Gaussian) pairs.  `state` must stay alive and untouched from
  * forward to its backward (it plays the role of UPSTREAM's geomBuffer /
  * binningBuffer / imgBuffer); `scratch` is only used during forward. */
+/* Which flavour of the blend kernels a call on a width x height image with these FsgsRasterCfg.flags takes on the CURRENT device:
+ * 1 = one wave per 16x16 tile, 4 = four waves per tile (csrc/raster_kernels.h use_quad_waves: the forward always 4; the backward
+ * up to 3.25 tiles per SIMD of the device -- 4.25 for the pose-only backward -- unless FSGS_FLAG_BLEND_ONE_WAVE / _QUAD_WAVES force
+ * one).  The backward's float summation order differs between the flavours, so profiles, bench lines and parity logs state
+ * which one ran.  No reference counterpart (UPSTREAM has one blend kernel). */
+int fsgs_blend_waves_per_tile(int width, int height, int flags, int backward, int pose_only);
+
 /* bytes of `scratch` a backward call with FSGS_FLAG_DETERMINISTIC needs (covers both fsgs_raster_backward and
  * fsgs_render_backward*): the per-Gaussian rows + one 64-byte row per pair slot + the per-workgroup dL/dw2c partials */
 size_t fsgs_deterministic_scratch_bytes(int P, int64_t max_pairs);

@@ -74,3 +74,17 @@ def test_rasterizer_argument_errors_match_upstream():
         r(means3D=x, means2D=x, opacities=x[:, :1], colors_precomp=x)  # no covariance
     with pytest.raises(RuntimeError):  # CPU tensors: loud failure, no fallback
         r(means3D=x, means2D=x, opacities=x[:, :1], colors_precomp=x, scales=x, rotations=torch.zeros(2, 4))
+
+
+def test_blend_flavour_query_follows_the_flags_and_the_tile_count(built_lib):
+    """fsgs_blend_waves_per_tile (which blend kernel a call takes is queryable, so bench lines and parity logs can
+    state it).  No GPU here: the device term falls back to an MI355X's 1024 SIMDs -> 3328 / 4352 tiles, the measured crossovers."""
+    from fsgs_amd import _lib
+
+    lib = _lib.load()
+    f = lib.fsgs_blend_waves_per_tile
+    assert f(1280, 1024, 0, 0, 0) == 4                      # the forward: four waves per tile at every size
+    assert f(640, 512, 0, 1, 0) == 4 and f(1280, 1024, 0, 1, 0) == 1      # C1: 1280 tiles; C2: 5120 tiles
+    assert f(1088, 896, 0, 1, 0) == 1 and f(1088, 896, 0, 1, 1) == 4      # 3808 tiles: mapping one wave, pose-only still four
+    assert f(1280, 1024, _lib.FSGS_FLAG_BLEND_QUAD_WAVES, 1, 0) == 4 and f(640, 512, _lib.FSGS_FLAG_BLEND_ONE_WAVE, 0, 0) == 1
+    assert f(0, 10, 0, 0, 0) < 0

@@ -132,6 +132,32 @@ def test_step_driver_kernels_agree_between_the_flavours(W, H, P):
     assert torch.allclose(one[1].t.detach(), quad[1].t.detach(), rtol=0, atol=1e-4)
 
 
+def test_flavours_agree_on_the_harness_scene_at_the_tight_tolerance():
+    """the pinned harness (tests/test_harness_pin_gpu.py) holds the four-waves backward only to the widened product
+    bounds; here the SAME scene (tests/golden/harness_pin.npz: 256x192, 983 Gaussians, SH degree as recorded) goes through both
+    flavours of the fused render directly -- forward bit-identical, every gradient within GRAD_TOL of its inf-norm -- so the
+    quad backward itself is pinned on that scene, not only its noise."""
+    import os
+
+    from fsgs_amd.render import render
+    from tests import ref_harness
+    from tests.test_render_gpu import _run
+
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness_pin.npz")))
+    pc, poses, frames = ref_harness.load_inputs(fx, DEV)
+    H, W = frames.colors[0].shape[-2:]
+    poses.set_pose(1, synth.PERTURBED_POSE["q"], synth.PERTURBED_POSE["t"])
+    g = torch.Generator(device="cpu").manual_seed(9)
+    wi = (torch.rand(3, H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    wd = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    ws = (torch.rand(H, W, generator=g) - 0.5).to(DEV) / (H * W)
+    for gs_grad, cam_grad in ((True, False), (False, True), (True, True)):
+        one, quad = _both(lambda: _run(render, pc, poses, gs_grad, cam_grad, wi, wd, ws))
+        for k in one[0]:
+            assert np.array_equal(one[0][k], quad[0][k]), k
+        _assert_grads_close(one[1], quad[1], "harness scene gs=%d cam=%d" % (gs_grad, cam_grad))
+
+
 def test_flavour_flags_reach_the_configuration_struct_and_bad_names_are_refused():
     """rasterizer.set_blend_variant -> FsgsRasterCfg.flags (include/fsgs.h: ONE_WAVE 32, QUAD_WAVES 64; neither = the
     library's own choice: forward four waves per tile, backward by the size of the tile grid)"""

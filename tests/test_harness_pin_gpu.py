@@ -41,17 +41,25 @@ def _run_gpu(fx, fused=True, with_global=False):
     return run
 
 
-@pytest.mark.parametrize("mode", ["deterministic", "product"])
+@pytest.mark.parametrize("mode", ["deterministic", "product", "product_one_wave"])
 def test_runner_reproduces_the_cpu_oracle_trajectory(mode):
+    """product_one_wave: the product path with the blend kernels forced to one wave per tile, held to round 4's
+    TIGHT bounds (5e-4 after the densification, 1.1e-3 in the global phase) -- the widened product bounds exist for the extra
+    atomic-order noise of the four-waves backward this grid size selects; the one-wave flavour must still meet the old ones, so a
+    regression the size of that noise cannot hide on every path at once."""
     from fsgs_amd import rasterizer
 
     fx = dict(np.load(FX))
-    post_rtol = ref_harness.POST_DENSIFY_RTOL if mode == "deterministic" else ref_harness.POST_DENSIFY_RTOL_PRODUCT
+    tight = mode in ("deterministic", "product_one_wave")
+    post_rtol = ref_harness.POST_DENSIFY_RTOL if tight else ref_harness.POST_DENSIFY_RTOL_PRODUCT
     prev = rasterizer.set_deterministic(mode == "deterministic")
+    prev_variant = rasterizer.set_blend_variant("one") if mode == "product_one_wave" else None
     try:
         run = _run_gpu(fx, with_global=True)
     finally:
         rasterizer.set_deterministic(prev)
+        if prev_variant is not None:
+            rasterizer.set_blend_variant(prev_variant)
     tr = run.trace[:run.after_progressive["n_trace"]]
     maps = [e for e in tr if e[0] == "map"]
     tracks = [e for e in tr if e[0] == "track"]
@@ -96,7 +104,8 @@ def test_runner_reproduces_the_cpu_oracle_trajectory(mode):
     assert [e[2][0] for e in gmaps] == fx["global_map_view"].tolist()
     assert [[e[1], e[2]] for e in gl if e[0] == "densify"] == fx["global_densify"].tolist()
     assert run.pc.num_points == int(fx["global_final_P"]) and run.pc.active_sh_degree == int(fx["global_sh_degree"]) == 2  # (raised at frame 0 and at global iteration 0)
-    np.testing.assert_allclose(np.array([e[3] for e in gmaps]), fx["global_map_loss"], rtol=ref_harness.GLOBAL_PHASE_RTOL_DETERMINISTIC if mode == "deterministic" else ref_harness.GLOBAL_PHASE_RTOL_PRODUCT)
+    np.testing.assert_allclose(np.array([e[3] for e in gmaps]), fx["global_map_loss"], rtol={"deterministic": ref_harness.GLOBAL_PHASE_RTOL_DETERMINISTIC, "product": ref_harness.GLOBAL_PHASE_RTOL_PRODUCT,
+                                     "product_one_wave": ref_harness.GLOBAL_PHASE_RTOL}[mode])
     np.testing.assert_allclose(run.pc.params["_xyz"].detach().mean(0).cpu().numpy(), fx["global_final_xyz_mean"], atol=5e-5)
     assert np.array_equal(run.poses.t.detach().cpu().numpy(), run.after_progressive["pose_t"])
 
