@@ -44,12 +44,67 @@ CONFIGS = {
     "X3": (1088, 896, 200_000, "trained"),  # 3808 tiles
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_SIMDS, VALU_CYCLES_PER_WAVE_INST, VALU_CLOCK_HZ = 1024, 2.0, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md
+VALU_SIMDS, VALU_CYCLES_PER_WAVE_INST, VALU_CLOCK_HZ = 1024, 2.0, 2.4e9  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md (2.4 GHz = the peak)
 
 
-def valu_frac(wave_insts, kernel_seconds):
-    """fraction of the spec VALU issue rate: (wave-instructions per SIMD x 2 cycles / 2.4 GHz) / kernel time"""
-    return (wave_insts / VALU_SIMDS) * VALU_CYCLES_PER_WAVE_INST / VALU_CLOCK_HZ / kernel_seconds
+def valu_frac(wave_insts, kernel_seconds, clock_hz=VALU_CLOCK_HZ):
+    """fraction of the spec VALU issue rate: (wave-instructions per SIMD x 2 cycles / shader clock) / kernel time"""
+    return (wave_insts / VALU_SIMDS) * VALU_CYCLES_PER_WAVE_INST / clock_hz / kernel_seconds
+
+
+def blend_flavours(W, H):
+    from fsgs_amd import _lib, rasterizer
+
+    lib = _lib.load()
+    flags = {"auto": 0, "one": _lib.FSGS_FLAG_BLEND_ONE_WAVE, "quad": _lib.FSGS_FLAG_BLEND_QUAD_WAVES}[rasterizer.blend_variant()]
+    q = lambda bwd, pose: int(lib.fsgs_blend_waves_per_tile(int(W), int(H), int(flags), bwd, pose))
+    return {"forward": q(0, 0), "backward": q(1, 0), "pose_only_backward": q(1, 1), "variant": rasterizer.blend_variant()}
+
+
+def load_issue_rates():
+    """newest profiles/r*_issue_rates.json (scripts/make_issue_rates_json.py): the shader clock MEASURED inside the blend kernels
+    and the issue micro-benchmark's ns per instruction and SIMD at 1..8 resident waves -- offline constants like the PMC counters"""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_rates.json")))
+    if not files:
+        return None, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+def valu_block(ent, kernel_name, family, avg_s, issue, issue_src):
+    """What actually bounds a blend kernel -- instruction issue -- in three numbers (VERDICT r5 #4):
+      valu_frac                 share of the SPEC issue rate (one wave64 VALU instruction per SIMD per 2 cycles) at the shader clock
+                                MEASURED inside the kernel (s_memtime / s_memrealtime per tile, diagnostics flavour); rounds 1-5
+                                assumed 2.4 GHz
+      valu_frac_of_achievable   share of what scripts/ubench/issue_clock.hip reaches with the backward body's instruction MIX
+                                (1 exp + 1 rcp + 3 cmp/cndmask + FMAs + broadcast LDS reads) at the number of waves per SIMD this
+                                kernel's registers allow -- the roof a kernel of this mix and occupancy really has
+    (rounds 4-5 also printed `valu_busy` = SQ_ACTIVE_INST_VALU x 4 / SIMDs / clock / time: the counter reads 4.0-4.2 per
+    instruction on EVERY kernel, i.e. it is a per-instruction constant, not pipe occupancy -- dropped, VERDICT r5 weak #3)"""
+    wi = ent.get("valu_wave_insts")
+    if not wi:
+        return None
+    per_simd = wi / VALU_SIMDS
+    out = {"wave_insts": wi, "salu_wave_insts": ent.get("salu_wave_insts"), "ns_per_valu_inst_per_simd": avg_s * 1e9 / per_simd,
+           "sq": ent.get("sq")}
+    clock_hz, clock_src = VALU_CLOCK_HZ, "assumed peak clock (no profiles/r*_issue_rates.json)"
+    if issue:
+        mhz = issue.get("shader_clock_mhz", {}).get(family)
+        if mhz:
+            clock_hz, clock_src = mhz * 1e6, "%s: delta s_memtime / delta s_memrealtime inside the kernel" % issue_src
+        w = None
+        for k, v in issue.get("waves_per_simd", {}).items():
+            if kernel_name.startswith(k) or k.startswith(kernel_name):
+                w = v["waves_per_simd"]
+        rows = issue.get("ubench", {}).get("blend", {})
+        if w and str(w) in rows:
+            ns = rows[str(w)]["ns_per_inst_per_simd"]
+            out.update({"waves_per_simd": w, "ubench_ns_per_inst_per_simd_at_that_occupancy": ns,
+                        "valu_frac_of_achievable": per_simd * ns * 1e-9 / avg_s})
+        out["ubench_blend_mix_ns_per_inst_per_simd"] = {k: v["ns_per_inst_per_simd"] for k, v in sorted(rows.items(), key=lambda kv: int(kv[0]))}
+    out.update({"valu_frac": valu_frac(wi, avg_s, clock_hz), "shader_clock_mhz": clock_hz / 1e6, "shader_clock_source": clock_src})
+    return out
 
 
 def build_problem(cfg_name, device, rank, world, n_frames=8, scene="default", texture=0.0):
@@ -851,30 +906,14 @@ def main():
                 roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % src
                 # the counters are an offline constant of that file, collected at ITS pair count; this run's R is `num_rendered`
                 roofline["traffic_collected_at_num_rendered"] = pmc.get("num_rendered")
-                wi = ent.get("valu_wave_insts")
-                if wi:
-                    # what actually bounds this kernel: instruction issue.  Measured (scripts/ubench/inst_cost.hip,
-                    # profiles/r02_inst_cost_ubench.txt): a SIMD retires one plain VALU wave-instruction per ~2.0 ns
-                    # at 4 waves/SIMD and per ~1.4 ns at 8 (one wave alone: 3.8 ns) -- issue is paced per wave.
-                    per_simd = avg_s * 1e9 / (wi / 1024.0)
-                    # roofline.valu_frac: the fraction of the SPEC VALU issue rate -- one wave-instruction per SIMD per 2
-                    # cycles (a wave64 op on a 32-wide datapath) at 2.4 GHz over 1024 SIMDs -- this kernel's instruction
-                    # stream reaches: (SQ_INSTS_VALU / 1024 x 2 / 2.4 GHz) / avg kernel time.  The roof these kernels
-                    # actually have (north_star declares HBM; `frac` above stays the mandated HBM fraction).
-                    roofline["valu_frac"] = valu_frac(wi, avg_s)
-                    # roofline.valu_busy: the share of the kernel's duration in which the VALU pipes were executing --
-                    # SQ_ACTIVE_INST_VALU (quad-cycles, x4) / 1024 SIMDs / 2.4 GHz / kernel time.  ~1.0 = the pipe is
-                    # never idle: only fewer instructions can make the kernel faster (valu_frac divides by the 2-cycle SPEC
-                    # issue rate, which a SIMD with 4-5 resident waves does not reach)
-                    acpi = ent.get("active_valu_cycles_per_inst")
-                    if acpi:
-                        roofline["valu_busy"] = acpi * wi / VALU_SIMDS / VALU_CLOCK_HZ / avg_s
-                    roofline["valu"] = {"wave_insts": wi, "salu_wave_insts": ent.get("salu_wave_insts"),
-                                        "ns_per_valu_inst_per_simd": per_simd,
-                                        "ubench_ns_per_fma_at_4_and_8_waves": [2.02, 1.38],
-                                        "waves_per_simd": ent.get("waves_per_simd"),
-                                        "active_valu_cycles_per_inst": ent.get("active_valu_cycles_per_inst"),
-                                        "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU in %s" % src}
+                issue, issue_src = load_issue_rates()
+                vb = valu_block(ent, hits[0], "blend_bwd", avg_s, issue, issue_src)
+                if vb:
+                    roofline["valu_frac"] = vb["valu_frac"]
+                    if "valu_frac_of_achievable" in vb:
+                        roofline["valu_frac_of_achievable"] = vb["valu_frac_of_achievable"]
+                    vb["source"] = "SQ_INSTS_VALU and the SQ_* stall counters in %s" % src
+                    roofline["valu"] = vb
                 # the second issue-bound kernel, same definitions: blend_fwd (HIP events of this run; counters offline)
                 fms, fl = prof.get("blend_fwd", (0.0, 0))
                 Cf = 4 if (use_fast and C == 6 and getattr(stepper, "mapping_planes4", False)) else C  # planes the step's forward blends
@@ -884,14 +923,12 @@ def main():
                     fent = pmc["kernels"][fhits[0]]
                     f_alg = R * (4 + 24 + 4 * Cf) + H * W * (4 * Cf + 4 + 8)
                     f_s = fms / fl / 1e3
+                    fvb = valu_block(fent, fhits[0], "blend_fwd", f_s, issue, issue_src) or {}
                     roofline["blend_fwd"] = {
                         "kernel": fhits[0], "avg_kernel_ms": fms / fl, "algorithmic_bytes": f_alg,
                         "achieved": f_alg / f_s / 1e9, "frac": f_alg / f_s / 1e9 / HBM_PEAK_GBS,
-                        "traffic": fent.get("traffic_bytes"),
-                        "valu_frac": valu_frac(fent["valu_wave_insts"], f_s) if fent.get("valu_wave_insts") else None,
-                        "valu_busy": (fent["active_valu_cycles_per_inst"] * fent["valu_wave_insts"] / VALU_SIMDS / VALU_CLOCK_HZ / f_s
-                                      if fent.get("valu_wave_insts") and fent.get("active_valu_cycles_per_inst") else None),
-                        "valu_wave_insts": fent.get("valu_wave_insts")}
+                        "traffic": fent.get("traffic_bytes"), "valu_frac": fvb.get("valu_frac"),
+                        "valu_frac_of_achievable": fvb.get("valu_frac_of_achievable"), "valu": fvb or None}
         except Exception as e:  # noqa: BLE001
             roofline["traffic_error"] = "%s: %s" % (type(e).__name__, e)
             sys.stderr.write("bench.py: roofline.traffic unavailable -- %s\n" % roofline["traffic_error"])
@@ -1013,6 +1050,43 @@ def main():
         dense = {"scene": "dense (every Gaussian x%.2f)" % SCENES["dense"], "num_rendered": Rd,
                  "upstream_num_rendered": upstream_pairs(st2, W, H), "ms_per_step": dd / nd * 1e3, "iters_per_sec": nd / dd,
                  "kernels_ms": {k: v[0] / v[1] for k, v in pd_.items() if v[1]}}
+        # round 6 (VERDICT r5 #4 e): the dense scene's OWN roofline block -- algorithmic bytes at ITS pair count, HIP events of THIS
+        # loop, counters from ITS PMC / SQ passes (profiles/r*_pmc_traffic_dense.json: PMC_ARGS="--scene dense" scripts/gpu_pmc.sh)
+        try:
+            import glob
+
+            dfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_dense.json")))
+            dpmc = json.load(open(dfiles[-1])) if dfiles else None
+            dsrc = os.path.relpath(dfiles[-1], ROOT) if dfiles else None
+            issue, issue_src = load_issue_rates()
+            Pd = st2.pc.num_points if hasattr(st2, "pc") else P
+            droof = {}
+            for fam, alg in (("blend_bwd", Rd * (4 + 24 + 4 * 6) + H * W * (4 * 4 + 8) + Pd * 4 * (6 + 6)),
+                             ("blend_fwd", Rd * (4 + 24 + 4 * 6) + H * W * (4 * 6 + 4 + 8))):
+                if fam not in pd_ or not pd_[fam][1]:
+                    continue
+                t_s = pd_[fam][0] / pd_[fam][1] / 1e3
+                blk = {"bound": "hbm", "avg_kernel_ms": t_s * 1e3, "algorithmic_bytes": alg, "achieved": alg / t_s / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None}
+                if dpmc:
+                    hits = [k for k in dpmc["kernels"] if k.startswith(fam)]
+                    if len(hits) == 1:
+                        ent = dpmc["kernels"][hits[0]]
+                        blk.update({"kernel": hits[0], "traffic": ent["traffic_bytes"], "traffic_over_algorithmic": ent["traffic_bytes"] / alg,
+                                    "traffic_source": dsrc, "traffic_collected_at_num_rendered": dpmc.get("num_rendered")})
+                        vb = valu_block(ent, hits[0], fam, t_s, issue, issue_src)
+                        if vb:
+                            blk.update({"valu_frac": vb["valu_frac"], "valu_frac_of_achievable": vb.get("valu_frac_of_achievable"), "valu": vb})
+                    else:
+                        blk["traffic_error"] = "%s has %d entries starting with %r" % (dsrc, len(hits), fam)
+                else:
+                    blk["traffic_error"] = "no profiles/r*_pmc_traffic_dense.json"
+                droof[fam] = blk
+            dense["roofline"] = droof.get("blend_bwd")
+            if "blend_fwd" in droof:
+                dense["roofline_blend_fwd"] = droof["blend_fwd"]
+        except Exception as e:  # noqa: BLE001
+            dense["roofline_error"] = "%s: %s" % (type(e).__name__, e)
         stepper = st2
 
     # ---- extra (N > 1): the step's one collective on its own, so the scaling numbers can be read ----
@@ -1149,6 +1223,9 @@ def main():
                                 "the previous step's Adam kernel (colour cache: evaluated once per step, on the updated "
                                 "parameters)" if use_fast else None,
                 "fused_render": fused, "hip_losses": hip_losses,
+                # which flavour of the blend kernels ran (waves per 16x16 tile; fsgs_blend_waves_per_tile on THIS device and
+                # the flags in force): the backward's summation order depends on it, so every A/B and parity log states it
+                "blend_waves_per_tile": blend_flavours(W, H),
                 "step_driver": "fast_step (one C-ABI call per stage, no autograd)" if use_fast else "torch.autograd",
                 "optimizer": ("Adam on all 59 floats/Gaussian every step: fused into the render-backward kernel (fsgs_render_backward_adam)"
                               if (use_fast and world == 1) else "Adam on all 59 floats/Gaussian every step, from the all-reduced compact [P,14] gradient (fsgs_adam_step_compact)"

@@ -12,7 +12,7 @@ for counters in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_S
                 "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"; do
   pass=$((pass + 1))
   rm -rf /tmp/sq && mkdir -p /tmp/sq
-  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d /tmp/sq -o sq -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-extras > gpurun_out/${tag}_pass${pass}.log 2>&1
+  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d /tmp/sq -o sq -- python bench.py --config $cfg ${PMC_ARGS:-} --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-extras > gpurun_out/${tag}_pass${pass}.log 2>&1
   f=$(find /tmp/sq -name "*counter_collection.csv" | head -1)
   python - "$f" "gpurun_out/${tag}_summary.txt" <<'PY'
 import csv, sys, collections, re

@@ -1,7 +1,10 @@
 """gpurun_out/pmc_{FETCH,WRITE}_SIZE_summary.csv (scripts/gpu_pmc.sh) + gpurun_out/sq_summary.txt (scripts/gpu_sq.sh)
 -> profiles/<tag>_pmc_*.csv, profiles/<tag>_sq_counters.txt and profiles/<tag>_pmc_traffic.json (read by bench.py).
 
-    python scripts/make_pmc_json.py r02 <R> [<P> <W> <H>]
+    python scripts/make_pmc_json.py r02 <R> [<P> <W> <H> [<suffix>]]
+
+<suffix> (round 6): e.g. "dense" -- reads gpurun_out/pmc_*_summary_dense.csv / sq_dense_summary.txt (scripts/gpu_pmc.sh and
+gpu_sq.sh run with PMC_ARGS="--scene dense") and writes profiles/<tag>_pmc_traffic_dense.json for the bench's dense-scene block.
 
 Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM section, and the calibration in profiles/r02_fetch_size_calibration.txt,
 scripts/ubench/gather_fetch.hip): wide COALESCED streaming reads are tallied at half their bytes (x2); a gather of whole
@@ -20,20 +23,22 @@ R = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 300000
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 1280
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
+sfx = ("_" + sys.argv[6]) if len(sys.argv) > 6 else ""
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    shutil.copy("gpurun_out/pmc_%s_summary.csv" % c, "profiles/%s_pmc_%s_summary.csv" % (tag, c))
+    shutil.copy("gpurun_out/pmc_%s_summary%s.csv" % (c, sfx), "profiles/%s_pmc_%s_summary%s.csv" % (tag, c, sfx))
 
 
 def load(f, col):
     return {r["kernel"]: float(r[col]) for r in csv.DictReader(open(f))}
 
 
-fe = load("profiles/%s_pmc_FETCH_SIZE_summary.csv" % tag, "FETCH_SIZE_per_launch")
-wr = load("profiles/%s_pmc_WRITE_SIZE_summary.csv" % tag, "WRITE_SIZE_per_launch")
+fe = load("profiles/%s_pmc_FETCH_SIZE_summary%s.csv" % (tag, sfx), "FETCH_SIZE_per_launch")
+wr = load("profiles/%s_pmc_WRITE_SIZE_summary%s.csv" % (tag, sfx), "WRITE_SIZE_per_launch")
 sq = {}
 try:
-    shutil.copy("gpurun_out/sq_summary.txt", "profiles/%s_sq_counters.txt" % tag)
-    for line in open("gpurun_out/sq_summary.txt"):
+    sq_src = "gpurun_out/sq%s_summary.txt" % sfx
+    shutil.copy(sq_src, "profiles/%s_sq_counters%s.txt" % (tag, sfx))
+    for line in open(sq_src):
         m = re.match(r"(\S.*?)\s+launches \d+ (.*)", line)
         if m:
             # (one line per kernel and --pmc pass: merge the passes)
@@ -48,7 +53,8 @@ coalesced = {
 }
 out = {"_about": __doc__.strip().split("\n\n")[-1] + "  Workload: bench.py config C2 (%dx%d, %d Gaussians, R=%d, fused "
        "6-channel render).  Counter unit = KiB." % (W, H, P, R),
-       "config": "C2", "num_rendered": R, "source": "profiles/%s_pmc_*_summary.csv, profiles/%s_sq_counters.txt" % (tag, tag),
+       "config": "C2", "scene": sfx[1:] or "default", "num_rendered": R,
+       "source": "profiles/%s_pmc_*_summary%s.csv, profiles/%s_sq_counters%s.txt" % (tag, sfx, tag, sfx),
        "kernels": {}}
 for k in sorted(set(fe) | set(wr)):
     if k.startswith(("at::", "rocprim", "__amd")):
@@ -69,8 +75,13 @@ for k in sorted(set(fe) | set(wr)):
                 ent["active_valu_cycles_per_inst"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / iv
                 ent["sq_wave_cycles"] = 4.0 * c.get("SQ_WAVE_CYCLES", 0.0)
                 ent["sq_wait_inst_any_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)
+                # round 6 (VERDICT r5 #4 d): the counters as collected (SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles per
+                # the guide; SQ_BUSY_CYCLES summed over the shader engines) -- per launch
+                ent["sq"] = {n: c[n] for n in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                               "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+                                               "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA") if n in c}
     out["kernels"][k] = ent
-json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
+json.dump(out, open("profiles/%s_pmc_traffic%s.json" % (tag, sfx), "w"), indent=1)
 for k, v in out["kernels"].items():
     print("%-40s fetch_raw %7.1f MB  write %7.1f MB  traffic %7.1f MB  %s" % (
         k[:40], v["fetch_raw_bytes"] / 1e6, v["write_bytes"] / 1e6, v["traffic_bytes"] / 1e6,

@@ -26,12 +26,21 @@ __device__ __forceinline__ Stamp stamp() {
   return s;
 }
 
+// `gate`: every workgroup checks in and spins (bounded) until all of the launch have -- so the timed loops of ALL waves overlap,
+// W per SIMD, or the run says that they did not (round 6's first version timed W = 8 launches whose waves lasted half the
+// kernel: the launch ramp / placement had put them in two generations, and "8 waves" meant ~4.3 resident).
 template <int MIX>
-__global__ __launch_bounds__(256) void k(float *out, unsigned long long *st, int iters, float b, float c) {
+__global__ __launch_bounds__(256) void k(float *out, unsigned long long *st, int iters, float b, float c, unsigned *gate) {
   __shared__ float4 lds[64];
   float a[8];
   for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 0.001f + i;
   if (threadIdx.x < 64) lds[threadIdx.x] = make_float4(a[0], a[1], b, c);
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+    if (spins >= (1 << 22)) __hip_atomic_fetch_add(gate + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // gave up
+  }
   __syncthreads();
   const Stamp s0 = stamp();
   for (int it = 0; it < iters; it++) {
@@ -69,14 +78,15 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *st, int
 }
 
 template <int MIX>
-static void run(int W, float *d_out, unsigned long long *d_st) {
+static void run(int W, float *d_out, unsigned long long *d_st, unsigned *d_gate) {
   const int blocks = 256 * W, iters = 20000, per_iter = 40;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 3; rep++) {
+    CK(hipMemsetAsync(d_gate, 0, 8, 0));
     CK(hipEventRecord(e0));
-    k<MIX><<<blocks, 256>>>(d_out, d_st, iters, 0.999f, 0.001f);
+    k<MIX><<<blocks, 256>>>(d_out, d_st, iters, 0.999f, 0.001f, d_gate);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -86,17 +96,22 @@ static void run(int W, float *d_out, unsigned long long *d_st) {
   CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
   double cyc = 0, rt = 0;
   for (size_t w = 0; w < (size_t)blocks * 4; w++) { cyc += (double)st[2 * w]; rt += (double)st[2 * w + 1]; }
+  unsigned gate[2];
+  CK(hipMemcpy(gate, d_gate, 8, hipMemcpyDeviceToHost));
   const double mhz = cyc / rt * 100.0;                       // shader cycles per 100 MHz tick
   const double n_inst = (double)iters * per_iter * W;        // wave-instructions per SIMD
-  const double cyc_per_wave = cyc / ((double)blocks * 4);    // a wave's loop, in shader cycles
-  printf("%-5s W=%d waves/SIMD: %7.3f ms  %6.3f ns/inst/SIMD  shader clock %6.0f MHz  %5.2f cycles/inst/SIMD  (%4.2f inst/cycle/SIMD; wave loop %.0f cycles)\n",
-         MIX ? "blend" : "fma", W, best, best * 1e6 / n_inst, mhz, cyc_per_wave / n_inst, n_inst / cyc_per_wave, cyc_per_wave);
+  const double wave_us = rt / ((double)blocks * 4) * 0.01;   // a wave's timed loop, wall time
+  const double cyc_per_wave = cyc / ((double)blocks * 4);    // ... and in shader cycles: all W waves of a SIMD run it at once
+  printf("%-5s W=%d waves/SIMD: kernel %7.3f ms, a wave's loop %7.3f ms (%s)  shader clock %6.0f MHz  %6.3f ns/inst/SIMD = %5.2f cycles/inst/SIMD "
+         "(%4.2f inst/cycle/SIMD)\n",
+         MIX ? "blend" : "fma", W, best, wave_us * 1e-3, gate[1] ? "NOT all resident at once" : "all waves resident at once",
+         mhz, wave_us * 1e3 / n_inst, cyc_per_wave / n_inst, n_inst / cyc_per_wave);
 }
 
 int main() {
-  float *d_out; unsigned long long *d_st;
-  CK(hipMalloc(&d_out, 4 * 256 * 256 * 8)); CK(hipMalloc(&d_st, 16 * 256 * 8 * 4));
-  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<0>(W, d_out, d_st);
-  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<1>(W, d_out, d_st);
+  float *d_out; unsigned long long *d_st; unsigned *d_gate;
+  CK(hipMalloc(&d_out, 4 * 256 * 256 * 8)); CK(hipMalloc(&d_st, 16 * 256 * 8 * 4)); CK(hipMalloc(&d_gate, 8));
+  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<0>(W, d_out, d_st, d_gate);
+  for (int W : {1, 2, 3, 4, 5, 6, 8}) run<1>(W, d_out, d_st, d_gate);
   return 0;
 }
