@@ -851,6 +851,26 @@ __device__ __forceinline__ bool blend_fwd_pixel(float &T, float &D, float2v (&ac
   return true;
 }
 
+// The same step for the record whose alpha has ALREADY been evaluated (e, ok): the two-records-per-trip walk of the four-waves
+// forward evaluates the exponents of two list neighbours side by side -- they do not depend on the transmittance -- and then
+// blends them in list order through here.  Same operations on the same values as blend_fwd_pixel: bit-identical results.
+template <int CP, bool WITH_DEPTH>
+__device__ __forceinline__ void blend_fwd_apply(float &T, float &D, float2v (&acc)[CP], uint32_t &last, const SplatEval &e, bool ok,
+                                                float bz, const float2v (&bcol2)[4], uint32_t pos) {
+  if (!(T > 0.f) || !ok) return;
+  const float test_T = T * (1.0f - e.alpha);
+  if (test_T < 0.0001f) {
+    T = -T;
+    return;
+  }
+  const float w = e.alpha * T;
+#pragma unroll
+  for (int cp = 0; cp < CP; cp++) acc[cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[cp]);
+  if (WITH_DEPTH) D = fmaf(bz, w, D);
+  T = test_T;
+  last = pos;
+}
+
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
 // silhouette / depth^2 planes).  WITH_DEPTH: also accumulate the depth-fork's third output.
 // DIAG (diagnostics flavour of the library only, `FSGS_DIAG=1 python free-surgs_amd/build.py`): the SAME instruction stream plus
@@ -1070,6 +1090,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // Per pair this is MORE issue slots than the one-wave kernel on a full chip (each wave pays its own loop and record reads),
 // which is why the big grids keep the one-wave kernel: launch_blend_fwd picks by the number of tiles.
 constexpr int QW_BATCH = 256;
+#ifndef FSGS_FWD_PAIR
+#define FSGS_FWD_PAIR 0  // two records per trip of the set-bit walk (A/B: FSGS_CFLAGS=-DFSGS_FWD_PAIR=1; profiles/r06_ab_fwd_pair.txt)
+#endif
 template <int C, bool WITH_DEPTH>
 __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
@@ -1130,6 +1153,37 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
       const int nsub = (n + 63) >> 6;
       for (int sub = 0; sub < nsub; sub++) {
         unsigned long long bits = __ballot(((reach[sub * 64 + lane] >> q) & 1u) != 0u);
+#if FSGS_FWD_PAIR
+        // Two set bits per trip: the exponents of two list neighbours are independent of the transmittance, so
+        // their record reads and v_exp chains run side by side and the walk's scalar bookkeeping (find-first-set, clear, compare,
+        // branch) is paid once per two records; the blends then follow in list order (blend_fwd_apply).
+        while (bits) {
+          const int j0 = sub * 64 + (int)__builtin_ctzll(bits);  // scalar
+          bits &= bits - 1ull;
+          const bool two = bits != 0ull;  // scalar
+          const int j1 = two ? sub * 64 + (int)__builtin_ctzll(bits) : j0;
+          bits &= bits - 1ull;            // (0 & anything = 0 when there was no second bit)
+          const float4 a0 = rec[j0 * REC4 + 0], a1 = rec[j0 * REC4 + 1];
+          const float4 b0 = rec[j1 * REC4 + 0], b1 = rec[j1 * REC4 + 1];
+          SplatEval e0, e1;
+          const bool ok0 = splat_alpha(__fsub_rn(__fsub_rn(a0.x, px0), offx), __fsub_rn(__fsub_rn(a0.y, py0), offy), a0.z, a0.w, a1.x,
+                                       a1.y, e0);
+          const bool ok1 = splat_alpha(__fsub_rn(__fsub_rn(b0.x, px0), offx), __fsub_rn(__fsub_rn(b0.y, py0), offy), b0.z, b0.w, b1.x,
+                                       b1.y, e1) && two;
+          {
+            const float4 r2 = rec[j0 * REC4 + 2];
+            const float4 r3 = C > 4 ? rec[j0 * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
+            blend_fwd_apply<CP, WITH_DEPTH>(T, D, acc, last, e0, ok0, a1.z, bcol2, (uint32_t)(base + j0 - rg.x + 1));
+          }
+          {
+            const float4 r2 = rec[j1 * REC4 + 2];
+            const float4 r3 = C > 4 ? rec[j1 * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
+            blend_fwd_apply<CP, WITH_DEPTH>(T, D, acc, last, e1, ok1, b1.z, bcol2, (uint32_t)(base + j1 - rg.x + 1));
+          }
+        }
+#else
         while (bits) {
           const int j = sub * 64 + (int)__builtin_ctzll(bits);  // scalar
           bits &= bits - 1ull;
@@ -1140,6 +1194,7 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
           blend_fwd_pixel<CP, WITH_DEPTH>(T, D, acc, last, __fsub_rn(dx0, offx), __fsub_rn(dy0, offy), r0.z, r0.w,
                                           r1.x, r1.y, r1.z, bcol2, (uint32_t)(base + j - rg.x + 1));
         }
+#endif
         if (__ballot(T > 0.f) == 0ull) break;  // the quadrant finished inside this batch
       }
     }

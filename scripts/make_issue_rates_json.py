@@ -26,7 +26,7 @@ for kind in ("bwd", "fwd"):
         if v:
             out["shader_clock_samples_mhz"]["blend_" + kind] = v
             out["shader_clock_mhz"]["blend_" + kind] = sorted(v)[len(v) // 2]
-pat = re.compile(r"(fma|blend)\s+W=(\d+) waves/SIMD: kernel\s+([\d.]+) ms, a wave's loop\s+([\d.]+) ms \((.*?)\)\s+shader clock\s+(\d+) MHz\s+"
+pat = re.compile(r"(fma|blend)\s+W=(\d+) waves/SIMD: kernel\s+([\d.]+) ms \(mean wave loop\s+([\d.]+) ms; (.*?)\)\s+shader clock\s+(\d+) MHz\s+"
                  r"([\d.]+) ns/inst/SIMD =\s+([\d.]+) cycles/inst/SIMD")
 f = os.path.join(root, "gpurun_out", "%s_issue_clock.txt" % tag)
 for l in open(f):

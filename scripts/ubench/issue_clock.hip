@@ -98,14 +98,18 @@ static void run(int W, float *d_out, unsigned long long *d_st, unsigned *d_gate)
   for (size_t w = 0; w < (size_t)blocks * 4; w++) { cyc += (double)st[2 * w]; rt += (double)st[2 * w + 1]; }
   unsigned gate[2];
   CK(hipMemcpy(gate, d_gate, 8, hipMemcpyDeviceToHost));
-  const double mhz = cyc / rt * 100.0;                       // shader cycles per 100 MHz tick
+  const double mhz = cyc / rt * 100.0;                       // shader cycles per 100 MHz tick, over every wave's own loop
   const double n_inst = (double)iters * per_iter * W;        // wave-instructions per SIMD
-  const double wave_us = rt / ((double)blocks * 4) * 0.01;   // a wave's timed loop, wall time
-  const double cyc_per_wave = cyc / ((double)blocks * 4);    // ... and in shader cycles: all W waves of a SIMD run it at once
-  printf("%-5s W=%d waves/SIMD: kernel %7.3f ms, a wave's loop %7.3f ms (%s)  shader clock %6.0f MHz  %6.3f ns/inst/SIMD = %5.2f cycles/inst/SIMD "
+  const double wave_ms = rt / ((double)blocks * 4) * 1e-5;   // MEAN duration of a wave's timed loop
+  // The rate is taken from the KERNEL's duration: a SIMD arbitrates VALU issue by age, so its W waves do not advance together --
+  // the oldest finishes first, the youngest last -- and the mean wave duration is well below the time the SIMD needs for all of
+  // them (W = 8: 3.9 ms against 6.6 ms; the first version of this file divided by the wave mean and "measured" 0.74 instructions
+  // per cycle, above the 32-lanes-per-cycle datapath).
+  const double ns = best * 1e6 / n_inst;
+  printf("%-5s W=%d waves/SIMD: kernel %7.3f ms (mean wave loop %7.3f ms; %s)  shader clock %6.0f MHz  %6.3f ns/inst/SIMD = %5.2f cycles/inst/SIMD "
          "(%4.2f inst/cycle/SIMD)\n",
-         MIX ? "blend" : "fma", W, best, wave_us * 1e-3, gate[1] ? "NOT all resident at once" : "all waves resident at once",
-         mhz, wave_us * 1e3 / n_inst, cyc_per_wave / n_inst, n_inst / cyc_per_wave);
+         MIX ? "blend" : "fma", W, best, wave_ms, gate[1] ? "NOT all resident at once" : "all waves resident at once",
+         mhz, ns, ns * mhz * 1e-3, 1.0 / (ns * mhz * 1e-3));
 }
 
 int main() {
