@@ -55,7 +55,7 @@ def _scene(cfg):
 def _report(name, rec):
     line = json.dumps(dict(test=name, **rec))
     print(line)
-    dump_attribution_log("r05_full_size_parity", json.loads(line))
+    dump_attribution_log("r06_full_size_parity", json.loads(line))
 
 
 def _assert_mostly_plain(stats, what):

@@ -169,7 +169,7 @@ def _record(got, ref, alt, test="harness_c1"):
                                   "reference_second_run": np.asarray(alt["pose_metrics"]).tolist()}
     rec["psnr_values"] = {"hip": np.asarray(got["psnr_test"]).tolist(), "reference": np.asarray(ref["psnr_test"]).tolist(),
                           "reference_second_run": np.asarray(alt["psnr_test"]).tolist()}
-    dump_attribution_log("r05_harness_c1", json.loads(json.dumps(rec)))
+    dump_attribution_log("r06_harness_c1", json.loads(json.dumps(rec)))
 
 
 def test_deterministic_c1_runs_are_bit_identical_and_sit_close_to_the_reference(oracle32):

@@ -114,7 +114,7 @@ def test_c1_init_scene_eight_poses(oracle32):
         # the witnessed outliers are a handful, and so is the set of fragile pixels the allowance applies to
         assert stats["image"][0] <= 40 and stats["depth"][0] <= 40, stats
         # the achieved error of every tensor, next to the full-size records
-        dump_attribution_log("r05_full_size_parity", dict(
+        dump_attribution_log("r06_full_size_parity", dict(
             test="raster_op", cfg="C1", pose=i, P=P, num_rendered_upstream=R,
             tensors={k: dict(outliers=v.outliers, size=v.size, max_err=v.max_err, p9999=v.p9999,
                              max_err_plain=v.max_err_plain, scale=v.scale, max_err_zero_amp=v.max_err_zero_amp,
@@ -558,7 +558,7 @@ def test_witnessed_outliers_of_c1_and_the_sweep_are_few_and_unsigned():
     pos, neg, z, share = assert_sign_balanced(recs, "C1 poses + 40-seed sweep")
     summary["sign_balance"] = dict(pos=pos, neg=neg, z=z, positive_share=share)
     print(summary)
-    dump_attribution_log("r05_outlier_statistics", summary)
+    dump_attribution_log("r06_outlier_statistics", summary)
 
 
 def test_unsupported_channel_count_is_an_error_not_a_wrong_image():
