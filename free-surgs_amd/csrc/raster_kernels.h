@@ -1336,6 +1336,9 @@ struct BwdSlots {
 // pair_rows[p][c] (a plain store into the pair's own 16-float row, passed in `grad_acc`); det_gather_kernel then sums a
 // Gaussian's rows in a fixed order.
 template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, int DIAG = 0, bool DET = false>
+#ifndef FSGS_BWD_PRIO_STEP
+#define FSGS_BWD_PRIO_STEP 0  // > 0: s_setprio by the entries a wave still has to walk (A/B: FSGS_CFLAGS=-DFSGS_BWD_PRIO_STEP=64)
+#endif
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
 #endif
@@ -1412,6 +1415,21 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   const int my_u = slots.u, my_c = slots.c;
   const bool c_used = slots.used;
   while (hi > 0) {
+#if FSGS_BWD_PRIO_STEP
+    // Issue priority by REMAINING work (longest remaining first): a SIMD arbitrates between its resident waves by priority, then
+    // age.  With the longest-first dispatch order the oldest wave of a SIMD is its longest tile, which age alone keeps ahead of
+    // the others to its very end -- it finishes first, the youngest (shortest) tiles last, alone on their SIMD, where a lone wave
+    // issues at less than half the rate of five (profiles/r06_tile_times_bwd.txt: lists of 300+ entries done after 180 us, lists
+    // of 100..200 after 225-240 us).  Four levels: a wave drops one each time FSGS_BWD_PRIO_STEP fewer entries remain, so the waves
+    // of a SIMD converge on a common finish and the SIMD keeps its five waves to the end.
+    {  // (s_setprio takes an immediate: a wave-uniform switch)
+      const int level = hi / FSGS_BWD_PRIO_STEP;
+      if (level >= 3) __builtin_amdgcn_s_setprio(3);
+      else if (level == 2) __builtin_amdgcn_s_setprio(2);
+      else if (level == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
     uint32_t gid = plist[rg.x + lo + (lane < n ? lane : 0)];

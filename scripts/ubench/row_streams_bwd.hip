@@ -99,7 +99,10 @@ __global__ __launch_bounds__(64, 5) void pair_loop(float *acc, int npairs) {
 }
 
 // ---- the row-stream step (four waves per tile, one pixel per lane, every 16-lane row its own record) ------------------------
-template <bool LDS_ATOMIC>
+// ACC: 0 = no accumulation (VALU floor, not a correct kernel), 1 = ds_add_f32 into per-record LDS sums (flushed once per batch),
+//      2 = one global atomic per lane and step straight into the per-record rows (5.75 x 12 = 69 atomics per pair where the
+//          shipping kernel issues 12-14)
+template <int ACC>
 __global__ __launch_bounds__(256) void row_loop(float *acc, int nsteps) {
   __shared__ float4 rec[BATCH * 3];
   __shared__ float sums[BATCH * 16];
@@ -124,8 +127,10 @@ __global__ __launch_bounds__(256) void row_loop(float *acc, int nsteps) {
     blend_bwd_pixel<CG, true, false>(v, T, gB, gBr, g, __fsub_rn(r0.x, px), __fsub_rn(r0.y, py), r0.z, r0.w, r1.x, r1.y, bcol, true);
     T = T > 1.0f ? 0.05f : T;
     const float tot = row_transpose_reduce12(v, lane);
-    if constexpr (LDS_ATOMIC) {
+    if constexpr (ACC == 1) {
       if (l < 12 && tot != 0.f) atomicAdd(&sums[j * 16 + l], tot);  // ds_add_f32: four addresses per instruction, one per row
+    } else if constexpr (ACC == 2) {
+      if (l < 12 && tot != 0.f) atomicAdd(acc + ((size_t)blockIdx.x * BATCH + j) * 16 + l, tot);
     } else {
       // (no accumulation at all -- NOT a correct kernel: the VALU-only floor of a row step, to separate the reduction's
       // instruction cost from the LDS atomics' in the timing)
@@ -180,8 +185,9 @@ int main() {
   CK(hipMemset(acc, 0, (size_t)tiles * BATCH * 16 * 4));
   const float t2 = time_ms([&] { pair_loop<2><<<tiles, 64>>>(acc, npairs); });
   const float t3 = time_ms([&] { pair_loop<3><<<tiles, 64>>>(acc, npairs); });
-  const float tr = time_ms([&] { row_loop<true><<<tiles, 256>>>(acc, nsteps); });
-  const float tr0 = time_ms([&] { row_loop<false><<<tiles, 256>>>(acc, nsteps); });
+  const float tr = time_ms([&] { row_loop<1><<<tiles, 256>>>(acc, nsteps); });
+  const float tr0 = time_ms([&] { row_loop<0><<<tiles, 256>>>(acc, nsteps); });
+  const float tr2 = time_ms([&] { row_loop<2><<<tiles, 256>>>(acc, nsteps); });
   // ns per pair (per step) and SIMD-slot: 5120 one-wave workgroups = 5 waves on each of 1024 SIMDs; 5120 x 4 waves = 20 per SIMD in
   // 2.5 generations of 8 -- both normalised to the WHOLE launch, which is what a kernel of 5120 tiles pays
   const double pair2 = t2 * 1e6 / ((double)npairs * tiles), pair3 = t3 * 1e6 / ((double)npairs * tiles), step = tr * 1e6 / ((double)nsteps * tiles * 4);
@@ -189,15 +195,17 @@ int main() {
          t2, pair2, t3, pair3, pair2 + 0.16 * (pair3 - pair2));
   const double step0 = tr0 * 1e6 / ((double)nsteps * tiles * 4);
   printf("row streams         : %.3f ms = %.4f ns per wave step (4 waves per tile: %.4f ns per tile step)\n", tr, step, 4 * step);
+  const double step2 = tr2 * 1e6 / ((double)nsteps * tiles * 4);
   printf("  ... without the ds_add_f32 into the per-record LDS sums (VALU floor, not a correct kernel): %.3f ms = %.4f ns per wave step\n", tr0, step0);
+  printf("  ... with one GLOBAL atomic per lane and step instead (no LDS sums, no flush): %.3f ms = %.4f ns per wave step\n", tr2, step2);
   const struct { const char *name; double steps, bodies; } sc[] = {{"C2", 1.556, 2.16}, {"C2 dense", 1.903, 2.32}, {"C4", 1.450, 1.98}};
   for (auto &c : sc) {
     const double pair = pair2 + (c.bodies - 2.0) * (pair3 - pair2);
     // a pair costs the row design `steps` wave steps IN EACH QUADRANT WAVE THAT HAS IT -- the counter is already per pair over the
     // tile's four quadrants (sum over quadrants of max over rows, divided by pairs)
     printf("  %-9s rows / shipping = %.3f x %.4f / %.4f = %.2f  (blend_bwd would take %.0f %% of today's time, before the per-batch "
-           "masks, lists and flush; with the LDS atomics free: %.2f)\n", c.name, c.steps, step, pair, c.steps * step / pair,
-           100.0 * c.steps * step / pair, c.steps * step0 / pair);
+           "masks, lists and flush; with the LDS atomics free: %.2f; with global atomics per step: %.2f)\n", c.name, c.steps, step, pair,
+           c.steps * step / pair, 100.0 * c.steps * step / pair, c.steps * step0 / pair, c.steps * step2 / pair);
   }
   return 0;
 }
