@@ -123,6 +123,7 @@ int fsgs_raster_backward(const FsgsRasterCfg *cfg, int P, const float *means3D, 
   if (deterministic && scratch_bytes < DL.total) return FSGS_ERR_CAPACITY;
   CamParams cam = make_cam(cfg);
   const int ntiles = cam.gx * cam.gy;
+  cam.bwd_prio_step = blend_bwd_prio_step(ntiles, num_rendered);
   const char *sb = (const char *)state;
   const float4 *co = (const float4 *)(sb + SL.conic_op);
   const float4 *rec = (const float4 *)(sb + SL.rec);  // colours as they were at the forward

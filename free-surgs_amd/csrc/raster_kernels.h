@@ -35,6 +35,7 @@ inline const char *diag_env(const char *name) {
 
 struct CamParams {
   int W, H, gx, gy, flags;
+  int bwd_prio_step;  // one-wave backward blend: entries per issue-priority level (0 = leave s_setprio alone); blend_bwd_prio_step()
   float tanfovx, tanfovy, fx, fy, scale_modifier;
   float V[16];
   float PM[16];
@@ -1336,9 +1337,6 @@ struct BwdSlots {
 // pair_rows[p][c] (a plain store into the pair's own 16-float row, passed in `grad_acc`); det_gather_kernel then sums a
 // Gaussian's rows in a fixed order.
 template <int C, bool SPLIT, bool POSE_ONLY = false, int CGRAD = C, int ROW = 0, int DIAG = 0, bool DET = false>
-#ifndef FSGS_BWD_PRIO_STEP
-#define FSGS_BWD_PRIO_STEP 0  // > 0: s_setprio by the entries a wave still has to walk (A/B: FSGS_CFLAGS=-DFSGS_BWD_PRIO_STEP=64)
-#endif
 #ifndef FSGS_BWD_WAVES
 #define FSGS_BWD_WAVES 5  // waves per SIMD the mapping backward is compiled for (A/B: free-surgs_amd/build.py FSGS_CFLAGS)
 #endif
@@ -1415,21 +1413,21 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
   const int my_u = slots.u, my_c = slots.c;
   const bool c_used = slots.used;
   while (hi > 0) {
-#if FSGS_BWD_PRIO_STEP
-    // Issue priority by REMAINING work (longest remaining first): a SIMD arbitrates between its resident waves by priority, then
-    // age.  With the longest-first dispatch order the oldest wave of a SIMD is its longest tile, which age alone keeps ahead of
-    // the others to its very end -- it finishes first, the youngest (shortest) tiles last, alone on their SIMD, where a lone wave
-    // issues at less than half the rate of five (profiles/r06_tile_times_bwd.txt: lists of 300+ entries done after 180 us, lists
-    // of 100..200 after 225-240 us).  Four levels: a wave drops one each time FSGS_BWD_PRIO_STEP fewer entries remain, so the waves
-    // of a SIMD converge on a common finish and the SIMD keeps its five waves to the end.
-    {  // (s_setprio takes an immediate: a wave-uniform switch)
-      const int level = hi / FSGS_BWD_PRIO_STEP;
+    // Issue priority by REMAINING work (round 6).  A SIMD arbitrates between its resident waves by priority, then age.  With the
+    // longest-first dispatch order the oldest wave of a SIMD is its longest tile, and age alone keeps it ahead of the others to its
+    // very end: it finishes first, the youngest (shortest) tiles last, alone on their SIMD, where a lone wave issues at less than
+    // half the rate of five (profiles/r06_tile_times_bwd.txt: lists of 300+ entries done after 180 us, lists of 100..200 after
+    // 225-240 us; residency 5 waves for 60 % of the launch, then draining).  With four levels -- a wave drops one each time
+    // `bwd_prio_step` fewer entries remain -- the wave with the most left to walk issues first, the waves of a SIMD converge on a
+    // common finish and the SIMD keeps its waves to the end: blend_bwd 256 -> 233 us at C2, 357 -> 314 us on the dense scene
+    // (profiles/r06_ab_bwd_prio*.txt).  Results do not depend on it (only WHEN a wave issues).
+    if (cam.bwd_prio_step > 0) {  // (s_setprio takes an immediate: a wave-uniform switch, once per 64 records)
+      const int level = hi / cam.bwd_prio_step;
       if (level >= 3) __builtin_amdgcn_s_setprio(3);
       else if (level == 2) __builtin_amdgcn_s_setprio(2);
       else if (level == 1) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-#endif
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
     uint32_t gid = plist[rg.x + lo + (lane < n ? lane : 0)];
@@ -1657,6 +1655,13 @@ __global__ __launch_bounds__(256) void blend_bwd_quad_kernel(
     __syncthreads();
     if (qlast > lo) {  // wave-uniform: something in this batch matters to this quadrant
       for (int sub = (n - 1) >> 6; sub >= 0; sub--) {
+        if (cam.bwd_prio_step > 0) {  // issue priority by the entries this tile still has to walk (see blend_bwd_kernel)
+          const int level = (lo + (sub + 1) * 64) / cam.bwd_prio_step;
+          if (level >= 3) __builtin_amdgcn_s_setprio(3);
+          else if (level == 2) __builtin_amdgcn_s_setprio(2);
+          else if (level == 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
         const int idx = sub * 64 + lane;
         unsigned long long bits = __ballot(((reach[idx] >> q) & 1u) != 0u && lo + idx < qlast);
         while (bits) {
@@ -1849,6 +1854,7 @@ CamParams make_cam(const FsgsRasterCfg *cfg) {
   c.fy = c.H / (2.0f * cfg->tanfovy);
   c.scale_modifier = cfg->scale_modifier;
   c.flags = cfg->flags;
+  c.bwd_prio_step = 0;
   memcpy(c.V, cfg->viewmatrix, sizeof(c.V));
   memcpy(c.PM, cfg->projmatrix, sizeof(c.PM));
   memcpy(c.bg, cfg->bg, sizeof(c.bg));
@@ -2110,6 +2116,19 @@ inline int quad_bwd_max_tiles(bool pose_only) {
   if (pose_only) return FSGS_QUAD_BWD_POSE_MAX_TILES;
 #endif
   return device_simd_count() * (pose_only ? kQuadBwdPoseQuarterTilesPerSimd : kQuadBwdQuarterTilesPerSimd) / 4;
+}
+// Entries per issue-priority level of the one-wave backward blend (CamParams::bwd_prio_step): a sixth of the mean list length --
+// measured optimum 32 at C2's 204 entries per tile, ~50 on the dense scene's 341 (profiles/r06_ab_bwd_prio2.txt) -- and only when
+// every tile of the launch is resident from the start (5 waves per SIMD): with more tiles than wave slots (C4: 8160 on 5120) the
+// launch runs in generations, late waves already start behind the early ones, and the sweep found nothing to gain (+0..1 %).
+// FSGS_BWD_PRIO_STEP (A/B builds) overrides it; 0 there switches the priorities off.
+inline int blend_bwd_prio_step(int ntiles, int64_t num_rendered) {
+#ifdef FSGS_BWD_PRIO_STEP
+  return FSGS_BWD_PRIO_STEP;
+#endif
+  if (ntiles <= 0 || num_rendered <= 0 || ntiles > 5 * device_simd_count()) return 0;
+  const int64_t step = num_rendered / ntiles / 6;
+  return (int)(step < 8 ? 8 : step > 4096 ? 4096 : step);
 }
 inline bool use_quad_waves(uint32_t flags, int ntiles, bool backward, bool pose_only = false) {
   if (flags & FSGS_FLAG_BLEND_ONE_WAVE) return false;

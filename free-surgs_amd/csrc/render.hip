@@ -939,6 +939,7 @@ int render_backward_impl(const FsgsRasterCfg *cfg, int P, const FsgsRenderArgs *
   CamParams cam = make_cam(cfg);
   for (int ch = 3; ch < 6; ch++) cam.bg[ch] = cfg->bg[ch - 3];
   const int ntiles = cam.gx * cam.gy;
+  cam.bwd_prio_step = blend_bwd_prio_step(ntiles, num_rendered);
   const char *sb = (const char *)state;
   float *grad_acc = (float *)scratch;
   float *dcolors6 = grad_acc + 8;  // floats 8..13 of every Gaussian's 64-byte row
