@@ -1655,13 +1655,6 @@ __global__ __launch_bounds__(256) void blend_bwd_quad_kernel(
     __syncthreads();
     if (qlast > lo) {  // wave-uniform: something in this batch matters to this quadrant
       for (int sub = (n - 1) >> 6; sub >= 0; sub--) {
-        if (cam.bwd_prio_step > 0) {  // issue priority by the entries this tile still has to walk (see blend_bwd_kernel)
-          const int level = (lo + (sub + 1) * 64) / cam.bwd_prio_step;
-          if (level >= 3) __builtin_amdgcn_s_setprio(3);
-          else if (level == 2) __builtin_amdgcn_s_setprio(2);
-          else if (level == 1) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-        }
         const int idx = sub * 64 + lane;
         unsigned long long bits = __ballot(((reach[idx] >> q) & 1u) != 0u && lo + idx < qlast);
         while (bits) {
@@ -2121,6 +2114,7 @@ inline int quad_bwd_max_tiles(bool pose_only) {
 // measured optimum 32 at C2's 204 entries per tile, ~50 on the dense scene's 341 (profiles/r06_ab_bwd_prio2.txt) -- and only when
 // every tile of the launch is resident from the start (5 waves per SIMD): with more tiles than wave slots (C4: 8160 on 5120) the
 // launch runs in generations, late waves already start behind the early ones, and the sweep found nothing to gain (+0..1 %).
+// The four-waves backward of the small grids (C1, X1, X2) gains nothing from it either (profiles/r06_ab_prio_quad.txt): not wired.
 // FSGS_BWD_PRIO_STEP (A/B builds) overrides it; 0 there switches the priorities off.
 inline int blend_bwd_prio_step(int ntiles, int64_t num_rendered) {
 #ifdef FSGS_BWD_PRIO_STEP
