@@ -146,14 +146,15 @@ __device__ __forceinline__ void clear_binning_cursors(const GeomOut &g) {
 // says which one a key takes), and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
 // (depth, index) order anyway).
 constexpr int BIN_SUBS = 8;
-// Which of a tile's BIN_SUBS sub-lists a key goes to.  Rounds 1-5: the Gaussian index (gaussian & 7).  Round 6: the XCD the
-// writing workgroup runs on (HW_REG_XCC_ID).  Every 64-byte line of a segment then collects its eight keys in ONE L2 -- with
-// the index rule the eight keys of a line arrived from up to eight XCDs, each of which wrote its own partial line back
-// (WRITE_SIZE 51.7 MB for 8.4 MB of keys, profiles/r05_pmc_traffic.json).  The per-tile sort orders by (depth, index), so
-// the sub-list a key sat in never shows in a result; the sub-lists stay balanced because consecutive workgroups (256
-// Gaussians each) land on consecutive XCDs.
+// Which of a tile's BIN_SUBS sub-lists a key goes to: the Gaussian index (gaussian & 7).  Round 6 tried the XCD the writing
+// workgroup runs on instead (HW_REG_XCC_ID; FSGS_BIN_SUB_XCC=1): every 64-byte line of a segment then collects its eight keys in ONE
+// L2 and the key stores' write amplification drops (WRITE_SIZE 51.7 -> 45.3 MB; the rest is the cursor atomics, tallied at 32 B a
+// request) -- but the 64 Gaussians of a wave are neighbours in the image (clouds are initialised in pixel order), so candidates of
+// different Gaussians for the SAME tile then share one cursor instead of spreading over eight, and same-address atomics serialise:
+// bin_scatter 27.7 -> 45.1 us at C2 (profiles/r06_bench_kernel_stats_xcc_sublists.csv).  Not kept.  The per-tile sort orders by
+// (depth, index), so the sub-list a key sat in never shows in a result either way.
 #ifndef FSGS_BIN_SUB_XCC
-#define FSGS_BIN_SUB_XCC 1
+#define FSGS_BIN_SUB_XCC 0
 #endif
 __device__ __forceinline__ uint32_t xcc_id() {
   uint32_t x;
@@ -1243,6 +1244,16 @@ __device__ __forceinline__ void unpack_moments(const float *m, float4 co, float 
   ga[7] = -fmaf(Cc, m[7], B * m[6]);
 }
 
+// s_setprio takes an immediate: a wave-uniform switch.  Level = remaining / step, once per 64-record batch.  (Round 6 also tried
+// setting it every 16 records and thresholds step/4, step/2, step: nothing over this, profiles/r06_ab_bwd_prio3.txt.)
+__device__ __forceinline__ void set_issue_priority(int remaining, int step) {
+  const int level = remaining / step;
+  if (level >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (level == 2) __builtin_amdgcn_s_setprio(2);
+  else if (level == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 // SPLIT (fused 6-channel pass): channels 0..2 are the RGB pass, 3..5 the depth/silhouette pass of the
 // reference's two calls; the RGB pass's own dL/dmean2D goes to accumulator slots 6,7 because
 // `viewspace_points` must not see the depth loss (gaussian_renderer/__init__.py:77,90; SURVEY a1 note i).
@@ -1421,13 +1432,7 @@ __global__ __launch_bounds__(64, (!POSE_ONLY && CGRAD > 4) ? 3 : (!POSE_ONLY ? F
     // `bwd_prio_step` fewer entries remain -- the wave with the most left to walk issues first, the waves of a SIMD converge on a
     // common finish and the SIMD keeps its waves to the end: blend_bwd 256 -> 233 us at C2, 357 -> 314 us on the dense scene
     // (profiles/r06_ab_bwd_prio*.txt).  Results do not depend on it (only WHEN a wave issues).
-    if (cam.bwd_prio_step > 0) {  // (s_setprio takes an immediate: a wave-uniform switch, once per 64 records)
-      const int level = hi / cam.bwd_prio_step;
-      if (level >= 3) __builtin_amdgcn_s_setprio(3);
-      else if (level == 2) __builtin_amdgcn_s_setprio(2);
-      else if (level == 1) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    }
+    if (cam.bwd_prio_step > 0) set_issue_priority(hi, cam.bwd_prio_step);  // once per 64 records
     const int lo = max(0, hi - 64);
     const int n = hi - lo;
     uint32_t gid = plist[rg.x + lo + (lane < n ? lane : 0)];
