@@ -368,47 +368,14 @@ constexpr int ORDER_FOLD = 1024;  // SIMDs of the chip = the period of the workg
 // tiles, C2's 1280 x 1024): with more tiles a freed slot takes the next workgroup, the balance is dynamic and wants the plain
 // longest-first order (C4, 8160 tiles: folding cost blend_bwd 0.4 - 2.5 %, blend_fwd 1 %)
 constexpr uint32_t ORDER_FOLD_ROUNDS = 5;
-__device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 KB + 8 KB of LDS */, int ntiles,
-                                                        const uint32_t *__restrict__ cursors, uint32_t cap_sub,
-                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ total_out,
-                                                        uint32_t *host_word) {
-  __shared__ uint32_t wave_tot[4], wave_len[4], wave_worst[4];
-  uint32_t *hist = smem;                                             // [256]
-  uint8_t *bins = reinterpret_cast<uint8_t *>(smem + ORDER_BINS_FUSED);  // [ntiles <= 8192]
-  uint32_t mine = 0, worst = 0;
-  hist[threadIdx.x] = 0;
-#pragma unroll 4
-  for (int i = (int)threadIdx.x; i < ntiles; i += 256) {  // strided ownership: coalesced 32-byte rows
-    const uint4 a = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS);
-    const uint4 b = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS + 4);
-    worst = max(worst, max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
-    const uint32_t n = min(a.x, cap_sub) + min(a.y, cap_sub) + min(a.z, cap_sub) + min(a.w, cap_sub) +
-                       min(b.x, cap_sub) + min(b.y, cap_sub) + min(b.z, cap_sub) + min(b.w, cap_sub);
-    mine += n;
-    bins[i] = (uint8_t)(ORDER_BINS_FUSED - 1 - (int)min(n >> 2, (uint32_t)(ORDER_BINS_FUSED - 1)));  // bin 0 = longest
-  }
+// Second half of the order construction: hist[] holds the bin counts, bins[] every tile's bin (0 = longest).  256 threads.  (A
+// function of its own since round 6 tried to re-form the backward's order from the quadrant bodies the forward blend counts per tile
+// -- weight 35 bodies + 63 pairs, one extra workgroup on the side stream: blend_bwd 232.5 vs 233 us at C2, 309 vs 314 dense,
+// profiles/r06_ab_refine_order_and_fwd_pair.txt -- not worth an entry point; dropped.)
+__device__ __forceinline__ void tile_order_finish(uint32_t *hist, const uint8_t *bins, int ntiles, uint32_t *__restrict__ order,
+                                                  bool write_plain) {
+  __shared__ uint32_t wave_tot[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  {
-    uint32_t sm = mine, wm = worst;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sm += (uint32_t)__shfl_xor((int)sm, off, 64);
-      wm = max(wm, (uint32_t)__shfl_xor((int)wm, off, 64));
-    }
-    if (lane == 0) { wave_len[wv] = sm; wave_worst[wv] = wm; }
-  }
-  __syncthreads();
-  for (int i = (int)threadIdx.x; i < ntiles; i += 256) atomicAdd(&hist[bins[i]], 1u);
-  if (threadIdx.x == 0) {
-    const uint32_t R = wave_len[0] + wave_len[1] + wave_len[2] + wave_len[3];
-    const uint32_t w = max(max(wave_worst[0], wave_worst[1]), max(wave_worst[2], wave_worst[3]));
-    const uint32_t need = w > cap_sub ? w : 0u;  // a segment overflowed: the capacity that would have sufficed
-    total_out[0] = R;
-    total_out[1] = need;
-    if (host_word)
-      __hip_atomic_store(host_word, need ? (0x80000000u | need) : R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __syncthreads();
   // exclusive scan of the 256 bins, one per thread
   const uint32_t c = hist[threadIdx.x];
   uint32_t incl = c;
@@ -477,8 +444,52 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
 #endif
     // ... and the plain longest-first order behind it, for the four-waves-per-tile launches: their 256-thread workgroups are
     // not placed with the period the fold is built on, and plain LPT is 3 % faster for them (C2 blend_fwd 118.5 -> 115.0 us)
-    order_plain(order, ntiles)[rank] = (uint32_t)i;
+    if (write_plain) order_plain(order, ntiles)[rank] = (uint32_t)i;
   }
+}
+
+__device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 KB + 8 KB of LDS */, int ntiles,
+                                                        const uint32_t *__restrict__ cursors, uint32_t cap_sub,
+                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ total_out,
+                                                        uint32_t *host_word) {
+  __shared__ uint32_t wave_len[4], wave_worst[4];
+  uint32_t *hist = smem;                                             // [256]
+  uint8_t *bins = reinterpret_cast<uint8_t *>(smem + ORDER_BINS_FUSED);  // [ntiles <= 8192]
+  uint32_t mine = 0, worst = 0;
+  hist[threadIdx.x] = 0;
+#pragma unroll 4
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) {  // strided ownership: coalesced 32-byte rows
+    const uint4 a = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS);
+    const uint4 b = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS + 4);
+    worst = max(worst, max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
+    const uint32_t n = min(a.x, cap_sub) + min(a.y, cap_sub) + min(a.z, cap_sub) + min(a.w, cap_sub) +
+                       min(b.x, cap_sub) + min(b.y, cap_sub) + min(b.z, cap_sub) + min(b.w, cap_sub);
+    mine += n;
+    bins[i] = (uint8_t)(ORDER_BINS_FUSED - 1 - (int)min(n >> 2, (uint32_t)(ORDER_BINS_FUSED - 1)));  // bin 0 = longest
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    uint32_t sm = mine, wm = worst;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sm += (uint32_t)__shfl_xor((int)sm, off, 64);
+      wm = max(wm, (uint32_t)__shfl_xor((int)wm, off, 64));
+    }
+    if (lane == 0) { wave_len[wv] = sm; wave_worst[wv] = wm; }
+  }
+  __syncthreads();
+  for (int i = (int)threadIdx.x; i < ntiles; i += 256) atomicAdd(&hist[bins[i]], 1u);
+  if (threadIdx.x == 0) {
+    const uint32_t R = wave_len[0] + wave_len[1] + wave_len[2] + wave_len[3];
+    const uint32_t w = max(max(wave_worst[0], wave_worst[1]), max(wave_worst[2], wave_worst[3]));
+    const uint32_t need = w > cap_sub ? w : 0u;  // a segment overflowed: the capacity that would have sufficed
+    total_out[0] = R;
+    total_out[1] = need;
+    if (host_word)
+      __hip_atomic_store(host_word, need ? (0x80000000u | need) : R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  tile_order_finish(hist, bins, ntiles, order, true);
 }
 
 // order != nullptr: the launch has ntiles + 1 workgroups, block 0 forms the dispatch order / R / mailbox word (above) and
@@ -619,6 +630,9 @@ __global__ __launch_bounds__(256) void sort_tiles_kernel(int ntiles, const uint3
 //     longest tile goes to position 8*i + x, so each L2 only ever sees the Gaussians of one band
 //     (without this the longest-first order scatters every XCD over the whole image and the fabric
 //     traffic of the blend kernels triples).
+// the sort launch's own order workgroup (tile_order_from_cursors) forms the orders: up to 8192 tiles, not with the XCD-banded order
+inline bool fused_order_workgroup(int flags, int ntiles) { return !(flags & FSGS_FLAG_XCD_BANDED_ORDER) && ntiles <= 8 * 1024; }
+
 constexpr int ORDER_MAX_TILES = 1 << 20;
 constexpr int ORDER_BINS = 1024;
 constexpr int ORDER_XCD = 8;
@@ -853,24 +867,25 @@ __device__ __forceinline__ bool blend_fwd_pixel(float &T, float &D, float2v (&ac
   return true;
 }
 
-// The same step for the record whose alpha has ALREADY been evaluated (e, ok): the two-records-per-trip walk of the four-waves
-// forward evaluates the exponents of two list neighbours side by side -- they do not depend on the transmittance -- and then
-// blends them in list order through here.  Same operations on the same values as blend_fwd_pixel: bit-identical results.
+// Branch-free form of the same step (A/B: FSGS_FWD_BRANCHFREE): 98 % of the executed quadrant bodies have at least one lane that
+// blends, so the three nested lane-mask branches of blend_fwd_pixel almost never skip an instruction for the WAVE -- they cost
+// ~10 scalar instructions per body and put the colour reads behind a second LDS round trip.  Here every lane runs the whole body
+// with w = 0 where it does not blend (acc + 0 c = acc, T (1 - 0) = T: the same bits), the skip decision is splat_alpha_masked's
+// (bit-identical to splat_alpha), and all of the record is read in one round.
 template <int CP, bool WITH_DEPTH>
-__device__ __forceinline__ void blend_fwd_apply(float &T, float &D, float2v (&acc)[CP], uint32_t &last, const SplatEval &e, bool ok,
-                                                float bz, const float2v (&bcol2)[4], uint32_t pos) {
-  if (!(T > 0.f) || !ok) return;
-  const float test_T = T * (1.0f - e.alpha);
-  if (test_T < 0.0001f) {
-    T = -T;
-    return;
-  }
-  const float w = e.alpha * T;
+__device__ __forceinline__ void blend_fwd_pixel_branchfree(float &T, float &D, float2v (&acc)[CP], uint32_t &last, float dx, float dy,
+                                                           float bA, float bB, float bC, float bo, float bz,
+                                                           const float2v (&bcol2)[4], uint32_t pos) {
+  SplatEval e;
+  const bool ok = splat_alpha_masked(dx, dy, bA, bB, bC, bo, T > 0.f, e);  // alpha = 0 for finished pixels and skipped pairs
+  const float test_T = T * (1.0f - e.alpha);                                  // == T where alpha == 0
+  const bool stop = ok && test_T < 0.0001f;
+  const float w = (ok && !stop) ? e.alpha * T : 0.0f;
 #pragma unroll
   for (int cp = 0; cp < CP; cp++) acc[cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[cp]);
   if (WITH_DEPTH) D = fmaf(bz, w, D);
-  T = test_T;
-  last = pos;
+  last = (ok && !stop) ? pos : last;
+  T = stop ? -T : test_T;
 }
 
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
@@ -1092,9 +1107,12 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // Per pair this is MORE issue slots than the one-wave kernel on a full chip (each wave pays its own loop and record reads),
 // which is why the big grids keep the one-wave kernel: launch_blend_fwd picks by the number of tiles.
 constexpr int QW_BATCH = 256;
-#ifndef FSGS_FWD_PAIR
-#define FSGS_FWD_PAIR 0  // two records per trip of the set-bit walk (A/B: FSGS_CFLAGS=-DFSGS_FWD_PAIR=1; profiles/r06_ab_fwd_pair.txt)
+#ifndef FSGS_FWD_BRANCHFREE
+#define FSGS_FWD_BRANCHFREE 1  // 0: the branchy body (A/B: profiles/r06_ab_fwd_branchfree.txt: C2 blend_fwd 115.4 -> 107.5 us, C1 step -2.7 %; a per-body
+// wave-level exit for finished quadrants on top of it: 108 -> 113.5 us at C2, 163 -> 160 dense, _branchfree2.txt: not kept)
 #endif
+// (Two records per trip of the set-bit walk were tried twice in round 6 -- on the branchy body, 115 -> 121 us, and on the branch-free
+// one, 108 -> 113 us: profiles/r06_ab_fwd_pair.txt, r06_ab_refine_order_and_fwd_pair.txt -- and are not in the source any more.)
 template <int C, bool WITH_DEPTH>
 __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
     CamParams cam, int ntiles, const uint32_t *__restrict__ order, const int2 *__restrict__ ranges,
@@ -1155,37 +1173,6 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
       const int nsub = (n + 63) >> 6;
       for (int sub = 0; sub < nsub; sub++) {
         unsigned long long bits = __ballot(((reach[sub * 64 + lane] >> q) & 1u) != 0u);
-#if FSGS_FWD_PAIR
-        // Two set bits per trip: the exponents of two list neighbours are independent of the transmittance, so
-        // their record reads and v_exp chains run side by side and the walk's scalar bookkeeping (find-first-set, clear, compare,
-        // branch) is paid once per two records; the blends then follow in list order (blend_fwd_apply).
-        while (bits) {
-          const int j0 = sub * 64 + (int)__builtin_ctzll(bits);  // scalar
-          bits &= bits - 1ull;
-          const bool two = bits != 0ull;  // scalar
-          const int j1 = two ? sub * 64 + (int)__builtin_ctzll(bits) : j0;
-          bits &= bits - 1ull;            // (0 & anything = 0 when there was no second bit)
-          const float4 a0 = rec[j0 * REC4 + 0], a1 = rec[j0 * REC4 + 1];
-          const float4 b0 = rec[j1 * REC4 + 0], b1 = rec[j1 * REC4 + 1];
-          SplatEval e0, e1;
-          const bool ok0 = splat_alpha(__fsub_rn(__fsub_rn(a0.x, px0), offx), __fsub_rn(__fsub_rn(a0.y, py0), offy), a0.z, a0.w, a1.x,
-                                       a1.y, e0);
-          const bool ok1 = splat_alpha(__fsub_rn(__fsub_rn(b0.x, px0), offx), __fsub_rn(__fsub_rn(b0.y, py0), offy), b0.z, b0.w, b1.x,
-                                       b1.y, e1) && two;
-          {
-            const float4 r2 = rec[j0 * REC4 + 2];
-            const float4 r3 = C > 4 ? rec[j0 * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
-            blend_fwd_apply<CP, WITH_DEPTH>(T, D, acc, last, e0, ok0, a1.z, bcol2, (uint32_t)(base + j0 - rg.x + 1));
-          }
-          {
-            const float4 r2 = rec[j1 * REC4 + 2];
-            const float4 r3 = C > 4 ? rec[j1 * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
-            blend_fwd_apply<CP, WITH_DEPTH>(T, D, acc, last, e1, ok1, b1.z, bcol2, (uint32_t)(base + j1 - rg.x + 1));
-          }
-        }
-#else
         while (bits) {
           const int j = sub * 64 + (int)__builtin_ctzll(bits);  // scalar
           bits &= bits - 1ull;
@@ -1193,10 +1180,14 @@ __global__ __launch_bounds__(256) void blend_fwd_quad_kernel(
           const float4 r3 = C > 4 ? rec[j * REC4 + 3] : make_float4(0.f, 0.f, 0.f, 0.f);
           const float2v bcol2[4] = {float2v{r2.x, r2.y}, float2v{r2.z, r2.w}, float2v{r3.x, r3.y}, float2v{r3.z, r3.w}};
           const float dx0 = __fsub_rn(r0.x, px0), dy0 = __fsub_rn(r0.y, py0);
+#if FSGS_FWD_BRANCHFREE
+          blend_fwd_pixel_branchfree<CP, WITH_DEPTH>(T, D, acc, last, __fsub_rn(dx0, offx), __fsub_rn(dy0, offy), r0.z, r0.w,
+                                                     r1.x, r1.y, r1.z, bcol2, (uint32_t)(base + j - rg.x + 1));
+#else
           blend_fwd_pixel<CP, WITH_DEPTH>(T, D, acc, last, __fsub_rn(dx0, offx), __fsub_rn(dy0, offy), r0.z, r0.w,
                                           r1.x, r1.y, r1.z, bcol2, (uint32_t)(base + j - rg.x + 1));
-        }
 #endif
+        }
         if (__ballot(T > 0.f) == 0ull) break;  // the quadrant finished inside this batch
       }
     }
@@ -1961,7 +1952,7 @@ inline int enqueue_binning(const CamParams &cam, int P, FwdBuffers &B, int64_t m
   tk.slot = mailbox_acquire();
   {
     ProfScope ps(PROF_SORT_TILE, stream);
-    if (!(cam.flags & FSGS_FLAG_XCD_BANDED_ORDER) && ntiles <= 8 * 1024) {
+    if (fused_order_workgroup(cam.flags, ntiles)) {
       // the default: dispatch order, R and the mailbox word come from workgroup 0 of the sort launch itself
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(ntiles + 1), dim3(256), 0, stream, ntiles, B.tile_count, B.keys, B.plist,
                          B.ranges, tk.cap_sub, B.total + 1, B.order, B.total, (uint32_t *)tk.slot);

@@ -759,3 +759,4 @@ def test_forward_done_event_orders_another_stream_behind_the_forward_blend():
     torch.cuda.synchronize()
     _lib.check(lib.fsgs_event_destroy(ev), "fsgs_event_destroy")
     assert lib.fsgs_event_destroy(None) == _lib.FSGS_OK
+
