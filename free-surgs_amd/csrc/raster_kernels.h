@@ -877,6 +877,21 @@ __device__ __forceinline__ void blend_fwd_pixel_branchfree(float &T, float &D, f
                                                            float bA, float bB, float bC, float bo, float bz,
                                                            const float2v (&bcol2)[4], uint32_t pos) {
   SplatEval e;
+#if FSGS_FWD_BF_LEAN
+  // (A/B) the three lane-mask combinations (ok && .., ok && !stop twice) replaced by what the values already say: alpha = 0 where
+  // the lane skips the pair, so test_T = T there, and T >= 1e-4 for every pixel still blending (a smaller one was stopped) while a
+  // finished pixel's T is negative -- "0 <= test_T < 1e-4" is ONE unsigned compare of the bits and is true exactly where
+  // ok && test_T < 1e-4; and the lane blends exactly where its weight is positive.
+  (void)splat_alpha_masked(dx, dy, bA, bB, bC, bo, T > 0.f, e);
+  const float test_T = T * (1.0f - e.alpha);
+  const bool stop = __float_as_uint(test_T) < 0x38D1B717u;  // bits of 1e-4f
+  const float w = stop ? 0.0f : e.alpha * T;
+#pragma unroll
+  for (int cp = 0; cp < CP; cp++) acc[cp] = __builtin_elementwise_fma(bcol2[cp], float2v{w, w}, acc[cp]);
+  if (WITH_DEPTH) D = fmaf(bz, w, D);
+  last = w > 0.0f ? pos : last;
+  T = stop ? -T : test_T;
+#else
   const bool ok = splat_alpha_masked(dx, dy, bA, bB, bC, bo, T > 0.f, e);  // alpha = 0 for finished pixels and skipped pairs
   const float test_T = T * (1.0f - e.alpha);                                  // == T where alpha == 0
   const bool stop = ok && test_T < 0.0001f;
@@ -886,6 +901,7 @@ __device__ __forceinline__ void blend_fwd_pixel_branchfree(float &T, float &D, f
   if (WITH_DEPTH) D = fmaf(bz, w, D);
   last = (ok && !stop) ? pos : last;
   T = stop ? -T : test_T;
+#endif
 }
 
 // out_color holds channels [0, min(C,3)); channels >= 3 go to out_color2 (the fused render's depth /
@@ -1107,6 +1123,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
 // Per pair this is MORE issue slots than the one-wave kernel on a full chip (each wave pays its own loop and record reads),
 // which is why the big grids keep the one-wave kernel: launch_blend_fwd picks by the number of tiles.
 constexpr int QW_BATCH = 256;
+#ifndef FSGS_FWD_BF_LEAN
+#define FSGS_FWD_BF_LEAN 0
+#endif
 #ifndef FSGS_FWD_BRANCHFREE
 #define FSGS_FWD_BRANCHFREE 1  // 0: the branchy body (A/B: profiles/r06_ab_fwd_branchfree.txt: C2 blend_fwd 115.4 -> 107.5 us, C1 step -2.7 %; a per-body
 // wave-level exit for finished quadrants on top of it: 108 -> 113.5 us at C2, 163 -> 160 dense, _branchfree2.txt: not kept)
