@@ -62,12 +62,12 @@ __device__ __forceinline__ float pixel_mask(const float *__restrict__ mask, cons
   if (presence) m = presence[p] > 0.f ? m : 0.f;
   return m;
 }
-__global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
-                                                              const float *__restrict__ gt,
-                                                              const float *__restrict__ mask,
-                                                              const float *__restrict__ presence,
-                                                              float *__restrict__ maps,
-                                                              float *__restrict__ partials) {
+// (the body of the kernel as a function of the tile id: photometric_fwd_kernel and the fused launch of a view's loss stage,
+// view_losses_fwd_kernel, both run it)
+__device__ __forceinline__ void photometric_fwd_tile(const int tile_id, int C, int H, int W, const float *__restrict__ img,
+                                                     const float *__restrict__ gt, const float *__restrict__ mask,
+                                                     const float *__restrict__ presence, float *__restrict__ maps,
+                                                     float *__restrict__ partials) {
   // image and target of a pixel side by side, the moments as two pairs: one 8-byte LDS access moves a pair and the 11-tap
   // filters of a pair are one v_pk_fma_f32 per tap, each component still accumulating its taps in the order k = 0..10.
   // SSIM needs the two second moments e11 = G*x^2 and e22 = G*y^2 only as their SUM (sigma1^2 + sigma2^2 =
@@ -82,11 +82,6 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   // is handed one contiguous run of tiles in (channel, row, column) order -- a band of the image -- and the 5-pixel halos
   // two neighbouring tiles both read meet in ONE L2 instead of being fetched over the fabric by two of them
   const int tiles_x = (W + SS_TILE - 1) / SS_TILE, tiles_y = (H + SS_TILE - 1) / SS_TILE;
-#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
-  const int tile_id = blockIdx.x;
-#else
-  const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
-#endif
   const int ch = tile_id / (tiles_x * tiles_y), in_plane = tile_id - ch * (tiles_x * tiles_y);
   const int tile_y = in_plane / tiles_x, tile_x = in_plane - tile_y * tiles_x;
   const int x0 = tile_x * SS_TILE, y0 = tile_y * SS_TILE;
@@ -207,6 +202,20 @@ __global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int 
   }
 }
 
+__global__ __launch_bounds__(256) void photometric_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                              const float *__restrict__ gt,
+                                                              const float *__restrict__ mask,
+                                                              const float *__restrict__ presence,
+                                                              float *__restrict__ maps,
+                                                              float *__restrict__ partials) {
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
+  const int tile_id = blockIdx.x;
+#else
+  const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+#endif
+  photometric_fwd_tile(tile_id, C, H, W, img, gt, mask, presence, maps, partials);
+}
+
 // ---- row-streaming geometry of the backward kernel ----
 constexpr int ST_W = 64;                      // columns per wave
 constexpr int ST_RS = 16;                     // output rows per wave
@@ -277,27 +286,15 @@ __global__ __launch_bounds__(256) void photometric_finish_kernel(const float *__
 // horizontal taps), the horizontal results of the last 11 rows live in a REGISTER ring and the vertical pass reads
 // only registers: no workgroup barrier, < 1 KB of LDS.  (The same scheme was measured for the forward kernel,
 // whose five moments need 154 VGPRs and 33 extra multiplies per row: 82 us against 55 us for the tiled kernel.)
-__global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W, const float *__restrict__ img,
-                                                             const float *__restrict__ gt,
-                                                             const float *__restrict__ mask,
-                                                             const float *__restrict__ presence,
-                                                             const float *__restrict__ maps,
-                                                             const float *__restrict__ upstream, float lambda_dssim,
-                                                             float *__restrict__ dimg, FinishArgs fin) {
+// (the body as a function of the strip id: photometric_bwd_kernel and view_losses_bwd_kernel both run it)
+__device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, int H, int W, const float *__restrict__ img,
+                                                      const float *__restrict__ gt, const float *__restrict__ mask,
+                                                      const float *__restrict__ presence, const float *__restrict__ maps,
+                                                      const float *__restrict__ upstream, float lambda_dssim,
+                                                      float *__restrict__ dimg) {
   __shared__ float row[3][ST_IN + 6];
   const int lane = threadIdx.x;
-  const int strips_x = (W + ST_W - 1) / ST_W, strips_y = (H + ST_RS - 1) / ST_RS, nstrips = strips_x * strips_y * C;
-  if ((int)blockIdx.x >= nstrips) {  // the grid is one workgroup longer: it finishes the loss
-    if (fin.out) photometric_finish_wave(fin, lambda_dssim, lane);
-    return;
-  }
-  // XCD-aware placement (see the forward kernel): every XCD streams one band of vertically adjacent strips, whose 10 shared
-  // halo rows per boundary then come out of its own L2
-#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
-  const int strip = blockIdx.x;
-#else
-  const int strip = xcd_swizzle(blockIdx.x, nstrips);
-#endif
+  const int strips_x = (W + ST_W - 1) / ST_W, strips_y = (H + ST_RS - 1) / ST_RS;
   const int ch = strip / (strips_x * strips_y), s2 = strip - ch * (strips_x * strips_y);
   const int strip_y = s2 / strips_x, strip_x = s2 - strip_y * strips_x;
   const int x0 = strip_x * ST_W, y0 = strip_y * ST_RS;
@@ -396,6 +393,28 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
   }
 }
 
+__global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                             const float *__restrict__ gt,
+                                                             const float *__restrict__ mask,
+                                                             const float *__restrict__ presence,
+                                                             const float *__restrict__ maps,
+                                                             const float *__restrict__ upstream, float lambda_dssim,
+                                                             float *__restrict__ dimg, FinishArgs fin) {
+  const int nstrips = ((W + ST_W - 1) / ST_W) * ((H + ST_RS - 1) / ST_RS) * C;
+  if ((int)blockIdx.x >= nstrips) {  // the grid is one workgroup longer: it finishes the loss
+    if (fin.out) photometric_finish_wave(fin, lambda_dssim, threadIdx.x);
+    return;
+  }
+  // XCD-aware placement (see the forward kernel): every XCD streams one band of vertically adjacent strips, whose 10 shared
+  // halo rows per boundary then come out of its own L2
+#if defined(FSGS_DIAG_HOOKS) && defined(FSGS_EXP_LOSS_NO_XCD)  // diagnostics flavour only (same results, other placement)
+  const int strip = blockIdx.x;
+#else
+  const int strip = xcd_swizzle(blockIdx.x, nstrips);
+#endif
+  photometric_bwd_strip(strip, C, H, W, img, gt, mask, presence, maps, upstream, lambda_dssim, dimg);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Pearson correlation losses (utils/loss_utils.py:98-127)
 // region 0 = whole image; regions 1..n = box x box patches with top-left (row0[r-1], col0[r-1]).
@@ -403,19 +422,18 @@ __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W
 // ---------------------------------------------------------------------------------------------------
 constexpr int PE_CHUNK = 4096;  // pixels per workgroup
 
-__global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int box, const int64_t *__restrict__ row0,
-                                                            const int64_t *__restrict__ col0,
-                                                            const float *__restrict__ src,
-                                                            const float *__restrict__ tgt,
-                                                            double *__restrict__ partials, int n0, int nb) {
+// (the body as a function of (region, chunk): pearson_stats_kernel and view_losses_fwd_kernel both run it)
+__device__ __forceinline__ void pearson_stats_chunk(const int r, const int chunk, int H, int W, int box,
+                                                    const int64_t *__restrict__ row0, const int64_t *__restrict__ col0,
+                                                    const float *__restrict__ src, const float *__restrict__ tgt,
+                                                    double *__restrict__ partials, int n0, int nb) {
   __shared__ float red[4];
-  const int r = blockIdx.y;
   int ry = 0, rx = 0, rh = H, rw = W;
   if (r > 0) {
     ry = (int)row0[r - 1]; rx = (int)col0[r - 1]; rh = box; rw = box;
   }
   const int n = rh * rw;
-  const int begin = blockIdx.x * PE_CHUNK;
+  const int begin = chunk * PE_CHUNK;
   if (begin >= n) return;
   const int end = min(n, begin + PE_CHUNK);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
@@ -451,9 +469,31 @@ __global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int bo
   if (threadIdx.x == 0) {
     // one partial per workgroup, summed in a fixed order by the finish kernel: hundreds of same-address double
     // atomics (~46 ns each) used to take longer than reading the two images, and made the sum order-dependent
-    double *st = partials + 5 * (size_t)(r == 0 ? blockIdx.x : n0 + (r - 1) * nb + blockIdx.x);
+    double *st = partials + 5 * (size_t)(r == 0 ? chunk : n0 + (r - 1) * nb + chunk);
     st[0] = (double)t0; st[1] = (double)t1; st[2] = (double)t2; st[3] = (double)t3; st[4] = (double)t4;
   }
+}
+
+__global__ __launch_bounds__(256) void pearson_stats_kernel(int H, int W, int box, const int64_t *__restrict__ row0,
+                                                            const int64_t *__restrict__ col0,
+                                                            const float *__restrict__ src,
+                                                            const float *__restrict__ tgt,
+                                                            double *__restrict__ partials, int n0, int nb) {
+  pearson_stats_chunk(blockIdx.y, blockIdx.x, H, W, box, row0, col0, src, tgt, partials, n0, nb);
+}
+
+// the five sums of a region -> its row of coefficients (below); the ONE statement of this arithmetic
+__device__ __forceinline__ void pearson_region_coef(const double (&st)[5], const double N, float *c) {
+  double ms = st[0] / N, mt = st[1] / N;
+  double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
+  vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
+  double sds = sqrt(vs), sdt = sqrt(vt);
+  double cov = st[4] / N - ms * mt;
+  double D = (sds + 1e-6) * (sdt + 1e-6);
+  c[0] = (float)ms; c[1] = (float)mt; c[2] = (float)(1.0 / (N * D));
+  c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
+  c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
+  c[5] = (float)(1.0 - cov / D);
 }
 
 // per region: coefficients of the gradient + the loss value
@@ -479,18 +519,8 @@ __global__ __launch_bounds__(1024) void pearson_finish_kernel(int H, int W, int 
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) st[q] += __shfl_xor(st[q], off, 64);
     if (lane == 0) {
-      double N = r == 0 ? (double)H * W : (double)box * box;
-      double ms = st[0] / N, mt = st[1] / N;
-      double vs = (st[2] - N * ms * ms) / (N - 1.0), vt = (st[3] - N * mt * mt) / (N - 1.0);
-      vs = vs > 0 ? vs : 0; vt = vt > 0 ? vt : 0;
-      double sds = sqrt(vs), sdt = sqrt(vt);
-      double cov = st[4] / N - ms * mt;
-      double D = (sds + 1e-6) * (sdt + 1e-6);
       float *c = coef + 8 * r;
-      c[0] = (float)ms; c[1] = (float)mt; c[2] = (float)(1.0 / (N * D));
-      c[3] = sdt > 0 ? (float)(cov / (D * (sdt + 1e-6) * (N - 1.0) * sdt)) : 0.f;
-      c[4] = sds > 0 ? (float)(cov / (D * (sds + 1e-6) * (N - 1.0) * sds)) : 0.f;
-      c[5] = (float)(1.0 - cov / D);
+      pearson_region_coef(st, r == 0 ? (double)H * W : (double)box * box, c);
       if (r == 0) out[0] = c[5];  // global loss
     }
   }
@@ -576,6 +606,192 @@ __global__ __launch_bounds__(256) void pearson_bwd_kernel(int H, int W, int box,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// One view's loss stage in TWO launches on ONE stream (round 6).
+// The photometric pair and the Pearson chain used to run on two streams: the fork behind the forward blend and the join
+// in front of the backward blend each cost a signal round trip between two hardware queues -- 10 and 15 us of idle GPU
+// per mapping iteration at 1280x1024 (profiles/r06_step_timeline.txt: blend_fwd ends at 173 us, photometric_fwd starts
+// at 183; photometric_bwd ends at 249, blend_bwd starts at 264), and the single-workgroup pearson_finish was a 22 us link of
+// the side chain.  Here the Pearson work rides in the photometric launches as extra workgroups at the FRONT of the grid
+// (dispatched first, they finish under the photometric tiles):
+//   launch 1 = pearson_stats chunks | photometric_fwd tiles
+//   launch 2 = pearson gradient chunks | photometric_bwd strips | one finishing wave
+// and no launch of its own finishes the Pearson regions: every gradient wave sums the per-chunk partials of launch 1
+// itself (region 0 by the whole wave, patch r by lane r -- 45 loads and one round of double arithmetic per wave, the same
+// order of additions as pearson_finish_kernel), so the stage needs nothing but the stream's own launch order.
+// Same results, bit for bit, as fsgs_photometric_loss_forward_backward + fsgs_pearson_forward + fsgs_pearson_backward.
+// ---------------------------------------------------------------------------------------------------
+struct PearsonView {
+  int box, nregions;          // nregions = n_patches + 1
+  const int64_t *row0, *col0;
+  const float *src, *tgt;     // mono-depth, rendered depth
+  double *partials;
+  int n0, nb;                 // chunks of region 0 / of a patch
+};
+
+constexpr int PV_PIX = 2048;   // pixels per gradient wave (8 chunks of 256)
+constexpr int PV_MAXNB = 4;    // a patch's partials are added by ONE lane in the butterfly's order: up to 4 of them (box <= 128;
+                               // 8 would cost the launch 40 more VGPRs and the photometric strips beside it a third of their waves)
+
+// the wave's copy of pearson_finish_kernel: lane r ends up with region r's coefficient row in c[0..5] (lanes >= nregions: zeros)
+__device__ __forceinline__ void pearson_coefs_wave(const PearsonView &pv, int H, int W, int lane, float (&c)[6]) {
+  // region 0: lane-strided sums + xor butterfly (every lane ends with the same bits)
+  double st[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = lane; i < pv.n0; i += 64)
+#pragma unroll
+    for (int q = 0; q < 5; q++) st[q] += pv.partials[5 * i + q];
+  // patch `lane`: its nb <= 4 partials, added as the butterfly of 64 lanes adds them when lanes >= nb hold zero:
+  // (p0 + p2) + (p1 + p3)
+  double t[5][PV_MAXNB];
+  const bool patch = lane >= 1 && lane < pv.nregions;
+  const double *base = pv.partials + 5 * (size_t)(pv.n0 + (patch ? lane - 1 : 0) * pv.nb);
+#pragma unroll
+  for (int i = 0; i < PV_MAXNB; i++)
+#pragma unroll
+    for (int q = 0; q < 5; q++) t[q][i] = (patch && i < pv.nb) ? base[5 * i + q] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 5; q++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) st[q] += __shfl_xor(st[q], off, 64);
+  if (patch) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      // (0.0 + p = p: the accumulators of pearson_finish_kernel start at zero)
+      st[q] = (t[q][0] + t[q][2]) + (t[q][1] + t[q][3]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) c[q] = 0.f;
+  if (lane < pv.nregions) pearson_region_coef(st, lane == 0 ? (double)H * W : (double)pv.box * pv.box, c);
+}
+
+// launch 1: blocks [0, n_pe) = Pearson statistics (region 0's n0 chunks, then nb per patch), the rest = photometric tiles
+__global__ __launch_bounds__(256) void view_losses_fwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                              const float *__restrict__ gt,
+                                                              const float *__restrict__ mask,
+                                                              const float *__restrict__ presence,
+                                                              float *__restrict__ maps, float *__restrict__ partials,
+                                                              PearsonView pv, int n_pe /* multiple of 8 */) {
+  const int b = blockIdx.x;
+  if (b < n_pe) {
+    int r = 0, chunk = b;
+    if (b >= pv.n0) {
+      r = 1 + (b - pv.n0) / pv.nb;
+      chunk = (b - pv.n0) - (r - 1) * pv.nb;
+    }
+    if (r < pv.nregions) pearson_stats_chunk(r, chunk, H, W, pv.box, pv.row0, pv.col0, pv.src, pv.tgt, pv.partials, pv.n0, pv.nb);
+    return;
+  }
+  // n_pe is a multiple of 8: block b still runs on XCD (b - n_pe) % 8 and the bands of photometric_fwd_kernel stay whole
+  photometric_fwd_tile(xcd_swizzle(b - n_pe, (int)gridDim.x - n_pe), C, H, W, img, gt, mask, presence, maps, partials);
+}
+
+// launch 2: blocks [0, n_pg) = Pearson gradient (one wave per PV_PIX pixels), then the photometric strips, then one
+// finishing wave (photometric loss value, Pearson loss values, the coefficient rows for callers that keep them)
+__global__ __launch_bounds__(64) void view_losses_bwd_kernel(int C, int H, int W, const float *__restrict__ img,
+                                                             const float *__restrict__ gt,
+                                                             const float *__restrict__ mask,
+                                                             const float *__restrict__ presence,
+                                                             const float *__restrict__ maps,
+                                                             const float *__restrict__ upstream, float lambda_dssim,
+                                                             float *__restrict__ dimg, FinishArgs fin, PearsonView pv,
+                                                             const float *__restrict__ weight, float *__restrict__ grad,
+                                                             float *__restrict__ coef, float *__restrict__ out2,
+                                                             int n_pg /* multiple of 8 */) {
+  const int lane = threadIdx.x;
+  const int nstrips = ((W + ST_W - 1) / ST_W) * ((H + ST_RS - 1) / ST_RS) * C;
+  const int b = blockIdx.x;
+  if (b >= n_pg && b < n_pg + nstrips) {
+    photometric_bwd_strip(xcd_swizzle(b - n_pg, nstrips), C, H, W, img, gt, mask, presence, maps, upstream, lambda_dssim, dimg);
+    return;
+  }
+  const size_t n = (size_t)H * W;
+  const bool finishing = b >= n_pg;
+  if (!finishing && (size_t)b * PV_PIX >= n) return;  // padding of n_pg
+  float c[6];
+  pearson_coefs_wave(pv, H, W, lane, c);
+  if (finishing) {
+    photometric_finish_wave(fin, lambda_dssim, lane);
+    if (lane < pv.nregions) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) coef[8 * lane + q] = c[q];
+    }
+    // the patch losses in the order of the reference's python loop (pearson_finish_kernel's last step)
+    float acc = 0.f;
+    for (int r = 1; r < pv.nregions && r < 64; r++) acc += readlane(c[5], r);
+    if (lane == 0) {
+      out2[0] = c[5];
+      out2[1] = pv.nregions > 1 ? acc / (float)(pv.nregions - 1) : 0.f;
+    }
+    return;
+  }
+  // ---- pearson_bwd_kernel for one wave: d/d tgt (the rendered depth), 4 pixels of a 256-pixel chunk per lane ----
+  __shared__ float s_coef[64][8];
+  __shared__ int s_rect[64][2];
+  __shared__ int s_list[64];
+  {
+    const float wgt = lane < pv.nregions ? weight[lane] : 0.f;
+    s_coef[lane][0] = c[0]; s_coef[lane][1] = c[1];
+    s_coef[lane][2] = c[2] * wgt; s_coef[lane][3] = c[3] * wgt; s_coef[lane][4] = c[4] * wgt;
+    s_rect[lane][0] = (lane >= 1 && lane < pv.nregions) ? (int)pv.row0[lane - 1] : 0;
+    s_rect[lane][1] = (lane >= 1 && lane < pv.nregions) ? (int)pv.col0[lane - 1] : 0;
+  }
+  __syncthreads();
+  const int box = pv.box;
+  const size_t first = (size_t)b * PV_PIX, last_ = min(n, first + PV_PIX);
+  for (size_t c0 = first; c0 < last_; c0 += 256) {
+    const size_t c1 = min(n, c0 + 256) - 1;  // last pixel of the chunk
+    const int ya = (int)(c0 / W), yb = (int)(c1 / W);
+    const int xa = ya == yb ? (int)(c0 - (size_t)ya * W) : 0, xb = ya == yb ? (int)(c1 - (size_t)yb * W) : W - 1;
+    // the loads of the chunk go out before the list is built
+    float sv[4], tv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t p = min(c0 + lane + 64 * k, n - 1);
+      sv[k] = pv.src[p];
+      tv[k] = pv.tgt[p];
+    }
+    __syncthreads();  // the previous chunk's list is no longer read
+    int nl;
+    {
+      const int r = 1 + lane;  // nregions <= 64 on this route
+      bool hit = false;
+      if (r < pv.nregions) {
+        const int py = s_rect[r][0], px_ = s_rect[r][1];
+        hit = py <= yb && py + box > ya && px_ <= xb && px_ + box > xa;
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) s_list[__popcll(m & ((1ull << lane) - 1ull))] = r;
+      nl = __popcll(m);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t p = c0 + lane + 64 * k;
+      if (p >= n) continue;
+      const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+      const float s_ = sv[k], t = tv[k];
+      float g = 0.f;
+      {
+        const float *cc = s_coef[0];
+        float a = s_ - cc[0], bb = t - cc[1];
+        g += -a * cc[2] + cc[3] * bb;
+      }
+      for (int q = 0; q < nl; q++) {
+        const int r = s_list[q];
+        int dy = y - s_rect[r][0], dx = x - s_rect[r][1];
+        if ((unsigned)dy < (unsigned)box && (unsigned)dx < (unsigned)box) {
+          const float *cc = s_coef[r];
+          float a = s_ - cc[0], bb = t - cc[1];
+          g += -a * cc[2] + cc[3] * bb;
+        }
+      }
+      grad[p] = g;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -636,6 +852,41 @@ int fsgs_photometric_loss_forward_backward(int C, int H, int W, const float *img
     ProfScope ps(PROF_LOSS_RGB_BWD, stream);
     hipLaunchKernelGGL(photometric_bwd_kernel, gb, dim3(64), 0, stream, C, H, W, img, gt, mask, presence, maps,
                        upstream, lambda_dssim, dimg, FinishArgs{partials, nblocks, (double)C * H * W, out3});
+  }
+  FSGS_HIP(hipGetLastError());
+  return FSGS_OK;
+}
+
+int fsgs_view_losses_forward_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                      const float *presence, float lambda_dssim, float *maps, void *photo_scratch,
+                                      float *out3, const float *upstream, float *dimg, int n_patches, int box,
+                                      const int64_t *patch_row0, const int64_t *patch_col0, const float *src,
+                                      const float *tgt, void *pearson_scratch, float *coef, float *out2,
+                                      const float *region_weight, float *grad_tgt, fsgs_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (C <= 0 || H <= 0 || W <= 0 || !img || !gt || !maps || !photo_scratch || !out3 || !dimg) return FSGS_ERR_INVALID;
+  if (n_patches < 0 || n_patches > 63 || !src || !tgt || !pearson_scratch || !coef || !out2 || !region_weight || !grad_tgt)
+    return FSGS_ERR_INVALID;
+  if (n_patches > 0 && (!patch_row0 || !patch_col0 || box <= 1 || box > H || box > W)) return FSGS_ERR_INVALID;
+  const int n0 = (int)(((size_t)H * W + PE_CHUNK - 1) / PE_CHUNK);
+  const int nb = n_patches > 0 ? (int)(((size_t)box * box + PE_CHUNK - 1) / PE_CHUNK) : 0;
+  if (nb > PV_MAXNB) return FSGS_ERR_INVALID;  // (boxes beyond 128 x 128: the three-call route)
+  PearsonView pv{box, n_patches + 1, patch_row0, patch_col0, src, tgt, (double *)pearson_scratch, n0, nb};
+  const int ntiles = ((W + SS_TILE - 1) / SS_TILE) * ((H + SS_TILE - 1) / SS_TILE) * C;
+  const int nstrips = ((W + ST_W - 1) / ST_W) * ((H + ST_RS - 1) / ST_RS) * C;
+  const int n_pe = (n0 + n_patches * nb + 7) & ~7;
+  const int n_pg = ((int)(((size_t)H * W + PV_PIX - 1) / PV_PIX) + 7) & ~7;
+  float *partials = (float *)photo_scratch;
+  {
+    ProfScope ps(PROF_LOSS_RGB_FWD, stream);
+    hipLaunchKernelGGL(view_losses_fwd_kernel, dim3(n_pe + ntiles), dim3(256), kFwdDynLds, stream, C, H, W, img, gt, mask,
+                       presence, maps, partials, pv, n_pe);
+  }
+  {
+    ProfScope ps(PROF_LOSS_RGB_BWD, stream);
+    hipLaunchKernelGGL(view_losses_bwd_kernel, dim3(n_pg + nstrips + 1), dim3(64), 0, stream, C, H, W, img, gt, mask,
+                       presence, maps, upstream, lambda_dssim, dimg, FinishArgs{partials, ntiles, (double)C * H * W, out3},
+                       pv, region_weight, grad_tgt, coef, out2, n_pg);
   }
   FSGS_HIP(hipGetLastError());
   return FSGS_OK;

@@ -163,6 +163,8 @@ _PROTOTYPES = {
     "fsgs_photometric_loss_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "fsgs_photometric_loss_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp]),
     "fsgs_photometric_loss_forward_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsgs_view_losses_forward_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp,
+                                               _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_pearson_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "fsgs_pearson_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsgs_flow_pose_loss_forward": (_i, [_i64, _vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i, _i, C.c_float, _vp, _vp,

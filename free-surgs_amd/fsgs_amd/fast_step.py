@@ -89,6 +89,11 @@ class FastStepper:
         self.compact = True    # multi-view / multi-rank steps: [P,14] gradient + fsgs_adam_step_compact
         self.fuse_pose = True  # tracking: pose adjoint + Adam + next pose in one launch
         # (FSGS_OVERLAP_VIEWS=0 / FSGS_CACHE_COLORS=0: bisection switches, diagnostics only)
+        # FSGS_LOSS_STREAMS=1: the loss stage as two launches on ONE stream (fsgs_view_losses_forward_backward, round 6).  Measured
+        # equal at 1280x1024 (0.5785 vs 0.5776 ms / step: the fork / join gaps a rocprofv3 timeline shows between the two streams
+        # are the tracer's, not the step's) and slower at 640x512 (0.190 vs 0.172): the default stays two streams
+        # (profiles/r06_ab_loss_streams.txt)
+        self.one_stream_losses = os.environ.get("FSGS_LOSS_STREAMS", "2") == "1"
         self.overlap_views = os.environ.get("FSGS_OVERLAP_VIEWS", "1") != "0"  # multi-view mapping steps: views >= 1 on their own streams beside view 0
         self.cache_colors = os.environ.get("FSGS_CACHE_COLORS", "1") != "0"    # the Adam kernels leave the next forward's per-Gaussian colours behind (16 B instead of 192 B)
         self.cache_hits = 0        # forwards served from that cache (tests / diagnostics)
@@ -440,6 +445,14 @@ class FastStepper:
         side = self._side_stream(dev, view)
         with torch.cuda.stream(side):  # (nothing here depends on the current stream: no event in front of the forward)
             cr = corners if corners is not None else losses.draw_patch_corners(H, W, BOX, P_CORR, dev)
+        b.corners_drawn = None
+        if corners is None and self.one_stream_losses:
+            # the one-stream loss stage reads the corners on the CURRENT stream: an event behind the draws, waited for at the
+            # loss stage only if it has not fired by then (it has: the draws run at once on the idle side stream, a forward ahead)
+            if getattr(b, "draw_event", None) is None:
+                b.draw_event = torch.cuda.Event()
+            b.draw_event.record(side)
+            b.corners_drawn = b.draw_event
         # the side stream's Pearson chain waits for the forward's outputs: an event that rides on the forward blend's launch
         # (fsgs_forward_done_event) instead of a marker recorded behind it, which would sit between the blend and the first
         # loss kernel on this stream (~6 us)
@@ -460,6 +473,23 @@ class FastStepper:
         stream = _lib.current_stream()
         ts, cr, side = ctx["ts"], ctx["cr"], ctx["side"]
         gt, mono = self.frames.colors[ts], self.frames.monodeps[ts]
+        if self.one_stream_losses and n_patches <= 63 and BOX <= 128:
+            # Round 6: the whole stage in two launches on THIS stream (fsgs_view_losses_forward_backward): the Pearson
+            # statistics ride in the photometric forward's launch, the Pearson gradient in the backward's.  The fork / join
+            # events of the two-stream layout below cost 10 + 15 us of idle GPU per iteration at 1280x1024.
+            drawn = getattr(b, "corners_drawn", None)
+            if drawn is not None and not drawn.query():
+                torch.cuda.current_stream().wait_event(drawn)
+            _lib.check(lib.fsgs_view_losses_forward_backward(
+                3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),
+                _lib.ptr(b.rgb_out), _lib.ptr(b.up_rgb), _lib.ptr(b.d_image), n_patches, BOX, _lib.ptr(cr[0]), _lib.ptr(cr[1]),
+                _lib.ptr(mono), _lib.ptr(b.depth_sil[0]), _lib.ptr(b.stats), _lib.ptr(b.coef), _lib.ptr(b.pe_out),
+                _lib.ptr(b.pe_w), _lib.ptr(b.d_depth_sil[0]), stream), "fsgs_view_losses_forward_backward")
+            if drawn is not None:  # drawn on the side stream, last read on this one
+                cur = torch.cuda.current_stream()
+                for t_ in cr:
+                    t_.record_stream(cur)
+            return
         # forward + backward in two launches (the loss value is finished by an extra workgroup of the backward)
         _lib.check(lib.fsgs_photometric_loss_forward_backward(
             3, H, W, _lib.ptr(b.image), _lib.ptr(gt), None, None, 0.2, _lib.ptr(b.maps), _lib.ptr(b.sums),

@@ -403,6 +403,20 @@ int fsgs_pearson_backward(int H, int W, int n_patches, int box, const int64_t *p
                           const float *src, const float *tgt, const float *coef, const float *region_weight,
                           int wrt_src, float *grad, fsgs_stream_t stream);
 
+/* One view's whole loss stage (train.py:236-258: rgb loss of the rendered image + global and local Pearson losses of the
+ * rendered depth against the mono-depth) in TWO launches on ONE stream: the Pearson statistics ride in the photometric
+ * forward's launch and the Pearson gradient (whose waves finish the regions' sums themselves) in the backward's, as
+ * extra workgroups at the front of each grid -- no second stream, no fork / join events.  Same results, bit for bit, as
+ * fsgs_photometric_loss_forward_backward(img, gt, ...) + fsgs_pearson_forward(src, tgt, ...) +
+ * fsgs_pearson_backward(..., wrt_src = 0, grad_tgt); arguments as there.  n_patches <= 63 and box <= 128 (at most
+ * 4 partial sums per patch), else FSGS_ERR_INVALID: use the three calls. */
+int fsgs_view_losses_forward_backward(int C, int H, int W, const float *img, const float *gt, const float *mask,
+                                      const float *presence, float lambda_dssim, float *maps, void *photo_scratch,
+                                      float *out3, const float *upstream, float *dimg, int n_patches, int box,
+                                      const int64_t *patch_row0, const int64_t *patch_col0, const float *src,
+                                      const float *tgt, void *pearson_scratch, float *coef, float *out2,
+                                      const float *region_weight, float *grad_tgt, fsgs_stream_t stream);
+
 /* ---- optical-flow reprojection loss of the tracking step (scene/pose_optimizer.py:164-218) ----------- */
 
 /* pts_world [M,3] and pix_vu int64 [M,2] = (v, u): the back-projected valid pixels of the previous frame

@@ -219,3 +219,80 @@ def test_fused_forward_backward_entry_equals_the_two_calls(shape, masked):
     # argument checks of the new entry
     assert lib.fsgs_photometric_loss_forward_backward(0, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, None, None, None,
                                                       None, None, stream) == _lib.FSGS_ERR_INVALID
+
+
+@pytest.mark.parametrize("shape,n_patches,box", [((3, 64, 96), 0, 0), ((3, 250, 333), 5, 100), ((3, 512, 640), 12, 128),
+                                                 ((3, 1024, 1280), 40, 128), ((3, 1080, 1920), 63, 128)])
+def test_one_stream_view_loss_stage_equals_the_three_calls(shape, n_patches, box):
+    """fsgs_view_losses_forward_backward (round 6: one view's loss stage in two launches on one stream -- the Pearson statistics
+    as extra workgroups of the photometric forward, the Pearson gradient, whose waves finish the regions' sums themselves, as
+    extra workgroups of the photometric backward) against fsgs_photometric_loss_forward_backward + fsgs_pearson_forward +
+    fsgs_pearson_backward through the raw C ABI: every output bit-identical (utils/loss_utils.py:41-127, train.py:250-258)."""
+    from fsgs_amd import _lib
+
+    lib = _lib.load()
+    Cc, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(11 + n_patches)
+    gt = torch.rand(shape, generator=g).to(DEV)
+    img = (gt + 0.1 * torch.randn(shape, generator=g).to(DEV)).clamp(0, 1).contiguous()
+    mono = torch.rand((H, W), generator=g).to(DEV)
+    depth = (0.6 * mono + 0.4 * torch.rand((H, W), generator=g).to(DEV) + 0.5).contiguous()
+    rows = torch.randint(0, max(H - box, 1), (max(n_patches, 1),), generator=g).to(DEV)
+    cols = torch.randint(0, max(W - box, 1), (max(n_patches, 1),), generator=g).to(DEV)
+    if n_patches >= 2:  # one patch in the corner, one overlapping it: the ragged cases of the patch list
+        rows[0], cols[0] = H - box - 1, W - box - 1
+        rows[1], cols[1] = H - box - 1 - box // 2, W - box - 1 - box // 3
+    up = torch.tensor([5.0], device=DEV)
+    wreg = torch.full((n_patches + 1,), 0.15 / max(n_patches, 1), device=DEV)
+    wreg[0] = 0.05
+    nbp = int(lib.fsgs_photometric_scratch_bytes(Cc, H, W))
+    nbs = int(lib.fsgs_pearson_scratch_bytes(H, W, n_patches, box))
+    stream = _lib.current_stream()
+
+    def run(fused):
+        maps = torch.empty((3, Cc, H, W), device=DEV)
+        sums = torch.zeros((nbp,), dtype=torch.uint8, device=DEV)
+        stats = torch.zeros((nbs,), dtype=torch.uint8, device=DEV)
+        out3, out2 = torch.zeros((3,), device=DEV), torch.zeros((2,), device=DEV)
+        coef = torch.zeros((8 * (n_patches + 1),), device=DEV)
+        dimg, ddep = torch.full(shape, 7.0, device=DEV), torch.full((H, W), 7.0, device=DEV)
+        if fused:
+            _lib.check(lib.fsgs_view_losses_forward_backward(
+                Cc, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, _lib.ptr(maps), _lib.ptr(sums), _lib.ptr(out3),
+                _lib.ptr(up), _lib.ptr(dimg), n_patches, box, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(mono), _lib.ptr(depth),
+                _lib.ptr(stats), _lib.ptr(coef), _lib.ptr(out2), _lib.ptr(wreg), _lib.ptr(ddep), stream),
+                "fsgs_view_losses_forward_backward")
+        else:
+            _lib.check(lib.fsgs_photometric_loss_forward_backward(
+                Cc, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, _lib.ptr(maps), _lib.ptr(sums), _lib.ptr(out3),
+                _lib.ptr(up), _lib.ptr(dimg), stream), "fsgs_photometric_loss_forward_backward")
+            _lib.check(lib.fsgs_pearson_forward(H, W, n_patches, box, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(mono),
+                                                _lib.ptr(depth), _lib.ptr(stats), _lib.ptr(coef), _lib.ptr(out2), stream),
+                       "fsgs_pearson_forward")
+            _lib.check(lib.fsgs_pearson_backward(H, W, n_patches, box, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(mono),
+                                                 _lib.ptr(depth), _lib.ptr(coef), _lib.ptr(wreg), 0, _lib.ptr(ddep), stream),
+                       "fsgs_pearson_backward")
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (out3, out2, coef.view(-1, 8)[:, :6], dimg, ddep)]
+
+    want, got = run(False), run(True)
+    for name, a, b in zip(("rgb terms", "pearson terms", "coefficient rows", "dL/dimage", "dL/ddepth"), want, got):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert bool(torch.isfinite(got[4]).all()) and float(got[4].abs().max()) > 0 and float(got[1][0]) > 0
+    if n_patches:
+        assert float(got[1][1]) > 0
+    # a second call over the same buffers (scratch not re-zeroed) gives the same bits
+    again = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    # argument checks: more than 63 patches / boxes beyond 128 belong to the three-call route
+    bad = lib.fsgs_view_losses_forward_backward(
+        Cc, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, _lib.ptr(img), _lib.ptr(img), _lib.ptr(img), None, _lib.ptr(img),
+        64, box, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(mono), _lib.ptr(depth), _lib.ptr(img), _lib.ptr(img), _lib.ptr(img),
+        _lib.ptr(wreg), _lib.ptr(img), stream)
+    assert bad == _lib.FSGS_ERR_INVALID
+    if H > 200 and W > 200:
+        bad = lib.fsgs_view_losses_forward_backward(
+            Cc, H, W, _lib.ptr(img), _lib.ptr(gt), None, None, 0.2, _lib.ptr(img), _lib.ptr(img), _lib.ptr(img), None,
+            _lib.ptr(img), 1, 130, _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(mono), _lib.ptr(depth), _lib.ptr(img), _lib.ptr(img),
+            _lib.ptr(img), _lib.ptr(wreg), _lib.ptr(img), stream)
+        assert bad == _lib.FSGS_ERR_INVALID
