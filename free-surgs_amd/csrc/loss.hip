@@ -40,6 +40,26 @@ __constant__ float kGauss[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.
                                  0.2660117249f, 0.2130055377f, 0.1093606895f, 0.0360007721f, 0.0075987581f,
                                  0.0010283801f};
 
+// element idx of a plane through a 32-bit BYTE offset: the load takes the plane's (uniform, scalar) base and one vector
+// offset register (global_load_dword v, v_off, s[base]) instead of a 64-bit address pair formed per load
+#ifndef FSGS_LOSS_V2
+#define FSGS_LOSS_V2 0
+#endif
+__device__ __forceinline__ float ld_plane(const float *__restrict__ base, uint32_t idx) {
+#if FSGS_LOSS_V2
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(uint32_t)(idx << 2));
+#else
+  return base[idx];
+#endif
+}
+__device__ __forceinline__ void st_plane(float *__restrict__ base, uint32_t idx, float v) {
+#if FSGS_LOSS_V2
+  *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)(uint32_t)(idx << 2)) = v;
+#else
+  base[idx] = v;
+#endif
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float *red) {
   // 4 waves: DPP wave sums, then one LDS hop
   float w = wave_sum(v);
@@ -99,11 +119,11 @@ __device__ __forceinline__ void photometric_fwd_tile(const int tile_id, int C, i
     const int ly = i / SS_IN, lx = i - ly * SS_IN;
     const int gy = y0 + ly - SS_HALO, gx = x0 + lx - SS_HALO;
     inb[r] = i < SS_IN * SS_IN && gy >= 0 && gy < H && gx >= 0 && gx < W;  // outside: zero padding (F.conv2d padding=5)
-    const size_t p = inb[r] ? (size_t)gy * W + gx : 0;
-    va[r] = ip[p];
-    vb[r] = gp[p];
-    vm[r] = mp[p];
-    vp[r] = pp[p];
+    const uint32_t p = inb[r] ? (uint32_t)gy * (uint32_t)W + (uint32_t)gx : 0u;  // inside one plane: < 2^30
+    va[r] = ld_plane(ip, p);
+    vb[r] = ld_plane(gp, p);
+    vm[r] = ld_plane(mp, p);
+    vp[r] = ld_plane(pp, p);
   }
 #pragma unroll
   for (int r = 0; r < NLD; r++) {
@@ -118,8 +138,19 @@ __device__ __forceinline__ void photometric_fwd_tile(const int tile_id, int C, i
   // it reads once (3.5 LDS reads per output and map instead of 11).  Every output still accumulates its taps in
   // the order k = 0..10.
   // horizontal pass of the five moments: SS_IN rows x (SS_TILE / SS_BLK) segments
+#if FSGS_LOSS_V2
+  // 336 tasks for 256 threads: the 80 tasks of the second round go to a different wave from tile to tile (in the plain
+  // order below they are always wave 0's and a quarter of wave 1's: if wave w of every workgroup sits on SIMD w, SIMD 0
+  // runs two rounds for every tile of the CU and SIMDs 2, 3 one)
+  const int rot_t = (int)((threadIdx.x + 64u * ((unsigned)tile_id & 3u)) & 255u);
+  for (int round = 0; round < 2; round++) {
+    const int task = round == 0 ? (int)threadIdx.x : 256 + rot_t;
+    if (task >= SS_IN * (SS_TILE / SS_BLK)) break;
+    const int ly = task / (SS_TILE / SS_BLK), lx = (task - ly * (SS_TILE / SS_BLK)) * SS_BLK;
+#else
   for (int task = threadIdx.x; task < SS_IN * (SS_TILE / SS_BLK); task += 256) {
     const int ly = task / (SS_TILE / SS_BLK), lx = (task - ly * (SS_TILE / SS_BLK)) * SS_BLK;
+#endif
     float2v ab[SS_BLK + 10], sq[SS_BLK + 10];
 #pragma unroll
     for (int j = 0; j < SS_BLK + 10; j++) {
@@ -185,10 +216,11 @@ __device__ __forceinline__ void photometric_fwd_tile(const int tile_id, int C, i
       ss_acc += S;
       const float2v c = sxy[ly + SS_HALO][lx + SS_HALO];
       l1_acc += fabsf(c.x - c.y);
-      size_t p = ch * plane + (size_t)gy * W + gx;
-      maps[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (rB1 - rB2);  // d/dm1
-      maps[cplane + p] = -S * rB2;                                         // d/de11
-      maps[2 * cplane + p] = 2.f * A1 * inv;                               // d/de12
+      const uint32_t p = (uint32_t)gy * (uint32_t)W + (uint32_t)gx;
+      float *mc = maps + (size_t)ch * plane;
+      st_plane(mc, p, 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * (rB1 - rB2));  // d/dm1
+      st_plane(mc + cplane, p, -S * rB2);                                         // d/de11
+      st_plane(mc + 2 * cplane, p, 2.f * A1 * inv);                               // d/de12
     }
   }
   float t1 = block_sum_256(l1_acc, red);
@@ -287,7 +319,10 @@ __global__ __launch_bounds__(256) void photometric_finish_kernel(const float *__
 // only registers: no workgroup barrier, < 1 KB of LDS.  (The same scheme was measured for the forward kernel,
 // whose five moments need 154 VGPRs and 33 extra multiplies per row: 82 us against 55 us for the tiled kernel.)
 // (the body as a function of the strip id: photometric_bwd_kernel and view_losses_bwd_kernel both run it)
-__device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, int H, int W, const float *__restrict__ img,
+// INTERIOR (FSGS_LOSS_V2): the strip and its halo lie inside the image (87 % of the strips at 1280x1024) -- nothing is zero
+// padding, the twelve selects per input row that put the zeros in are left out
+template <bool INTERIOR>
+__device__ __forceinline__ void photometric_bwd_strip_t(const int strip, int C, int H, int W, const float *__restrict__ img,
                                                       const float *__restrict__ gt, const float *__restrict__ mask,
                                                       const float *__restrict__ presence, const float *__restrict__ maps,
                                                       const float *__restrict__ upstream, float lambda_dssim,
@@ -315,8 +350,8 @@ __device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, in
   const uint32_t gxc = (uint32_t)min(gx, W - 1);
   auto fetch_row = [&](int gy, float (&v0)[3], float (&v1)[3]) {
     const uint32_t rowoff = (uint32_t)min(max(gy, 0), H - 1) * (uint32_t)W;  // 32-bit offsets inside one plane (H * W < 2^30)
-    v0[0] = map0[rowoff + c0c]; v0[1] = map1[rowoff + c0c]; v0[2] = map2[rowoff + c0c];
-    v1[0] = map0[rowoff + c1c]; v1[1] = map1[rowoff + c1c]; v1[2] = map2[rowoff + c1c];
+    v0[0] = ld_plane(map0, rowoff + c0c); v0[1] = ld_plane(map1, rowoff + c0c); v0[2] = ld_plane(map2, rowoff + c0c);
+    v1[0] = ld_plane(map0, rowoff + c1c); v1[1] = ld_plane(map1, rowoff + c1c); v1[2] = ld_plane(map2, rowoff + c1c);
   };
   const float up = upstream ? upstream[0] : 1.0f;
   const float invN = 1.0f / ((float)C * (float)H * (float)W);
@@ -331,10 +366,10 @@ __device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, in
   float n0[ST_PF][3], n1[ST_PF][3], nx[ST_PF], ny[ST_PF], nm[ST_PF], np_[ST_PF];
   auto fetch_pixel = [&](int rr, float &x, float &y, float &m, float &pr) {  // the output pixel of iteration rr
     const uint32_t e = (uint32_t)min(max(y0 + rr - 2 * SS_HALO, 0), H - 1) * (uint32_t)W + gxc;
-    x = img_c[e];
-    y = gt_c[e];
-    m = mask_c[e];
-    pr = pres_c[e];
+    x = ld_plane(img_c, e);
+    y = ld_plane(gt_c, e);
+    m = ld_plane(mask_c, e);
+    pr = ld_plane(pres_c, e);
   };
 #pragma unroll
   for (int st = 0; st < ST_PF; st++) {
@@ -354,13 +389,13 @@ __device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, in
         const bool in_row = gy >= 0 && gy < H;  // outside the image: zero padding (F.conv2d padding = 5)
 #pragma unroll
         for (int m = 0; m < 3; m++) {
-          row[m][lane] = (in_row && in_c0) ? n0[st][m] : 0.f;
-          if (lane < 2 * SS_HALO) row[m][ST_W + lane] = (in_row && in_c1) ? n1[st][m] : 0.f;
+          row[m][lane] = (INTERIOR || (in_row && in_c0)) ? n0[st][m] : 0.f;
+          if (lane < 2 * SS_HALO) row[m][ST_W + lane] = (INTERIOR || (in_row && in_c1)) ? n1[st][m] : 0.f;
         }
       }
       __syncthreads();
       const int oy = y0 + r - 2 * SS_HALO;
-      const bool out_ok = r >= 2 * SS_HALO && oy < H && gx < W;
+      const bool out_ok = INTERIOR || (r >= 2 * SS_HALO && oy < H && gx < W);  // (r < 2 * SS_HALO leaves the iteration below)
       const float ex = nx[st], ey = ny[st], em = nm[st], ep = np_[st];
       fetch_row(y0 - SS_HALO + r + ST_PF, n0[st], n1[st]);  // (the last ST_PF requests are never used: no condition, see above)
       fetch_pixel(r + ST_PF, nx[st], ny[st], nm[st], np_[st]);
@@ -381,16 +416,32 @@ __device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, in
         f[m] = acc;
       }
       if (out_ok) {
-        const size_t p = ch * plane + (size_t)oy * W + gx;
         float mk = mask ? em : 1.0f;  // pixel_mask()
         if (presence) mk = ep > 0.f ? mk : 0.f;
         const float x = ex * mk, y = ey * mk;
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dimg[p] = mk * (k_l1 * sgn + k_ss * (f[0] + 2.f * x * f[1] + y * f[2]));
+        dimg[ch * plane + (size_t)oy * W + gx] = mk * (k_l1 * sgn + k_ss * (f[0] + 2.f * x * f[1] + y * f[2]));
       }
     }
   }
+}
+
+__device__ __forceinline__ void photometric_bwd_strip(const int strip, int C, int H, int W, const float *__restrict__ img,
+                                                      const float *__restrict__ gt, const float *__restrict__ mask,
+                                                      const float *__restrict__ presence, const float *__restrict__ maps,
+                                                      const float *__restrict__ upstream, float lambda_dssim,
+                                                      float *__restrict__ dimg) {
+#if FSGS_LOSS_V2
+  const int strips_x = (W + ST_W - 1) / ST_W, strips_y = (H + ST_RS - 1) / ST_RS;
+  const int s2 = strip % (strips_x * strips_y);
+  const int x0 = (s2 % strips_x) * ST_W, y0 = (s2 / strips_x) * ST_RS;
+  if (x0 >= SS_HALO && x0 + ST_W + SS_HALO <= W && y0 >= SS_HALO && y0 + ST_RS + SS_HALO <= H) {  // wave-uniform
+    photometric_bwd_strip_t<true>(strip, C, H, W, img, gt, mask, presence, maps, upstream, lambda_dssim, dimg);
+    return;
+  }
+#endif
+  photometric_bwd_strip_t<false>(strip, C, H, W, img, gt, mask, presence, maps, upstream, lambda_dssim, dimg);
 }
 
 __global__ __launch_bounds__(64) void photometric_bwd_kernel(int C, int H, int W, const float *__restrict__ img,

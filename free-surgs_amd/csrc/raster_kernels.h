@@ -145,7 +145,11 @@ __device__ __forceinline__ void clear_binning_cursors(const GeomOut &g) {
 // list alone would cost > 100 us per binning pass.  Every tile therefore owns BIN_SUBS counters / cursors (bin_slot below
 // says which one a key takes), and its list is the concatenation of the BIN_SUBS sub-lists (the per-tile sort restores the
 // (depth, index) order anyway).
-constexpr int BIN_SUBS = 8;
+#ifndef FSGS_BIN_SUBS
+#define FSGS_BIN_SUBS 8  // (A/B build switch, a power of two >= 4: scripts/dev/ab_bin_subs.sh)
+#endif
+constexpr int BIN_SUBS = FSGS_BIN_SUBS;
+static_assert(BIN_SUBS >= 4 && (BIN_SUBS & (BIN_SUBS - 1)) == 0, "bin_slot masks with BIN_SUBS - 1; the order pass reads the cursors as uint4");
 // Which of a tile's BIN_SUBS sub-lists a key goes to: the Gaussian index (gaussian & 7).  Round 6 tried the XCD the writing
 // workgroup runs on instead (HW_REG_XCC_ID; FSGS_BIN_SUB_XCC=1): every 64-byte line of a segment then collects its eight keys in ONE
 // L2 and the key stores' write amplification drops (WRITE_SIZE 51.7 -> 45.3 MB; the rest is the cursor atomics, tallied at 32 B a
@@ -290,7 +294,13 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int P, int gx, const u
           klo[u] = __float_as_uint(b.w);
           khi[u] = __float_as_uint(b.z);
           seg[u] = (uint32_t)bin_slot(ty * gx + tx, FSGS_BIN_SUB_XCC ? xcc : (int)klo[u]);
+#if FSGS_BIN_SUB_XCC == 2
+          // the cursor of (tile, XCD) is only ever touched from this XCD: the atomic can execute in the XCD's own L2 (no sc1:
+          // workgroup scope), not at the memory side where agent-scope atomics of a multi-XCD part meet
+          slot[u] = __hip_atomic_fetch_add(&cursors[seg[u]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
           slot[u] = atomicAdd(&cursors[seg[u]], 1u);
+#endif
         }
       }
     }
@@ -459,11 +469,13 @@ __device__ __forceinline__ void tile_order_from_cursors(uint32_t *smem /* >= 1 K
   hist[threadIdx.x] = 0;
 #pragma unroll 4
   for (int i = (int)threadIdx.x; i < ntiles; i += 256) {  // strided ownership: coalesced 32-byte rows
-    const uint4 a = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS);
-    const uint4 b = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS + 4);
-    worst = max(worst, max(max(max(a.x, a.y), max(a.z, a.w)), max(max(b.x, b.y), max(b.z, b.w))));
-    const uint32_t n = min(a.x, cap_sub) + min(a.y, cap_sub) + min(a.z, cap_sub) + min(a.w, cap_sub) +
-                       min(b.x, cap_sub) + min(b.y, cap_sub) + min(b.z, cap_sub) + min(b.w, cap_sub);
+    uint32_t n = 0;
+#pragma unroll
+    for (int q = 0; q < BIN_SUBS; q += 4) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(cursors + (size_t)i * BIN_SUBS + q);
+      worst = max(worst, max(max(a.x, a.y), max(a.z, a.w)));
+      n += min(a.x, cap_sub) + min(a.y, cap_sub) + min(a.z, cap_sub) + min(a.w, cap_sub);
+    }
     mine += n;
     bins[i] = (uint8_t)(ORDER_BINS_FUSED - 1 - (int)min(n >> 2, (uint32_t)(ORDER_BINS_FUSED - 1)));  // bin 0 = longest
   }
