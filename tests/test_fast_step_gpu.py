@@ -760,3 +760,40 @@ def test_forward_done_event_orders_another_stream_behind_the_forward_blend():
     _lib.check(lib.fsgs_event_destroy(ev), "fsgs_event_destroy")
     assert lib.fsgs_event_destroy(None) == _lib.FSGS_OK
 
+
+
+@pytest.mark.parametrize("given_corners", [True, False])
+def test_one_stream_loss_stage_is_the_same_step(given_corners):
+    """FSGS_LOSS_STREAMS=1 (`one_stream_losses`: the view's loss stage as the two launches of
+    fsgs_view_losses_forward_backward on the step's own stream, patch corners drawn on the side stream and joined by an
+    event that has fired long before) against the default two-stream layout: the first step's loss terms and loss
+    gradients are the same bits (the forward and the loss kernels are deterministic); further one- and two-view steps stay
+    within the run-to-run noise of the backward's float atomics; both consume the RNG alike (train.py:236-258)."""
+    H, W = 256, 320
+    wa, wb = _world(), _world()
+    fa, fb = FastStepper(wa[0], wa[1], wa[2]), FastStepper(wb[0], wb[1], wb[2])
+    fa.one_stream_losses, fb.one_stream_losses = False, True
+    corners = losses.draw_patch_corners(H, W, 128, 0.5, DEV) if given_corners else None
+    seeds = []
+    for fs in (fa, fb):
+        torch.manual_seed(5)
+        fs.mapping_step([1], corners=corners)
+        torch.cuda.synchronize()
+        seeds.append(torch.cuda.get_rng_state().clone())
+    assert torch.equal(seeds[0], seeds[1])
+    ba, bb = fa.buf, fb.buf  # view 0's buffer set
+    assert torch.equal(ba.terms[:5], bb.terms[:5]), (ba.terms, bb.terms)
+    assert torch.equal(ba.d_image, bb.d_image) and torch.equal(ba.d_depth_sil[0], bb.d_depth_sil[0])
+    assert float(bb.d_depth_sil[0].abs().max()) > 0 and float(bb.terms[4]) > 0
+    for views in ([2, 1], [0], [1, 2, 0], [2]):
+        ls = []
+        for fs in (fa, fb):
+            torch.manual_seed(11 + len(views))
+            ls.append(fs.mapping_step(views, corners=corners))
+        torch.cuda.synchronize()
+        assert abs(ls[0].item() - ls[1].item()) <= 1e-5 * abs(ls[0].item())
+    for k in PARAM_NAMES:
+        pa, pb = wa[0].params[k].detach(), wb[0].params[k].detach()
+        assert ((pa - pb).abs() > 1e-5 * pa.abs().max()).float().mean().item() < 2e-3, k
+    for k in ("max_radii2D", "denom"):
+        assert torch.equal(wa[0].variables[k], wb[0].variables[k]), k
