@@ -100,7 +100,11 @@ def test_runner_reaches_the_outcome_of_the_cpu_oracle_harness_on_c1_as_stated(or
 #     negative control below.
 FLOORS = {
     "gross": dict(per_frame=dict(track_first=0.6, track_last=0.6, map_mean=0.15), means=dict(track_first=0.2, track_last=0.2, map_mean=0.08),
-                  cloud=0.01, pose_t_steps=0.15, pose_r=1e-3, rpe_ate_steps=0.2, rpe_r_deg=0.05, psnr_db=3.0),
+                  # (round 6, 1 750 runs of the test body, scripts/dev/harness_margins.py, profiles/r06_harness_margins.json: with
+                  # pose_t_steps = 0.15 / pose_r = 1e-3 the tracked rotations came to 1.19 x their bound and crossed it in 14 of 1 500
+                  # runs, the translations to 1.05 x in 1 of 250 -- a one-in-a-hundred red suite; every other bound stays below
+                  # 0.77 x.  The two floors now sit at ~1.6 x the largest excursion seen; the deterministic run keeps 2e-4 / 0.03)
+                  cloud=0.01, pose_t_steps=0.25, pose_r=2e-3, rpe_ate_steps=0.2, rpe_r_deg=0.05, psnr_db=3.0),
     "tight": dict(per_frame=dict(track_first=0.06, track_last=0.06, map_mean=0.04), means=dict(track_first=0.02, track_last=0.02, map_mean=0.015),
                   cloud=0.002, pose_t_steps=0.03, pose_r=2e-4, rpe_ate_steps=0.03, rpe_r_deg=0.01, psnr_db=0.75),
 }
