@@ -155,7 +155,10 @@ static_assert(BIN_SUBS >= 4 && (BIN_SUBS & (BIN_SUBS - 1)) == 0, "bin_slot masks
 // L2 and the key stores' write amplification drops (WRITE_SIZE 51.7 -> 45.3 MB; the rest is the cursor atomics, tallied at 32 B a
 // request) -- but the 64 Gaussians of a wave are neighbours in the image (clouds are initialised in pixel order), so candidates of
 // different Gaussians for the SAME tile then share one cursor instead of spreading over eight, and same-address atomics serialise:
-// bin_scatter 27.7 -> 45.1 us at C2 (profiles/r06_bench_kernel_stats_xcc_sublists.csv).  Not kept.  The per-tile sort orders by
+// bin_scatter 27.7 -> 45.1 us at C2 (profiles/r06_bench_kernel_stats_xcc_sublists.csv).  Not kept.  FSGS_BIN_SUB_XCC=2: the same with the cursor atomic executed in the XCD's own
+// L2 (workgroup scope, no sc1) -- 29.5 -> 46.6 us, no better: it is the shared cursor that serialises, not where the atomic runs
+// (profiles/r06_ab_bin_l2_atomics.txt).  More sub-lists do not help either: FSGS_BIN_SUBS = 16 / 32 -> 50 / 47 us, 4 -> +-0
+// (profiles/r06_ab_bin_subs_and_loss_v2.txt).  The per-tile sort orders by
 // (depth, index), so the sub-list a key sat in never shows in a result either way.
 #ifndef FSGS_BIN_SUB_XCC
 #define FSGS_BIN_SUB_XCC 0
